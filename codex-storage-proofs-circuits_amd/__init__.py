@@ -1,0 +1,474 @@
+"""ctypes binding of libcodex_p2.so (include/codex_p2.h) for tests and bench.py.
+
+This is glue, not the product: the product is the HIP library and its C ABI, with the C++ host
+layer (`host/`) mirroring the reference's Nim interface.  The binding never computes a hash itself and
+has no CPU fallback -- if the library is missing or no gfx950 GPU is usable it raises.
+
+The directory name contains '-', so import it through `__graft_entry__.load_package()`.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcodex_p2.so")
+CLI_PATH = os.path.join(_HERE, "cli")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "codex_p2.h")
+
+CP2_OK = 0
+FELT = 32
+
+
+class CodexP2Error(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        super().__init__("%s failed: status %d%s" % (where, status, (" (" + detail + ")") if detail else ""))
+
+
+class Config(ctypes.Structure):
+    """cp2_config (GlobalConfig + DataSetConfig of reference/nim/proof_input/src/types.nim:82-101)."""
+    _fields_ = [("max_depth", ctypes.c_int32), ("max_log2_nslots", ctypes.c_int32),
+                ("cell_size", ctypes.c_uint64), ("block_size", ctypes.c_uint64),
+                ("n_slots", ctypes.c_uint64), ("n_cells", ctypes.c_uint64),
+                ("n_samples", ctypes.c_uint64), ("seed", ctypes.c_uint64),
+                ("file_base", ctypes.c_char_p)]
+
+
+def build(force=False, verbose=False):
+    """Compile libcodex_p2.so and the cli twin in-tree with hipcc for gfx950."""
+    args = ["make", "-C", _HERE] + (["-B"] if force else [])
+    subprocess.check_call(args, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # PyTorch-ROCm wheels bundle their own libamdhip64; two HIP runtimes in one process do not work
+    # ("No HIP GPUs are available" from whichever comes second).  When torch is installed, load it first
+    # so that this library binds to the runtime torch already mapped (same SONAME).
+    import sys
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, sz, u64, u32, i32, cp = (ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
+                                 ctypes.c_char_p)
+    pvp = ctypes.POINTER(ctypes.c_void_p)
+    sigs = {
+        "cp2_init": (i32, [i32, pvp]),
+        "cp2_free": (None, [vp]),
+        "cp2_set_stream": (i32, [vp, vp]),
+        "cp2_sync": (i32, [vp]),
+        "cp2_strerror": (cp, [i32]),
+        "cp2_last_error": (cp, [vp]),
+        "cp2_device_is_native": (i32, [vp]),
+        "cp2_permute_batch": (i32, [vp, vp, vp, sz]),
+        "cp2_permute_batch_dev": (i32, [vp, vp, vp, sz]),
+        "cp2_compress_batch": (i32, [vp, vp, u32, vp, sz]),
+        "cp2_sponge2_felts": (i32, [vp, vp, sz, vp]),
+        "cp2_sponge2_felts_batch": (i32, [vp, vp, sz, sz, vp]),
+        "cp2_sponge2_felts_batch_dev": (i32, [vp, vp, sz, sz, vp]),
+        "cp2_felts_per_bytes": (sz, [sz]),
+        "cp2_bytes_to_felts": (i32, [vp, sz, vp]),
+        "cp2_hash_cells": (i32, [vp, vp, sz, sz, vp]),
+        "cp2_hash_cells_dev": (i32, [vp, vp, sz, sz, vp]),
+        "cp2_hash_bytes": (i32, [vp, vp, sz, vp]),
+        "cp2_merkle_total": (sz, [sz]),
+        "cp2_merkle_num_layers": (sz, [sz]),
+        "cp2_merkle_tree": (i32, [vp, vp, sz, vp, ctypes.POINTER(sz), ctypes.POINTER(sz)]),
+        "cp2_merkle_trees_dev": (i32, [vp, vp, sz, sz, vp]),
+        "cp2_merkle_root": (i32, [vp, vp, sz, vp]),
+        "cp2_slot_seed": (u64, [u64, u64]),
+        "cp2_gen_fake_cells": (i32, [vp, u64, u64, sz, sz, vp]),
+        "cp2_gen_fake_cells_dev": (i32, [vp, u64, u64, sz, sz, vp]),
+        "cp2_cell_indices": (i32, [vp, vp, vp, u64, sz, vp]),
+        "cp2_slot_trees_build_fake": (i32, [vp, u64, u64, sz, sz, sz, sz, pvp]),
+        "cp2_slot_trees_build_dev": (i32, [vp, vp, sz, sz, sz, sz, pvp]),
+        "cp2_slot_trees_build_host": (i32, [vp, vp, sz, sz, sz, sz, pvp]),
+        "cp2_slot_trees_free": (None, [vp]),
+        "cp2_slot_trees_count": (sz, [vp]),
+        "cp2_slot_trees_depth": (sz, [vp]),
+        "cp2_slot_trees_roots": (i32, [vp, vp]),
+        "cp2_slot_trees_roots_dev": (vp, [vp]),
+        "cp2_slot_trees_paths": (i32, [vp, sz, vp, sz, sz, vp, vp]),
+        "cp2_dataset_build": (i32, [vp, ctypes.POINTER(Config), u64, u64, pvp]),
+        "cp2_dataset_free": (None, [vp]),
+        "cp2_dataset_local_roots": (i32, [vp, vp]),
+        "cp2_dataset_set_roots": (i32, [vp, vp]),
+        "cp2_dataset_root": (i32, [vp, vp]),
+        "cp2_proof_input_generate": (i32, [vp, u64, vp, pvp]),
+        "cp2_proof_input_free": (None, [vp]),
+        "cp2_proof_input_roots": (i32, [vp, vp, vp, vp]),
+        "cp2_proof_input_nsamples": (sz, [vp]),
+        "cp2_proof_input_cell_indices": (vp, [vp]),
+        "cp2_proof_input_cell_data": (vp, [vp]),
+        "cp2_proof_input_merkle_paths": (vp, [vp]),
+        "cp2_proof_input_slot_proof": (vp, [vp]),
+        "cp2_proof_input_write_json": (i32, [vp, cp]),
+        "cp2_proof_input_json": (i32, [vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz)]),
+        "cp2_free_buffer": (None, [vp]),
+        "cp2_write_circom_main": (i32, [ctypes.POINTER(Config), cp]),
+    }
+    for name, (res, args) in sigs.items():
+        f = getattr(L, name)   # AttributeError if the header and the library ever disagree
+        f.restype, f.argtypes = res, args
+    L._cp2_signatures = sigs
+    _lib = L
+    return L
+
+
+def exported_symbols():
+    """Names declared in include/codex_p2.h (parsed from the header text)."""
+    import re
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cp2_[a-z0-9_]+)\s*\(", text)))
+
+
+def _u8(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.uint8))
+
+
+def _p(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def felt_bytes(x):
+    return np.frombuffer(int(x).to_bytes(32, "little"), dtype=np.uint8).copy()
+
+
+def felts_to_array(xs):
+    out = np.zeros((len(xs), 32), dtype=np.uint8)
+    for i, x in enumerate(xs):
+        out[i] = felt_bytes(x)
+    return out
+
+
+def array_to_felts(a):
+    a = _u8(a).reshape(-1, 32)
+    return [int.from_bytes(a[i].tobytes(), "little") for i in range(a.shape[0])]
+
+
+class Context:
+    """One cp2_ctx.  Host-array methods mirror the host-pointer ABI; *_dev methods take raw device pointers."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        h = ctypes.c_void_p()
+        st = self.L.cp2_init(device, ctypes.byref(h))
+        if st != CP2_OK:
+            raise CodexP2Error(st, "cp2_init", self.L.cp2_strerror(st).decode())
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.cp2_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, st, where):
+        if st != CP2_OK:
+            raise CodexP2Error(st, where, self.L.cp2_last_error(self.h).decode() or self.L.cp2_strerror(st).decode())
+
+    # -- plumbing
+    def set_stream(self, stream_ptr):
+        self._ck(self.L.cp2_set_stream(self.h, ctypes.c_void_p(stream_ptr)), "cp2_set_stream")
+
+    def sync(self):
+        self._ck(self.L.cp2_sync(self.h), "cp2_sync")
+
+    # -- a1
+    def permute_batch(self, states):
+        s = _u8(states).reshape(-1, 96)
+        out = np.empty_like(s)
+        self._ck(self.L.cp2_permute_batch(self.h, _p(s), _p(out), s.shape[0]), "cp2_permute_batch")
+        return out
+
+    def permute_batch_dev(self, d_in, d_out, n):
+        self._ck(self.L.cp2_permute_batch_dev(self.h, ctypes.c_void_p(d_in), ctypes.c_void_p(d_out), n), "cp2_permute_batch_dev")
+
+    # -- a6
+    def compress_batch(self, xy, key):
+        a = _u8(xy).reshape(-1, 64)
+        out = np.empty((a.shape[0], 32), dtype=np.uint8)
+        self._ck(self.L.cp2_compress_batch(self.h, _p(a), key, _p(out), a.shape[0]), "cp2_compress_batch")
+        return out
+
+    # -- a3
+    def sponge2_felts(self, felts):
+        f = _u8(felts).reshape(-1, 32)
+        out = np.empty(32, dtype=np.uint8)
+        self._ck(self.L.cp2_sponge2_felts(self.h, _p(f) if f.size else None, f.shape[0], _p(out)), "cp2_sponge2_felts")
+        return out
+
+    def sponge2_felts_batch(self, felts, nf):
+        f = _u8(felts).reshape(-1, 32)
+        nitems = f.shape[0] // nf if nf else 0
+        out = np.empty((nitems, 32), dtype=np.uint8)
+        self._ck(self.L.cp2_sponge2_felts_batch(self.h, _p(f), nf, nitems, _p(out)), "cp2_sponge2_felts_batch")
+        return out
+
+    # -- a4
+    def bytes_to_felts(self, data):
+        d = _u8(np.frombuffer(bytes(data), dtype=np.uint8))
+        n = self.L.cp2_felts_per_bytes(d.size)
+        out = np.empty((n, 32), dtype=np.uint8)
+        self._ck(self.L.cp2_bytes_to_felts(_p(d) if d.size else None, d.size, _p(out)), "cp2_bytes_to_felts")
+        return out
+
+    # -- a5
+    def hash_cells(self, cells, cell_size):
+        c = _u8(cells).reshape(-1)
+        n = c.size // cell_size if cell_size else 0
+        out = np.empty((n, 32), dtype=np.uint8)
+        self._ck(self.L.cp2_hash_cells(self.h, _p(c), cell_size, n, _p(out)), "cp2_hash_cells")
+        return out
+
+    def hash_cells_dev(self, d_cells, cell_size, n_cells, d_out):
+        self._ck(self.L.cp2_hash_cells_dev(self.h, ctypes.c_void_p(d_cells), cell_size, n_cells, ctypes.c_void_p(d_out)), "cp2_hash_cells_dev")
+
+    def hash_bytes(self, data):
+        d = _u8(np.frombuffer(bytes(data), dtype=np.uint8))
+        out = np.empty(32, dtype=np.uint8)
+        self._ck(self.L.cp2_hash_bytes(self.h, _p(d) if d.size else None, d.size, _p(out)), "cp2_hash_bytes")
+        return out
+
+    # -- a7
+    def merkle_tree(self, leaves):
+        lv = _u8(leaves).reshape(-1, 32)
+        n = lv.shape[0]
+        total = self.L.cp2_merkle_total(n)
+        out = np.empty((total, 32), dtype=np.uint8)
+        sizes = (ctypes.c_size_t * 80)()
+        nl = ctypes.c_size_t()
+        self._ck(self.L.cp2_merkle_tree(self.h, _p(lv) if n else None, n, _p(out), sizes, ctypes.byref(nl)), "cp2_merkle_tree")
+        layers, off = [], 0
+        for i in range(nl.value):
+            layers.append(out[off:off + sizes[i]])
+            off += sizes[i]
+        return layers
+
+    def merkle_trees_dev(self, d_leaves, n, nseg, d_layers):
+        self._ck(self.L.cp2_merkle_trees_dev(self.h, ctypes.c_void_p(d_leaves), n, nseg, ctypes.c_void_p(d_layers)), "cp2_merkle_trees_dev")
+
+    def merkle_root(self, leaves):
+        lv = _u8(leaves).reshape(-1, 32)
+        out = np.empty(32, dtype=np.uint8)
+        self._ck(self.L.cp2_merkle_root(self.h, _p(lv) if lv.size else None, lv.shape[0], _p(out)), "cp2_merkle_root")
+        return out
+
+    # -- a10
+    def slot_seed(self, seed, slot_idx):
+        return self.L.cp2_slot_seed(seed, slot_idx)
+
+    def gen_fake_cells(self, seed, first, n, cell_size):
+        out = np.empty((n, cell_size), dtype=np.uint8)
+        self._ck(self.L.cp2_gen_fake_cells(self.h, seed, first, n, cell_size, _p(out)), "cp2_gen_fake_cells")
+        return out
+
+    def gen_fake_cells_dev(self, seed, first, n, cell_size, d_out):
+        self._ck(self.L.cp2_gen_fake_cells_dev(self.h, seed, first, n, cell_size, ctypes.c_void_p(d_out)), "cp2_gen_fake_cells_dev")
+
+    # -- a12
+    def cell_indices(self, entropy, slot_root, n_cells, n_samples):
+        e, r = _u8(entropy), _u8(slot_root)
+        out = np.empty(n_samples, dtype=np.uint64)
+        self._ck(self.L.cp2_cell_indices(self.h, _p(e), _p(r), n_cells, n_samples, _p(out)), "cp2_cell_indices")
+        return out
+
+    # -- slot trees
+    def slot_trees_fake(self, dataset_seed, first_slot, n_slots, cell_size, block_size, n_cells):
+        h = ctypes.c_void_p()
+        self._ck(self.L.cp2_slot_trees_build_fake(self.h, dataset_seed, first_slot, n_slots, cell_size, block_size, n_cells,
+                                                  ctypes.byref(h)), "cp2_slot_trees_build_fake")
+        return SlotTrees(self, h)
+
+    def slot_trees_dev(self, d_cells, n_slots, cell_size, block_size, n_cells):
+        h = ctypes.c_void_p()
+        self._ck(self.L.cp2_slot_trees_build_dev(self.h, ctypes.c_void_p(d_cells), n_slots, cell_size, block_size, n_cells,
+                                                 ctypes.byref(h)), "cp2_slot_trees_build_dev")
+        return SlotTrees(self, h)
+
+    def slot_trees_host(self, cells, n_slots, cell_size, block_size, n_cells):
+        c = _u8(cells).reshape(-1)
+        h = ctypes.c_void_p()
+        self._ck(self.L.cp2_slot_trees_build_host(self.h, _p(c), n_slots, cell_size, block_size, n_cells, ctypes.byref(h)),
+                 "cp2_slot_trees_build_host")
+        t = SlotTrees(self, h)
+        t._keep = c   # the library keeps the host pointer for sampled-cell retrieval
+        return t
+
+    # -- dataset / proof input
+    def dataset(self, cfg, first_slot=0, n_local=None):
+        return Dataset(self, cfg, first_slot, cfg.n_slots if n_local is None else n_local)
+
+
+def make_config(maxDepth=32, maxLog2NSlots=8, cellSize=2048, blockSize=65536, nSlots=11, nCells=256, nSamples=5,
+                seed=12345, file=None):
+    """Defaults are the reference CLI's (reference/nim/proof_input/src/cli.nim:47-76)."""
+    c = Config()
+    c.max_depth, c.max_log2_nslots = maxDepth, maxLog2NSlots
+    c.cell_size, c.block_size = cellSize, blockSize
+    c.n_slots, c.n_cells, c.n_samples, c.seed = nSlots, nCells, nSamples, seed
+    c.file_base = file.encode() if file else None
+    return c
+
+
+class SlotTrees:
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def free(self):
+        if self.h:
+            self.ctx.L.cp2_slot_trees_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    @property
+    def count(self):
+        return self.ctx.L.cp2_slot_trees_count(self.h)
+
+    @property
+    def depth(self):
+        return self.ctx.L.cp2_slot_trees_depth(self.h)
+
+    def roots(self):
+        out = np.empty((self.count, 32), dtype=np.uint8)
+        self.ctx._ck(self.ctx.L.cp2_slot_trees_roots(self.h, _p(out)), "cp2_slot_trees_roots")
+        return out
+
+    def roots_dev(self):
+        return self.ctx.L.cp2_slot_trees_roots_dev(self.h)
+
+    def paths(self, slot, cell_idx, max_depth):
+        idx = np.ascontiguousarray(np.asarray(cell_idx, dtype=np.uint64))
+        out = np.empty((idx.size, max_depth, 32), dtype=np.uint8)
+        leaves = np.empty((idx.size, 32), dtype=np.uint8)
+        self.ctx._ck(self.ctx.L.cp2_slot_trees_paths(self.h, slot, _p(idx), idx.size, max_depth, _p(out), _p(leaves)),
+                     "cp2_slot_trees_paths")
+        return out, leaves
+
+
+class Dataset:
+    def __init__(self, ctx, cfg, first_slot, n_local):
+        self.ctx, self.cfg = ctx, cfg
+        h = ctypes.c_void_p()
+        ctx._ck(ctx.L.cp2_dataset_build(ctx.h, ctypes.byref(cfg), first_slot, n_local, ctypes.byref(h)), "cp2_dataset_build")
+        self.h, self.first_slot, self.n_local = h, first_slot, n_local
+
+    def free(self):
+        if self.h:
+            self.ctx.L.cp2_dataset_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def local_roots(self):
+        out = np.empty((self.n_local, 32), dtype=np.uint8)
+        self.ctx._ck(self.ctx.L.cp2_dataset_local_roots(self.h, _p(out)), "cp2_dataset_local_roots")
+        return out
+
+    def set_roots(self, all_roots=None):
+        if all_roots is None:
+            self.ctx._ck(self.ctx.L.cp2_dataset_set_roots(self.h, None), "cp2_dataset_set_roots")
+        else:
+            r = _u8(all_roots).reshape(-1, 32)
+            assert r.shape[0] == self.cfg.n_slots
+            self.ctx._ck(self.ctx.L.cp2_dataset_set_roots(self.h, _p(r)), "cp2_dataset_set_roots")
+
+    def root(self):
+        out = np.empty(32, dtype=np.uint8)
+        self.ctx._ck(self.ctx.L.cp2_dataset_root(self.h, _p(out)), "cp2_dataset_root")
+        return out
+
+    def proof_input(self, slot_idx, entropy):
+        e = _u8(entropy if not isinstance(entropy, int) else felt_bytes(entropy))
+        h = ctypes.c_void_p()
+        self.ctx._ck(self.ctx.L.cp2_proof_input_generate(self.h, slot_idx, _p(e), ctypes.byref(h)), "cp2_proof_input_generate")
+        return ProofInput(self.ctx, h, self.cfg)
+
+
+class ProofInput:
+    def __init__(self, ctx, h, cfg):
+        self.ctx, self.h, self.cfg = ctx, h, cfg
+
+    def free(self):
+        if self.h:
+            self.ctx.L.cp2_proof_input_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def _arr(self, ptr, shape, dtype=np.uint8):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        if n == 0:
+            return np.zeros(shape, dtype=dtype)
+        buf = (ctypes.c_uint8 * n).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape).copy()
+
+    def roots(self):
+        d, s, e = (np.empty(32, dtype=np.uint8) for _ in range(3))
+        self.ctx._ck(self.ctx.L.cp2_proof_input_roots(self.h, _p(d), _p(s), _p(e)), "cp2_proof_input_roots")
+        return d, s, e
+
+    def cell_indices(self):
+        n = self.ctx.L.cp2_proof_input_nsamples(self.h)
+        return self._arr(self.ctx.L.cp2_proof_input_cell_indices(self.h), (n,), np.uint64)
+
+    def cell_data(self):
+        n = self.ctx.L.cp2_proof_input_nsamples(self.h)
+        return self._arr(self.ctx.L.cp2_proof_input_cell_data(self.h), (n, self.cfg.cell_size))
+
+    def merkle_paths(self):
+        n = self.ctx.L.cp2_proof_input_nsamples(self.h)
+        return self._arr(self.ctx.L.cp2_proof_input_merkle_paths(self.h), (n, self.cfg.max_depth, 32))
+
+    def slot_proof(self):
+        return self._arr(self.ctx.L.cp2_proof_input_slot_proof(self.h), (self.cfg.max_log2_nslots, 32))
+
+    def json(self):
+        text, ln = ctypes.c_void_p(), ctypes.c_size_t()
+        self.ctx._ck(self.ctx.L.cp2_proof_input_json(self.h, ctypes.byref(text), ctypes.byref(ln)), "cp2_proof_input_json")
+        s = ctypes.string_at(text, ln.value).decode()
+        self.ctx.L.cp2_free_buffer(text)
+        return s
+
+    def write_json(self, path):
+        self.ctx._ck(self.ctx.L.cp2_proof_input_write_json(self.h, path.encode()), "cp2_proof_input_write_json")
+
+
+def write_circom_main(cfg, path):
+    L = load_library()
+    st = L.cp2_write_circom_main(ctypes.byref(cfg), path.encode())
+    if st != CP2_OK:
+        raise CodexP2Error(st, "cp2_write_circom_main", L.cp2_strerror(st).decode())

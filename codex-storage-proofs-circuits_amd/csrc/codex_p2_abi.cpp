@@ -1,0 +1,314 @@
+// C ABI of libcodex_p2.so (include/codex_p2.h): contexts, device memory, kernel sequencing.
+// No CPU fallback lives here: every hash goes through the HIP kernels of kernels.hip.
+#include "../../include/codex_p2.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "internal.hpp"
+#include "kernels.hpp"
+
+using namespace cp2i;
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+extern "C" int cp2_init(int device, cp2_ctx** out) {
+  if (!out) return CP2_ERR_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return CP2_ERR_NO_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return CP2_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return CP2_ERR_NO_DEVICE;
+  cp2_ctx* c = new (std::nothrow) cp2_ctx();
+  if (!c) return CP2_ERR_ALLOC;
+  c->device = device;
+  c->native = std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+  if (!c->native) {   // the code object only holds gfx950 ISA: fail loudly instead of faulting at launch
+    delete c;
+    return CP2_ERR_NO_DEVICE;
+  }
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return CP2_ERR_HIP;
+  }
+  c->stream = c->own_stream;
+  *out = c;
+  return CP2_OK;
+}
+
+extern "C" void cp2_free(cp2_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+extern "C" int cp2_set_stream(cp2_ctx* ctx, void* hip_stream) {
+  if (!ctx) return CP2_ERR_INVALID;
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return CP2_OK;
+}
+
+extern "C" int cp2_sync(cp2_ctx* ctx) {
+  if (!ctx) return CP2_ERR_INVALID;
+  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return CP2_OK;
+}
+
+extern "C" const char* cp2_strerror(int status) {
+  switch (status) {
+    case CP2_OK: return "ok";
+    case CP2_ERR_INVALID: return "invalid argument";
+    case CP2_ERR_NO_DEVICE: return "no usable gfx950 HIP device";
+    case CP2_ERR_HIP: return "HIP runtime error";
+    case CP2_ERR_ALLOC: return "allocation failed";
+    case CP2_ERR_IO: return "I/O error";
+    case CP2_ERR_ALIGN: return "device pointer not 16-byte aligned";
+    default: return "unknown status";
+  }
+}
+
+extern "C" const char* cp2_last_error(const cp2_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+extern "C" int cp2_device_is_native(const cp2_ctx* ctx) { return ctx && ctx->native ? 1 : 0; }
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---------------------------------------------------------------------------------------------
+// a1 permutation
+// ---------------------------------------------------------------------------------------------
+extern "C" int cp2_permute_batch_dev(cp2_ctx* ctx, const void* d_in, void* d_out, size_t n) {
+  if (!ctx || (n && (!d_in || !d_out))) return CP2_ERR_INVALID;
+  if (!aligned16(d_in) || !aligned16(d_out)) return CP2_ERR_ALIGN;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  CP2_HIP(ctx, cp2k::launch_permute_batch(d_in, d_out, n, ctx->stream));
+  return CP2_OK;
+}
+
+extern "C" int cp2_permute_batch(cp2_ctx* ctx, const uint8_t* in, uint8_t* out, size_t n) {
+  if (!ctx || (n && (!in || !out))) return CP2_ERR_INVALID;
+  if (n == 0) return CP2_OK;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  DevBuf d_in, d_out;
+  CP2_TRY(d_in.alloc(ctx, n * 96));
+  CP2_TRY(d_out.alloc(ctx, n * 96));
+  CP2_HIP(ctx, hipMemcpyAsync(d_in.p, in, n * 96, hipMemcpyHostToDevice, ctx->stream));
+  CP2_TRY(cp2_permute_batch_dev(ctx, d_in.p, d_out.p, n));
+  CP2_HIP(ctx, hipMemcpyAsync(out, d_out.p, n * 96, hipMemcpyDeviceToHost, ctx->stream));
+  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return CP2_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a6 keyed compression
+// ---------------------------------------------------------------------------------------------
+extern "C" int cp2_compress_batch(cp2_ctx* ctx, const uint8_t* xy, uint32_t key, uint8_t* out, size_t n) {
+  if (!ctx || key > 3 || (n && (!xy || !out))) return CP2_ERR_INVALID;
+  if (n == 0) return CP2_OK;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  // build (x, y, key) states and run the permutation kernel; keep the first element of each result
+  std::vector<uint8_t> st(n * 96, 0), res(n * 96);
+  for (size_t i = 0; i < n; ++i) {
+    std::memcpy(&st[96 * i], xy + 64 * i, 64);
+    st[96 * i + 64] = (uint8_t)key;
+  }
+  CP2_TRY(cp2_permute_batch(ctx, st.data(), res.data(), n));
+  for (size_t i = 0; i < n; ++i) std::memcpy(out + 32 * i, &res[96 * i], 32);
+  return CP2_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a3 sponge over field elements
+// ---------------------------------------------------------------------------------------------
+extern "C" int cp2_sponge2_felts_batch_dev(cp2_ctx* ctx, const void* d_felts, size_t nf, size_t nitems, void* d_out) {
+  if (!ctx || (nitems && (!d_out || (nf && !d_felts)))) return CP2_ERR_INVALID;
+  if (!aligned16(d_felts) || !aligned16(d_out)) return CP2_ERR_ALIGN;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  CP2_HIP(ctx, cp2k::launch_sponge2_felts(d_felts, nf, nitems, d_out, ctx->stream));
+  return CP2_OK;
+}
+
+extern "C" int cp2_sponge2_felts_batch(cp2_ctx* ctx, const uint8_t* felts, size_t nf, size_t nitems, uint8_t* out) {
+  if (!ctx || (nitems && (!out || (nf && !felts)))) return CP2_ERR_INVALID;
+  if (nitems == 0) return CP2_OK;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  DevBuf d_in, d_out;
+  CP2_TRY(d_in.alloc(ctx, std::max<size_t>(nf * nitems * 32, 32)));
+  CP2_TRY(d_out.alloc(ctx, nitems * 32));
+  if (nf) CP2_HIP(ctx, hipMemcpyAsync(d_in.p, felts, nf * nitems * 32, hipMemcpyHostToDevice, ctx->stream));
+  CP2_TRY(cp2_sponge2_felts_batch_dev(ctx, d_in.p, nf, nitems, d_out.p));
+  CP2_HIP(ctx, hipMemcpyAsync(out, d_out.p, nitems * 32, hipMemcpyDeviceToHost, ctx->stream));
+  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return CP2_OK;
+}
+
+extern "C" int cp2_sponge2_felts(cp2_ctx* ctx, const uint8_t* felts, size_t n, uint8_t out[32]) {
+  return cp2_sponge2_felts_batch(ctx, felts, n, 1, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// a4 bytes -> field elements (pure byte packing, host)
+// ---------------------------------------------------------------------------------------------
+extern "C" size_t cp2_felts_per_bytes(size_t len) { return (len + 1 + 30) / 31; }
+
+extern "C" int cp2_bytes_to_felts(const uint8_t* data, size_t len, uint8_t* out) {
+  if ((len && !data) || !out) return CP2_ERR_INVALID;
+  size_t n = cp2_felts_per_bytes(len);
+  std::memset(out, 0, n * 32);
+  for (size_t k = 0; k < n; ++k) {
+    for (size_t i = 0; i < 31; ++i) {
+      size_t pos = 31 * k + i;
+      if (pos < len) out[32 * k + i] = data[pos];
+      else if (pos == len) out[32 * k + i] = 0x01;
+    }
+  }
+  return CP2_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a5 hashCell
+// ---------------------------------------------------------------------------------------------
+extern "C" int cp2_hash_cells_dev(cp2_ctx* ctx, const void* d_cells, size_t cell_size, size_t n_cells, void* d_out) {
+  if (!ctx || (n_cells && (!d_out || (cell_size && !d_cells)))) return CP2_ERR_INVALID;
+  if (!aligned16(d_out)) return CP2_ERR_ALIGN;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  CP2_HIP(ctx, cp2k::launch_hash_cells(d_cells, cell_size, n_cells, d_out, ctx->stream));
+  return CP2_OK;
+}
+
+extern "C" int cp2_hash_cells(cp2_ctx* ctx, const uint8_t* cells, size_t cell_size, size_t n_cells, uint8_t* out) {
+  if (!ctx || (n_cells && (!out || (cell_size && !cells)))) return CP2_ERR_INVALID;
+  if (n_cells == 0) return CP2_OK;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  DevBuf d_in, d_out;
+  CP2_TRY(d_in.alloc(ctx, std::max<size_t>(cell_size * n_cells, 16)));
+  CP2_TRY(d_out.alloc(ctx, n_cells * 32));
+  if (cell_size) CP2_HIP(ctx, hipMemcpyAsync(d_in.p, cells, cell_size * n_cells, hipMemcpyHostToDevice, ctx->stream));
+  CP2_TRY(cp2_hash_cells_dev(ctx, d_in.p, cell_size, n_cells, d_out.p));
+  CP2_HIP(ctx, hipMemcpyAsync(out, d_out.p, n_cells * 32, hipMemcpyDeviceToHost, ctx->stream));
+  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return CP2_OK;
+}
+
+extern "C" int cp2_hash_bytes(cp2_ctx* ctx, const uint8_t* data, size_t len, uint8_t out[32]) {
+  return cp2_hash_cells(ctx, data, len, 1, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// a7 Merkle trees
+// ---------------------------------------------------------------------------------------------
+extern "C" size_t cp2_merkle_num_layers(size_t n) { return layer_sizes_of(n).size(); }
+
+extern "C" size_t cp2_merkle_total(size_t n) {
+  size_t t = 0;
+  for (size_t m : layer_sizes_of(n)) t += m;
+  return t;
+}
+
+// layer-major: layer k of all nseg trees is contiguous, tree s at s * size_k inside it
+int cp2i::merkle_trees_dev(cp2_ctx* ctx, const void* d_leaves, size_t n, size_t nseg, void* d_layers_out,
+                           bool leaves_in_place) {
+  if (n == 0 || nseg == 0) return CP2_OK;
+  std::vector<size_t> sizes = layer_sizes_of(n);
+  uint8_t* base = static_cast<uint8_t*>(d_layers_out);
+  if (!leaves_in_place)
+    CP2_HIP(ctx, hipMemcpyAsync(base, d_leaves, n * nseg * 32, hipMemcpyDeviceToDevice, ctx->stream));
+  size_t off = 0;
+  for (size_t k = 0; k + 1 < sizes.size(); ++k) {
+    const uint8_t* in = base + off * 32;
+    uint8_t* out = base + (off + sizes[k] * nseg) * 32;
+    CP2_HIP(ctx, cp2k::launch_compress_layer(in, out, sizes[k], nseg, k == 0, sizes[k], sizes[k + 1], ctx->stream));
+    off += sizes[k] * nseg;
+  }
+  return CP2_OK;
+}
+
+extern "C" int cp2_merkle_trees_dev(cp2_ctx* ctx, const void* d_leaves, size_t n, size_t nseg, void* d_layers_out) {
+  if (!ctx || !d_leaves || !d_layers_out) return CP2_ERR_INVALID;
+  if (!aligned16(d_leaves) || !aligned16(d_layers_out)) return CP2_ERR_ALIGN;
+  if (n == 0) return CP2_ERR_INVALID;   // Merkle.hs:72 "input is empty"
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  return merkle_trees_dev(ctx, d_leaves, n, nseg, d_layers_out, d_leaves == d_layers_out);
+}
+
+extern "C" int cp2_merkle_tree(cp2_ctx* ctx, const uint8_t* leaves, size_t n, uint8_t* layers_out, size_t* layer_sizes,
+                               size_t* n_layers) {
+  if (!ctx || !leaves || !layers_out || n == 0) return CP2_ERR_INVALID;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<size_t> sizes = layer_sizes_of(n);
+  size_t total = cp2_merkle_total(n);
+  DevBuf d;
+  CP2_TRY(d.alloc(ctx, total * 32));
+  CP2_HIP(ctx, hipMemcpyAsync(d.p, leaves, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  CP2_TRY(merkle_trees_dev(ctx, d.p, n, 1, d.p, true));
+  CP2_HIP(ctx, hipMemcpyAsync(layers_out, d.p, total * 32, hipMemcpyDeviceToHost, ctx->stream));
+  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (layer_sizes) std::copy(sizes.begin(), sizes.end(), layer_sizes);
+  if (n_layers) *n_layers = sizes.size();
+  return CP2_OK;
+}
+
+extern "C" int cp2_merkle_root(cp2_ctx* ctx, const uint8_t* leaves, size_t n, uint8_t out[32]) {
+  if (!ctx || !leaves || !out || n == 0) return CP2_ERR_INVALID;
+  size_t total = cp2_merkle_total(n);
+  std::vector<uint8_t> layers(total * 32);
+  CP2_TRY(cp2_merkle_tree(ctx, leaves, n, layers.data(), nullptr, nullptr));
+  std::memcpy(out, &layers[(total - 1) * 32], 32);
+  return CP2_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a10 fake data
+// ---------------------------------------------------------------------------------------------
+extern "C" uint64_t cp2_slot_seed(uint64_t dataset_seed, uint64_t slot_idx) { return dataset_seed + 72 + 1001 * slot_idx; }
+
+extern "C" int cp2_gen_fake_cells_dev(cp2_ctx* ctx, uint64_t seed, uint64_t first, size_t n, size_t cell_size, void* d_out) {
+  if (!ctx || (n && cell_size && !d_out)) return CP2_ERR_INVALID;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  CP2_HIP(ctx, cp2k::launch_gen_fake_cells(seed, 0, first, nullptr, n, cell_size, d_out, ctx->stream));
+  return CP2_OK;
+}
+
+extern "C" int cp2_gen_fake_cells(cp2_ctx* ctx, uint64_t seed, uint64_t first, size_t n, size_t cell_size, uint8_t* out) {
+  if (!ctx || (n && cell_size && !out)) return CP2_ERR_INVALID;
+  if (n == 0 || cell_size == 0) return CP2_OK;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  DevBuf d;
+  CP2_TRY(d.alloc(ctx, n * cell_size));
+  CP2_TRY(cp2_gen_fake_cells_dev(ctx, seed, first, n, cell_size, d.p));
+  CP2_HIP(ctx, hipMemcpyAsync(out, d.p, n * cell_size, hipMemcpyDeviceToHost, ctx->stream));
+  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return CP2_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a12 sampling
+// ---------------------------------------------------------------------------------------------
+extern "C" int cp2_cell_indices(cp2_ctx* ctx, const uint8_t entropy[32], const uint8_t slot_root[32], uint64_t n_cells,
+                                size_t n_samples, uint64_t* out) {
+  if (!ctx || !entropy || !slot_root || (n_samples && !out)) return CP2_ERR_INVALID;
+  if (n_cells == 0 || (n_cells & (n_cells - 1)) != 0) return CP2_ERR_INVALID;   // sample/bn254.nim:19-20
+  if (n_samples == 0) return CP2_OK;
+  std::vector<uint8_t> felts(n_samples * 96, 0), dig(n_samples * 32);
+  for (size_t i = 0; i < n_samples; ++i) {
+    std::memcpy(&felts[96 * i], entropy, 32);
+    std::memcpy(&felts[96 * i + 32], slot_root, 32);
+    uint64_t counter = i + 1;                                                    // sample/bn254.nim:27
+    std::memcpy(&felts[96 * i + 64], &counter, 8);
+  }
+  CP2_TRY(cp2_sponge2_felts_batch(ctx, felts.data(), 3, n_samples, dig.data()));
+  for (size_t i = 0; i < n_samples; ++i) {
+    uint64_t lo;
+    std::memcpy(&lo, &dig[32 * i], 8);                                           // extractLowBits, types/bn254.nim:47-59
+    out[i] = lo & (n_cells - 1);
+  }
+  return CP2_OK;
+}

@@ -1,0 +1,223 @@
+// BN254 scalar-field (Fr) arithmetic for gfx950 (MI355X), one field element per lane.
+//
+// Representation: 9 limbs x 29 bits in 32-bit VGPRs ("redundant radix"), Montgomery radix R = 2^261.
+// Why this and not 8 x 32-bit limbs: tools/ubench_valu.hip measured v_mad_u64_u32 on gfx950 at about the
+// same issue cost as any other VOP3 instruction (it is NOT quarter rate, and v_fma_f64 is no faster), so
+// the kernel is bound by the NUMBER of VALU instructions.  With 29-bit limbs a whole column of partial
+// products (9 of a*b plus 9 of m*N) fits a 64-bit accumulator, so every partial product is exactly one
+// v_mad_u64_u32 with the accumulator as both addend and destination: no carry flags, no v_addc, no moves.
+// Saturated 32-bit limbs need a third accumulator word and one v_addc per product (2 instructions each).
+//
+// Bounds (U = 2^29, N = field modulus, R = 2^261 ~ 169.3 N):
+//   * a limb vector is "normalized" when limbs 0..7 < U + 8 (and the top limb is small);
+//   * mont_mul / mont_sqr accept limbs up to 2.47 U on either operand (column sum
+//       2^35 + 9*La*Lb + 9*U*U < 2^64 needs La*Lb < 6.1 U^2) and produce limbs 0..7 < U;
+//   * value bound: out < A*B/R + N, so inputs below 13 N give outputs below 2 N and no
+//     conditional subtraction is ever needed inside a chain (lazy Montgomery).
+//
+// What the reference computes with this arithmetic: Permutation.hs:14-45 (field ops of
+// zikkurat-algebra / constantine there).  Nothing here is derived from those libraries' code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fr {
+
+#include "p2_consts_dev.inc"
+
+constexpr int NL = 9;
+constexpr uint32_t U29 = 1u << 29;
+constexpr uint32_t MASK = U29 - 1;
+
+struct Fe {
+  uint32_t l[NL];
+};
+
+__device__ __forceinline__ Fe fe_const(const uint32_t (&c)[9]) {
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = c[i];
+  return r;
+}
+
+__device__ __forceinline__ Fe fe_zero() {
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = 0;
+  return r;
+}
+
+// limb-wise lazy add (no carry propagation): limb bounds add
+__device__ __forceinline__ Fe add_lazy(const Fe& a, const Fe& b) {
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = a.l[i] + b.l[i];
+  return r;
+}
+
+// one parallel carry step: limbs (< 2^32) -> limbs 0..7 < U + 8, value unchanged
+__device__ __forceinline__ Fe norm(const Fe& a) {
+  Fe r;
+  r.l[0] = a.l[0] & MASK;
+#pragma unroll
+  for (int i = 1; i < NL - 1; ++i) r.l[i] = (a.l[i] & MASK) + (a.l[i - 1] >> 29);
+  r.l[NL - 1] = a.l[NL - 1] + (a.l[NL - 2] >> 29);
+  return r;
+}
+
+// full sequential carry propagation: limbs 0..7 < U exactly
+__device__ __forceinline__ Fe norm_full(const Fe& a) {
+  Fe r;
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < NL - 1; ++i) {
+    uint32_t t = a.l[i] + c;
+    r.l[i] = t & MASK;
+    c = t >> 29;
+  }
+  r.l[NL - 1] = a.l[NL - 1] + c;
+  return r;
+}
+
+// Montgomery product a*b/R (finely integrated product scanning, 17 columns).
+__device__ __forceinline__ Fe mont_mul(const Fe& a, const Fe& b) {
+  Fe r;
+  uint32_t m[NL];
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * FR_N[k - i];
+    m[k] = ((uint32_t)acc * FR_NPRIME) & MASK;
+    acc += (uint64_t)m[k] * FR_N[0];
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) acc += (uint64_t)m[i] * FR_N[k - i];
+    r.l[k - NL] = (uint32_t)acc & MASK;
+    acc >>= 29;
+  }
+  r.l[NL - 1] = (uint32_t)acc;
+  return r;
+}
+
+// Montgomery square a*a/R: 45 products instead of 81 (cross terms against the doubled operand).
+__device__ __forceinline__ Fe mont_sqr(const Fe& a) {
+  Fe r;
+  uint32_t m[NL], d[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) d[i] = a.l[i] << 1;   // limbs < 2.47 U  =>  doubled < 2^32
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+#pragma unroll
+    for (int i = 0; 2 * i < k; ++i) acc += (uint64_t)a.l[i] * d[k - i];
+    if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+    for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * FR_N[k - i];
+    m[k] = ((uint32_t)acc * FR_NPRIME) & MASK;
+    acc += (uint64_t)m[k] * FR_N[0];
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+    for (int i = k - NL + 1; 2 * i < k; ++i) acc += (uint64_t)a.l[i] * d[k - i];
+    if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) acc += (uint64_t)m[i] * FR_N[k - i];
+    r.l[k - NL] = (uint32_t)acc & MASK;
+    acc >>= 29;
+  }
+  r.l[NL - 1] = (uint32_t)acc;
+  return r;
+}
+
+// x^5 (Permutation.hs:14-17).  Input limbs < 2.47 U, value < 13 N; output normalized, value < 1.1 N.
+__device__ __forceinline__ Fe sbox(const Fe& x) {
+  Fe x2 = mont_sqr(x);
+  Fe x4 = mont_sqr(x2);
+  return mont_mul(x4, x);
+}
+
+// ---- lazy modular reduction -----------------------------------------------------------------
+// Table of (bias - q*N) rows lives in LDS (filled by qtab_fill); row q, 9 dwords, stride 9 (odd, so
+// lanes with different q hit different banks and equal q broadcasts).
+constexpr int QTAB_ROWS = 32;
+constexpr int QTAB_WORDS = QTAB_ROWS * NL;
+
+// Fill the LDS table: row q holds U_i = bias_i - (q*N)_i with bias = {U, U-1, ..., U-1, -1}
+// (the bias sums to zero as a number, so  v + row(q)  ==  v - q*N  with every limb 0..7 non-negative).
+__device__ __forceinline__ void qtab_fill(uint32_t* tab, int tid, int nthreads) {
+  for (int idx = tid; idx < QTAB_WORDS; idx += nthreads) {
+    int q = idx / NL, i = idx % NL;
+    uint32_t t = FR_QN_TAB[q][i];
+    uint32_t bias = (i == 0) ? U29 : (i == NL - 1 ? 0xffffffffu : U29 - 1);
+    tab[idx] = bias - t;
+  }
+}
+
+// Reduce a lazily-accumulated value: input limbs < 6 U (so limb + row < 2^32), value < 30 N;
+// output limbs 0..7 < U exactly, top limb small, value < 2 N (q is floor(v/N) or one less).
+__device__ __forceinline__ Fe reduce_lazy(const Fe& a, const uint32_t* tab) {
+  // t ~ floor(v / 2^232), never an over-estimate; N / 2^232 = 0x30644e.72e1...
+  uint32_t t = a.l[NL - 1] + (a.l[NL - 2] >> 29);
+  // q = floor(t / (0x30644e + 1)) via 2^32 / 3171407 = 1354.27...; under-estimates only
+  uint32_t q = __umulhi(t, 1354u);
+  const uint32_t* row = tab + q * NL;
+  Fe r;
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < NL - 1; ++i) {
+    uint32_t d = a.l[i] + row[i] + c;
+    r.l[i] = d & MASK;
+    c = d >> 29;
+  }
+  r.l[NL - 1] = a.l[NL - 1] + row[NL - 1] + c;
+  return r;
+}
+
+// ---- conversions ------------------------------------------------------------------------------
+// 8 little-endian dwords (a 256-bit integer) -> 9 x 29-bit limbs (raw value, NOT Montgomery form)
+__device__ __forceinline__ Fe from_words(const uint32_t (&w)[8]) {
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int bit = 29 * i, k = bit / 32, s = bit % 32;
+    uint32_t lo = w[k] >> s;
+    if (s + 29 > 32 && k + 1 < 8) lo |= w[k + 1] << (32 - s);
+    r.l[i] = (i == NL - 1) ? lo : (lo & MASK);   // top limb keeps all remaining 24 bits
+  }
+  return r;
+}
+
+// raw 256-bit integer -> Montgomery form (value < 2N, normalized): a * R^2 / R
+__device__ __forceinline__ Fe to_mont(const Fe& raw) { return mont_mul(raw, fe_const(FR_R2)); }
+
+// Montgomery form (limbs < 2.47 U, value < R) -> canonical integer in [0, N) as 8 dwords
+__device__ __forceinline__ void to_canonical_words(const Fe& a, uint32_t (&w)[8]) {
+  Fe one = fe_zero();
+  one.l[0] = 1;
+  Fe c = mont_mul(a, one);            // (a + m N)/R <= N, limbs 0..7 < U
+  bool is_n = true;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) is_n = is_n && (c.l[i] == FR_N[i]);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) c.l[i] = is_n ? 0u : c.l[i];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int bit = 32 * j, i = bit / 29, s = bit % 29;   // word j starts inside limb i at bit s
+    uint32_t v = c.l[i] >> s;
+    if (i + 1 < NL) v |= c.l[i + 1] << (29 - s);
+    if (29 - s + 29 < 32 && i + 2 < NL) v |= c.l[i + 2] << (58 - s);
+    w[j] = v;
+  }
+}
+
+}  // namespace fr

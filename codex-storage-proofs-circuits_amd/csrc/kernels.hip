@@ -1,0 +1,336 @@
+// HIP kernels (gfx950 only) for the Codex storage-proof hot path.  One field element per lane.
+//
+//   k_permute_batch   a1  Permutation.hs:40-45                       192 algorithmic B / permutation
+//   k_hash_cells      a5  blocks/bn254.nim:23-29 (= Slot.hs:222-270 + Sponge.hs:30-43)   cellSize+32 B / cell
+//   k_compress_layer  a7  merkle/bn254.nim:24-58 (one tree layer, many trees at once)    96 B / node
+//   k_sponge2_felts   a3  Sponge.hs:30-43 over field elements (sampling, generic byte strings)
+//   k_gen_fake_cells  a10 slot.nim:22-32
+//   k_gather_rows         path / cell gather for proof inputs (merkle.nim:21-42 does this on the host)
+//
+// All global-memory field elements are 32-byte little-endian canonical integers (the ABI format).
+#include "kernels.hpp"
+#include "poseidon2_dev.hpp"
+
+namespace cp2k {
+using fr::Fe;
+using p2::State;
+
+constexpr int TPB = 256;
+
+__device__ __forceinline__ Fe load_fe_canonical(const uint4* p) {
+  uint4 a = p[0], b = p[1];
+  uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  return fr::to_mont(fr::from_words(w));
+}
+
+__device__ __forceinline__ void store_fe_canonical(uint4* p, const Fe& v) {
+  uint32_t w[8];
+  fr::to_canonical_words(v, w);
+  p[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  p[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+__device__ __forceinline__ Fe key_fe(uint32_t key) {   // nodeKey, Merkle.hs:162-165, Montgomery form
+  Fe k0 = fr::fe_const(fr::FR_KEY0_MONT), k1 = fr::fe_const(fr::FR_KEY1_MONT);
+  Fe k2 = fr::fe_const(fr::FR_KEY2_MONT), k3 = fr::fe_const(fr::FR_KEY3_MONT);
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < fr::NL; ++i) {
+    uint32_t lo = (key & 1) ? k1.l[i] : k0.l[i];
+    uint32_t hi = (key & 1) ? k3.l[i] : k2.l[i];
+    r.l[i] = (key & 2) ? hi : lo;
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB) k_permute_batch(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n) {
+  __shared__ uint32_t qtab[fr::QTAB_WORDS];
+  fr::qtab_fill(qtab, threadIdx.x, TPB);
+  __syncthreads();
+  size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  State s;
+  s.x = load_fe_canonical(in + 6 * i);
+  s.y = load_fe_canonical(in + 6 * i + 2);
+  s.z = load_fe_canonical(in + 6 * i + 4);
+  p2::permute(s, qtab);
+  store_fe_canonical(out + 6 * i, s.x);
+  store_fe_canonical(out + 6 * i + 2, s.y);
+  store_fe_canonical(out + 6 * i + 4, s.z);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One Merkle layer for nseg independent trees: out[seg][j] = compress(in[seg][2j], in[seg][2j+1], key)
+// with the odd-tail rule of merkle/bn254.nim:47-53 (compress(last, 0) with key+2).
+__global__ void __launch_bounds__(TPB) k_compress_layer(const uint4* __restrict__ in, uint4* __restrict__ out,
+                                                          size_t m_in, size_t m_out, size_t nseg, uint32_t bottom,
+                                                          size_t in_seg_stride, size_t out_seg_stride) {
+  __shared__ uint32_t qtab[fr::QTAB_WORDS];
+  fr::qtab_fill(qtab, threadIdx.x, TPB);
+  __syncthreads();
+  size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (t >= m_out * nseg) return;
+  size_t seg = t / m_out, j = t - seg * m_out;
+  const uint4* src = in + 2 * (seg * in_seg_stride + 2 * j);
+  bool pair = (2 * j + 1 < m_in);
+  State s;
+  s.x = load_fe_canonical(src);
+  s.y = pair ? load_fe_canonical(src + 2) : fr::fe_zero();
+  s.z = key_fe((bottom ? 1u : 0u) + (pair ? 0u : 2u));
+  p2::permute(s, qtab);
+  store_fe_canonical(out + 2 * (seg * out_seg_stride + j), s.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched rate-2 sponge over field elements (Sponge.hs:30-43): item i hashes felts[i*nf .. i*nf+nf).
+__global__ void __launch_bounds__(TPB) k_sponge2_felts(const uint4* __restrict__ felts, size_t nf, size_t nitems,
+                                                         uint4* __restrict__ out) {
+  __shared__ uint32_t qtab[fr::QTAB_WORDS];
+  fr::qtab_fill(qtab, threadIdx.x, TPB);
+  __syncthreads();
+  size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (t >= nitems) return;
+  const uint4* src = felts + 2 * t * nf;
+  State s;
+  s.x = fr::fe_zero();
+  s.y = fr::fe_zero();
+  s.z = fr::fe_const(fr::FR_CIV_RATE2_MONT);
+  const Fe one = fr::fe_const(fr::FR_R1);
+  size_t padded = (nf + 2) & ~(size_t)1;   // nf odd: +1 ("1"); nf even: +2 ("1","0")
+#pragma unroll 1
+  for (size_t k = 0; k < padded; k += 2) {
+    Fe a = (k < nf) ? load_fe_canonical(src + 2 * k) : (k == nf ? one : fr::fe_zero());
+    Fe b = (k + 1 < nf) ? load_fe_canonical(src + 2 * (k + 1)) : (k + 1 == nf ? one : fr::fe_zero());
+    s.x = fr::norm(fr::add_lazy(s.x, a));
+    s.y = fr::norm(fr::add_lazy(s.y, b));
+    p2::permute(s, qtab);
+  }
+  store_fe_canonical(out + 2 * t, s.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// hashCell for a contiguous array of cells: one cell per lane.
+//
+// The byte stream a lane absorbs is  cell || 0x01 || 0-pad to 31*nfelts || sponge pad, where the
+// sponge's "1" pad element is itself the chunk {0x01,0,...} and the optional "0" element a zero
+// chunk (Slot.hs:243-250 then Sponge.hs:36-39).  So the whole padded input is one byte stream cut
+// into 31-byte little-endian chunks, two per permutation.
+//
+// Staging: each wave copies 124 bytes (= 4 chunks = 2 permutations) of each of its 64 cells into
+// LDS with lane-linear dword loads (31 consecutive lanes read one cell's 124 contiguous bytes), then
+// every lane reads back its own row; row stride 31 dwords is odd, so both sides are bank-conflict free.
+constexpr int TILE_WORDS = 31;            // 124 bytes
+constexpr int TILE_BYTES = 124;
+
+__device__ __forceinline__ Fe chunk_limbs(const uint32_t* row, int j) {
+  // chunk j of the row = bits [248j, 248j+248) -> 9 raw limbs (8 x 29 bits + 16 bits)
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < fr::NL; ++i) {
+    const int bit = 248 * j + 29 * i, k = bit / 32, s = bit % 32;
+    const int width = (i == fr::NL - 1) ? 16 : 29;
+    uint32_t v = row[k] >> s;
+    if (s + width > 32) v |= row[k + 1] << (32 - s);
+    r.l[i] = v & ((1u << width) - 1);
+  }
+  return r;
+}
+
+__global__ void __launch_bounds__(TPB) k_hash_cells(const uint8_t* __restrict__ cells, size_t cell_size,
+                                                      size_t n_cells, uint4* __restrict__ out) {
+  __shared__ uint32_t qtab[fr::QTAB_WORDS];
+  __shared__ uint32_t stage[TPB / 64][64 * TILE_WORDS];
+  fr::qtab_fill(qtab, threadIdx.x, TPB);
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t cell0 = (size_t)blockIdx.x * TPB + (size_t)wave * 64;
+  const size_t my_cell = cell0 + lane;
+  const size_t nfelts = (cell_size + 31) / 31;            // chunks of cell || 0x01
+  const size_t total = (nfelts + 2) & ~(size_t)1;          // + sponge pad, even
+  const size_t sponge_pad_pos = 31 * nfelts;               // byte position of the sponge's "1"
+  const size_t ntiles = (total + 3) / 4;
+  const bool aligned4 = ((cell_size & 3) == 0) && ((reinterpret_cast<uintptr_t>(cells) & 3) == 0);
+
+  State s;
+  s.x = fr::fe_zero();
+  s.y = fr::fe_zero();
+  s.z = fr::fe_const(fr::FR_CIV_RATE2_MONT);
+
+  uint32_t* my_stage = stage[wave];
+#pragma unroll 1
+  for (size_t tile = 0; tile < ntiles; ++tile) {
+    __syncthreads();   // previous tile fully consumed (also orders the qtab fill on the first pass)
+#pragma unroll 1
+    for (int k = 0; k < TILE_WORDS; ++k) {
+      const int idx = k * 64 + lane;
+      const int c = idx / TILE_WORDS, w = idx - c * TILE_WORDS;
+      const size_t cell = cell0 + c;
+      const size_t p0 = tile * TILE_BYTES + (size_t)w * 4;
+      uint32_t val = 0;
+      if (cell < n_cells) {
+        const uint8_t* base = cells + cell * cell_size;
+        if (aligned4 && p0 + 4 <= cell_size) {
+          val = *reinterpret_cast<const uint32_t*>(base + p0);
+        } else {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            size_t p = p0 + b;
+            uint32_t byte = (p < cell_size) ? base[p] : (p == cell_size ? 1u : 0u);
+            val |= byte << (8 * b);
+          }
+        }
+        if (sponge_pad_pos >= p0 && sponge_pad_pos < p0 + 4) val |= 1u << (8 * (sponge_pad_pos - p0));
+      }
+      my_stage[idx] = val;
+    }
+    __syncthreads();
+    const uint32_t* row = my_stage + lane * TILE_WORDS;
+    {
+      uint32_t r[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) r[i] = row[i];
+      Fe a = fr::to_mont(chunk_limbs(r, 0));
+      Fe b = fr::to_mont(chunk_limbs(r, 1));
+      s.x = fr::norm(fr::add_lazy(s.x, a));
+      s.y = fr::norm(fr::add_lazy(s.y, b));
+      p2::permute(s, qtab);
+    }
+    if (4 * tile + 2 < total) {
+      uint32_t r[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) r[i] = row[15 + i];   // chunks 2,3 start at bit 496 = dword 15, bit 16
+      // re-base: chunk 2 begins 16 bits into r[0]; chunk_limbs wants bit 248*j from the row start,
+      // so shift the window: treat r as the row starting at dword 15 and use explicit bit offsets.
+      Fe a, b;
+#pragma unroll
+      for (int i = 0; i < fr::NL; ++i) {
+        const int width = (i == fr::NL - 1) ? 16 : 29;
+        {
+          const int bit = 16 + 29 * i, k = bit / 32, sh = bit % 32;
+          uint32_t v = r[k] >> sh;
+          if (sh + width > 32) v |= r[k + 1] << (32 - sh);
+          a.l[i] = v & ((1u << width) - 1);
+        }
+        {
+          const int bit = 16 + 248 + 29 * i, k = bit / 32, sh = bit % 32;
+          uint32_t v = r[k] >> sh;
+          if (sh + width > 32) v |= r[k + 1] << (32 - sh);
+          b.l[i] = v & ((1u << width) - 1);
+        }
+      }
+      a = fr::to_mont(a);
+      b = fr::to_mont(b);
+      s.x = fr::norm(fr::add_lazy(s.x, a));
+      s.y = fr::norm(fr::add_lazy(s.y, b));
+      p2::permute(s, qtab);
+    }
+  }
+  if (my_cell < n_cells) store_fe_canonical(out + 2 * my_cell, s.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// genFakeCell (slot.nim:22-32): sequential in a cell, independent across cells; one cell per lane.
+// Thread t makes "global cell" g = list ? list[t] : first + t.  With cells_per_slot != 0 the global
+// index spans several slots: slot = g / cells_per_slot uses seed0 + 1001*slot (dataset.nim:32, seed0
+// already holding the "+72" of the first slot) and the cell index inside the slot is g % cells_per_slot.
+__global__ void __launch_bounds__(TPB) k_gen_fake_cells(uint64_t seed0, uint64_t cells_per_slot, uint64_t first,
+                                                          const uint64_t* __restrict__ list, size_t n_cells,
+                                                          size_t cell_size, uint8_t* __restrict__ out) {
+  size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (t >= n_cells) return;
+  const uint64_t g = list ? list[t] : first + t;
+  const uint64_t slot = cells_per_slot ? g / cells_per_slot : 0;
+  const uint64_t idx = cells_per_slot ? g - slot * cells_per_slot : g;
+  const uint64_t seed1 = (seed0 + 1001 * slot) + 0xdeadcafeULL;
+  const uint64_t seed2 = idx + 0x98765432ULL;
+  uint64_t state = 1;
+  uint8_t* dst = out + t * cell_size;
+  const bool wide = ((cell_size & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  if (wide) {
+#pragma unroll 1
+    for (size_t i = 0; i < cell_size; i += 16) {
+      uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int b = 0; b < 16; ++b) {
+        state = state * (state + seed1) * (state + seed2) + state * (state ^ 0x5a5a5a5aULL) + seed1 * state + (seed2 + 17);
+        state = state % 1698428844001831ULL;
+        w[b >> 2] |= (uint32_t)(state & 0xff) << (8 * (b & 3));
+      }
+      *reinterpret_cast<uint4*>(dst + i) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  } else {
+#pragma unroll 1
+    for (size_t i = 0; i < cell_size; ++i) {
+      state = state * (state + seed1) * (state + seed2) + state * (state ^ 0x5a5a5a5aULL) + seed1 * state + (seed2 + 17);
+      state = state % 1698428844001831ULL;
+      dst[i] = (uint8_t)state;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gather nrows rows of row_bytes bytes: out[r] = src[index[r] * row_bytes ...]; rows whose index is
+// ~0 are zero-filled (the reference pads paths with zero, merkle.nim:33-34, types.nim:27-37).
+__global__ void __launch_bounds__(TPB) k_gather_rows(const uint8_t* __restrict__ src, const uint64_t* __restrict__ index,
+                                                       size_t nrows, size_t row_bytes, uint8_t* __restrict__ out) {
+  const size_t words_per_row = row_bytes / 4;
+  size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * TPB;
+  for (; t < nrows * words_per_row; t += stride) {
+    size_t r = t / words_per_row, w = t - r * words_per_row;
+    uint64_t idx = index[r];
+    uint32_t v = 0;
+    if (idx != ~0ULL) v = reinterpret_cast<const uint32_t*>(src + idx * row_bytes)[w];
+    reinterpret_cast<uint32_t*>(out + r * row_bytes)[w] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+static inline unsigned grid_for(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
+
+hipError_t launch_permute_batch(const void* in, void* out, size_t n, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_permute_batch, dim3(grid_for(n)), dim3(TPB), 0, st, (const uint4*)in, (uint4*)out, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_compress_layer(const void* in, void* out, size_t m_in, size_t nseg, bool bottom,
+                                 size_t in_seg_stride, size_t out_seg_stride, hipStream_t st) {
+  size_t m_out = (m_in + 1) / 2;
+  if (m_out * nseg == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_compress_layer, dim3(grid_for(m_out * nseg)), dim3(TPB), 0, st, (const uint4*)in, (uint4*)out,
+                     m_in, m_out, nseg, bottom ? 1u : 0u, in_seg_stride, out_seg_stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_sponge2_felts(const void* felts, size_t nf, size_t nitems, void* out, hipStream_t st) {
+  if (nitems == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_sponge2_felts, dim3(grid_for(nitems)), dim3(TPB), 0, st, (const uint4*)felts, nf, nitems, (uint4*)out);
+  return hipGetLastError();
+}
+
+hipError_t launch_hash_cells(const void* cells, size_t cell_size, size_t n_cells, void* out, hipStream_t st) {
+  if (n_cells == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_hash_cells, dim3(grid_for(n_cells)), dim3(TPB), 0, st, (const uint8_t*)cells, cell_size, n_cells, (uint4*)out);
+  return hipGetLastError();
+}
+
+hipError_t launch_gen_fake_cells(uint64_t seed0, uint64_t cells_per_slot, uint64_t first, const uint64_t* list,
+                                 size_t n_cells, size_t cell_size, void* out, hipStream_t st) {
+  if (n_cells == 0 || cell_size == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_gen_fake_cells, dim3(grid_for(n_cells)), dim3(TPB), 0, st, seed0, cells_per_slot, first, list,
+                     n_cells, cell_size, (uint8_t*)out);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_rows(const void* src, const uint64_t* index, size_t nrows, size_t row_bytes, void* out, hipStream_t st) {
+  if (nrows == 0) return hipSuccess;
+  size_t work = nrows * (row_bytes / 4);
+  unsigned grid = grid_for(work);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(TPB), 0, st, (const uint8_t*)src, index, nrows, row_bytes, (uint8_t*)out);
+  return hipGetLastError();
+}
+
+}  // namespace cp2k

@@ -1,0 +1,634 @@
+// Slot trees, datasets and proof inputs behind the C ABI (include/codex_p2.h).
+//
+// Mirrors reference/nim/proof_input/src/gen_input/bn254.nim:21-79 (buildSlotTreeFull, generateProofInput),
+// merkle.nim:21-42,86-100 (merkleProof, mergeMerkleProofs), types.nim:27-37 (padMerkleProof) and
+// json/bn254.nim:19-78 + json/shared.nim:17-25 (exportProofInput).  All hashing runs in the HIP kernels;
+// what stays on the host is index arithmetic, byte packing and text formatting.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "internal.hpp"
+#include "kernels.hpp"
+
+using namespace cp2i;
+
+namespace {
+constexpr uint64_t NO_ROW = ~0ULL;
+constexpr size_t STAGE_BYTES = (size_t)1 << 31;   // device staging buffer for generated / uploaded cells
+
+bool is_pow2(uint64_t x) { return x && !(x & (x - 1)); }
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// slot trees
+// ---------------------------------------------------------------------------------------------
+enum class CellSrc { Fake, Dev, Host, File };
+
+struct cp2_slot_trees {
+  cp2_ctx* ctx = nullptr;
+  size_t n_slots = 0, cell_size = 0, block_size = 0, n_cells = 0, cpb = 0, nblocks = 0;
+  std::vector<size_t> bsizes, tsizes;   // per-tree layer sizes: block tree (cpb leaves), big tree (nblocks leaves)
+  std::vector<size_t> boff, toff;       // element offsets of each layer in `nodes` (layer-major)
+  DevBuf nodes;
+  // where sampled cells come from
+  CellSrc src = CellSrc::Fake;
+  uint64_t dataset_seed = 0, first_slot = 0;
+  const uint8_t* d_cells = nullptr;     // not owned
+  const uint8_t* h_cells = nullptr;     // not owned
+  std::string file_base;
+};
+
+static int trees_layout(cp2_slot_trees* t) {
+  t->bsizes = layer_sizes_of(t->cpb);
+  t->tsizes = layer_sizes_of(t->nblocks);
+  size_t off = 0;
+  t->boff.clear();
+  t->toff.clear();
+  const size_t nb = t->n_slots * t->nblocks;
+  for (size_t k = 0; k < t->bsizes.size(); ++k) {
+    t->boff.push_back(off);
+    if (k + 1 < t->bsizes.size()) off += nb * t->bsizes[k];
+  }
+  // the last block-tree layer (one root per block) is layer 0 of the big trees
+  for (size_t k = 0; k < t->tsizes.size(); ++k) {
+    t->toff.push_back(off);
+    off += t->n_slots * t->tsizes[k];
+  }
+  return t->nodes.alloc(t->ctx, off * 32);
+}
+
+static int trees_check_geometry(size_t cell_size, size_t block_size, size_t n_cells, size_t n_slots) {
+  if (cell_size == 0 || block_size == 0 || n_cells == 0 || n_slots == 0) return CP2_ERR_INVALID;
+  if (block_size % cell_size != 0) return CP2_ERR_INVALID;        // types.nim:104-107 cellsPerBlock assert
+  size_t cpb = block_size / cell_size;
+  if (n_cells % cpb != 0) return CP2_ERR_INVALID;                 // gen_input/bn254.nim:25 assert
+  return CP2_OK;
+}
+
+static cp2_slot_trees* trees_new(cp2_ctx* ctx, size_t n_slots, size_t cell_size, size_t block_size, size_t n_cells) {
+  cp2_slot_trees* t = new (std::nothrow) cp2_slot_trees();
+  if (!t) return nullptr;
+  t->ctx = ctx;
+  t->n_slots = n_slots;
+  t->cell_size = cell_size;
+  t->block_size = block_size;
+  t->n_cells = n_cells;
+  t->cpb = block_size / cell_size;
+  t->nblocks = n_cells / t->cpb;
+  return t;
+}
+
+// all layers above the cell hashes (which are already in nodes[0 .. n_slots*n_cells))
+static int trees_build_layers(cp2_slot_trees* t) {
+  cp2_ctx* ctx = t->ctx;
+  uint8_t* base = t->nodes.u8();
+  const size_t nb = t->n_slots * t->nblocks;
+  for (size_t k = 0; k + 1 < t->bsizes.size(); ++k)   // networkBlockTree, blocks/bn254.nim:60-67
+    CP2_HIP(ctx, cp2k::launch_compress_layer(base + t->boff[k] * 32, base + t->boff[k + 1] * 32, t->bsizes[k], nb, k == 0,
+                                             t->bsizes[k], t->bsizes[k + 1], ctx->stream));
+  for (size_t k = 0; k + 1 < t->tsizes.size(); ++k)   // bigTree, gen_input/bn254.nim:28-29
+    CP2_HIP(ctx, cp2k::launch_compress_layer(base + t->toff[k] * 32, base + t->toff[k + 1] * 32, t->tsizes[k], t->n_slots,
+                                             k == 0, t->tsizes[k], t->tsizes[k + 1], ctx->stream));
+  return CP2_OK;
+}
+
+extern "C" int cp2_slot_trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_slot, size_t n_slots,
+                                         size_t cell_size, size_t block_size, size_t n_cells, cp2_slot_trees** out) {
+  if (!ctx || !out) return CP2_ERR_INVALID;
+  *out = nullptr;
+  CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  cp2_slot_trees* t = trees_new(ctx, n_slots, cell_size, block_size, n_cells);
+  if (!t) return CP2_ERR_ALLOC;
+  t->src = CellSrc::Fake;
+  t->dataset_seed = dataset_seed;
+  t->first_slot = first_slot;
+  int st = trees_layout(t);
+  if (st != CP2_OK) { delete t; return st; }
+  const size_t total_cells = n_slots * n_cells;
+  const size_t chunk = std::max<size_t>(1, std::min(total_cells, STAGE_BYTES / cell_size));
+  DevBuf stage;
+  st = stage.alloc(ctx, chunk * cell_size);
+  if (st != CP2_OK) { delete t; return st; }
+  const uint64_t seed0 = cp2_slot_seed(dataset_seed, first_slot);
+  for (size_t c0 = 0; c0 < total_cells; c0 += chunk) {
+    size_t n = std::min(chunk, total_cells - c0);
+    hipError_t e = cp2k::launch_gen_fake_cells(seed0, n_cells, c0, nullptr, n, cell_size, stage.p, ctx->stream);
+    if (e == hipSuccess) e = cp2k::launch_hash_cells(stage.p, cell_size, n, t->nodes.u8() + c0 * 32, ctx->stream);
+    if (e != hipSuccess) { ctx->err = hipGetErrorString(e); delete t; return CP2_ERR_HIP; }
+  }
+  st = trees_build_layers(t);
+  if (st == CP2_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = CP2_ERR_HIP;
+  if (st != CP2_OK) { delete t; return st; }
+  *out = t;
+  return CP2_OK;
+}
+
+extern "C" int cp2_slot_trees_build_dev(cp2_ctx* ctx, const void* d_cells, size_t n_slots, size_t cell_size,
+                                        size_t block_size, size_t n_cells, cp2_slot_trees** out) {
+  if (!ctx || !out || !d_cells) return CP2_ERR_INVALID;
+  *out = nullptr;
+  CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  cp2_slot_trees* t = trees_new(ctx, n_slots, cell_size, block_size, n_cells);
+  if (!t) return CP2_ERR_ALLOC;
+  t->src = CellSrc::Dev;
+  t->d_cells = static_cast<const uint8_t*>(d_cells);
+  int st = trees_layout(t);
+  if (st == CP2_OK) {
+    hipError_t e = cp2k::launch_hash_cells(d_cells, cell_size, n_slots * n_cells, t->nodes.p, ctx->stream);
+    if (e != hipSuccess) { ctx->err = hipGetErrorString(e); st = CP2_ERR_HIP; }
+  }
+  if (st == CP2_OK) st = trees_build_layers(t);
+  if (st != CP2_OK) { delete t; return st; }
+  *out = t;   // asynchronous: the caller syncs (cp2_sync) or reads roots (which syncs)
+  return CP2_OK;
+}
+
+// upload + hash `n` cells from host memory into leaf slots [leaf0, leaf0+n), double-buffered
+static int hash_host_cells(cp2_slot_trees* t, const uint8_t* cells, size_t n, size_t leaf0, DevBuf stage[2], size_t chunk,
+                           hipEvent_t done[2]) {
+  cp2_ctx* ctx = t->ctx;
+  size_t i = 0;
+  for (size_t c0 = 0; c0 < n; c0 += chunk, ++i) {
+    size_t m = std::min(chunk, n - c0);
+    int b = (int)(i & 1);
+    CP2_HIP(ctx, hipEventSynchronize(done[b]));   // the kernel that last read this buffer has finished
+    CP2_HIP(ctx, hipMemcpyAsync(stage[b].p, cells + c0 * t->cell_size, m * t->cell_size, hipMemcpyHostToDevice, ctx->stream));
+    CP2_HIP(ctx, cp2k::launch_hash_cells(stage[b].p, t->cell_size, m, t->nodes.u8() + (leaf0 + c0) * 32, ctx->stream));
+    CP2_HIP(ctx, hipEventRecord(done[b], ctx->stream));
+  }
+  return CP2_OK;
+}
+
+struct HostStage {
+  DevBuf buf[2];
+  hipEvent_t done[2] = {nullptr, nullptr};
+  size_t chunk = 0;
+  ~HostStage() {
+    for (auto& e : done)
+      if (e) (void)hipEventDestroy(e);
+  }
+  int init(cp2_ctx* ctx, size_t cell_size, size_t max_cells) {
+    chunk = std::max<size_t>(1, std::min(max_cells, (STAGE_BYTES / 8) / cell_size));
+    for (int b = 0; b < 2; ++b) {
+      CP2_TRY(buf[b].alloc(ctx, chunk * cell_size));
+      CP2_HIP(ctx, hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
+      CP2_HIP(ctx, hipEventRecord(done[b], ctx->stream));
+    }
+    return CP2_OK;
+  }
+};
+
+extern "C" int cp2_slot_trees_build_host(cp2_ctx* ctx, const uint8_t* cells, size_t n_slots, size_t cell_size,
+                                         size_t block_size, size_t n_cells, cp2_slot_trees** out) {
+  if (!ctx || !out || !cells) return CP2_ERR_INVALID;
+  *out = nullptr;
+  CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  cp2_slot_trees* t = trees_new(ctx, n_slots, cell_size, block_size, n_cells);
+  if (!t) return CP2_ERR_ALLOC;
+  t->src = CellSrc::Host;
+  t->h_cells = cells;
+  HostStage hs;
+  int st = trees_layout(t);
+  if (st == CP2_OK) st = hs.init(ctx, cell_size, n_slots * n_cells);
+  if (st == CP2_OK) st = hash_host_cells(t, cells, n_slots * n_cells, 0, hs.buf, hs.chunk, hs.done);
+  if (st == CP2_OK) st = trees_build_layers(t);
+  if (st == CP2_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = CP2_ERR_HIP;
+  if (st != CP2_OK) { delete t; return st; }
+  *out = t;
+  return CP2_OK;
+}
+
+// slot files "<base><k>.dat" (dataset.nim:34), streamed through the staging buffers; short files read as zeros
+static int trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t first_slot, size_t n_slots, size_t cell_size,
+                             size_t block_size, size_t n_cells, cp2_slot_trees** out) {
+  *out = nullptr;
+  CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  cp2_slot_trees* t = trees_new(ctx, n_slots, cell_size, block_size, n_cells);
+  if (!t) return CP2_ERR_ALLOC;
+  t->src = CellSrc::File;
+  t->file_base = base;
+  t->first_slot = first_slot;
+  HostStage hs;
+  int st = trees_layout(t);
+  if (st == CP2_OK) st = hs.init(ctx, cell_size, n_cells);
+  std::vector<uint8_t> host[2];
+  if (st == CP2_OK) {
+    host[0].resize(hs.chunk * cell_size);
+    host[1].resize(hs.chunk * cell_size);
+  }
+  size_t turn = 0;
+  for (size_t s = 0; st == CP2_OK && s < n_slots; ++s) {
+    std::string fname = base + std::to_string(first_slot + s) + ".dat";
+    FILE* f = std::fopen(fname.c_str(), "rb");
+    if (!f) { ctx->err = "cannot open " + fname; st = CP2_ERR_IO; break; }
+    for (size_t c0 = 0; st == CP2_OK && c0 < n_cells; c0 += hs.chunk, ++turn) {
+      size_t m = std::min(hs.chunk, n_cells - c0);
+      int b = (int)(turn & 1);
+      if (hipEventSynchronize(hs.done[b]) != hipSuccess) { st = CP2_ERR_HIP; break; }
+      size_t got = std::fread(host[b].data(), 1, m * cell_size, f);
+      if (got < m * cell_size) std::memset(host[b].data() + got, 0, m * cell_size - got);
+      hipError_t e = hipMemcpyAsync(hs.buf[b].p, host[b].data(), m * cell_size, hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess)
+        e = cp2k::launch_hash_cells(hs.buf[b].p, cell_size, m, t->nodes.u8() + (s * n_cells + c0) * 32, ctx->stream);
+      if (e == hipSuccess) e = hipEventRecord(hs.done[b], ctx->stream);
+      if (e != hipSuccess) { ctx->err = hipGetErrorString(e); st = CP2_ERR_HIP; }
+    }
+    std::fclose(f);
+  }
+  if (st == CP2_OK) st = trees_build_layers(t);
+  if (st == CP2_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = CP2_ERR_HIP;
+  if (st != CP2_OK) { delete t; return st; }
+  *out = t;
+  return CP2_OK;
+}
+
+extern "C" void cp2_slot_trees_free(cp2_slot_trees* t) {
+  if (!t) return;
+  (void)hipSetDevice(t->ctx->device);
+  (void)hipStreamSynchronize(t->ctx->stream);
+  delete t;
+}
+
+extern "C" size_t cp2_slot_trees_count(const cp2_slot_trees* t) { return t ? t->n_slots : 0; }
+extern "C" size_t cp2_slot_trees_depth(const cp2_slot_trees* t) {
+  return t ? (t->bsizes.size() - 1) + (t->tsizes.size() - 1) : 0;
+}
+
+extern "C" const void* cp2_slot_trees_roots_dev(const cp2_slot_trees* t) {
+  return t ? t->nodes.u8() + t->toff.back() * 32 : nullptr;
+}
+
+extern "C" int cp2_slot_trees_roots(cp2_slot_trees* t, uint8_t* out) {
+  if (!t || !out) return CP2_ERR_INVALID;
+  cp2_ctx* ctx = t->ctx;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  CP2_HIP(ctx, hipMemcpyAsync(out, cp2_slot_trees_roots_dev(t), t->n_slots * 32, hipMemcpyDeviceToHost, ctx->stream));
+  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return CP2_OK;
+}
+
+// node-row indices of the merged path of `cell` in slot `slot` (merkle.nim:21-42 twice, then :86-100)
+static void path_rows(const cp2_slot_trees* t, size_t slot, uint64_t cell, size_t max_depth, uint64_t* rows) {
+  size_t b = cell / t->cpb, j = cell % t->cpb, d = 0;
+  size_t m = t->cpb;
+  for (size_t k = 0; k + 1 < t->bsizes.size(); ++k, ++d) {
+    size_t sib = j ^ 1;
+    rows[d] = (sib < m) ? t->boff[k] + (slot * t->nblocks + b) * t->bsizes[k] + sib : NO_ROW;   // zero if out of range
+    j >>= 1;
+    m = (m + 1) >> 1;
+  }
+  size_t i = b;
+  m = t->nblocks;
+  for (size_t k = 0; k + 1 < t->tsizes.size(); ++k, ++d) {
+    size_t sib = i ^ 1;
+    rows[d] = (sib < m) ? t->toff[k] + slot * t->tsizes[k] + sib : NO_ROW;
+    i >>= 1;
+    m = (m + 1) >> 1;
+  }
+  for (; d < max_depth; ++d) rows[d] = NO_ROW;                                                  // padMerkleProof
+}
+
+extern "C" int cp2_slot_trees_paths(cp2_slot_trees* t, size_t slot, const uint64_t* cell_idx, size_t n, size_t max_depth,
+                                    uint8_t* out, uint8_t* leaf_hashes) {
+  if (!t || (n && (!cell_idx || !out)) || slot >= t->n_slots) return CP2_ERR_INVALID;
+  if (cp2_slot_trees_depth(t) > max_depth) return CP2_ERR_INVALID;     // types.nim:29 assert(pad >= 0)
+  if (n == 0) return CP2_OK;
+  cp2_ctx* ctx = t->ctx;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t per = max_depth + 1;                                     // + the leaf itself
+  std::vector<uint64_t> rows(n * per);
+  for (size_t i = 0; i < n; ++i) {
+    if (cell_idx[i] >= t->n_cells) return CP2_ERR_INVALID;              // merkle.nim:27 assert
+    path_rows(t, slot, cell_idx[i], max_depth, &rows[i * per]);
+    rows[i * per + max_depth] = slot * t->n_cells + cell_idx[i];
+  }
+  DevBuf d_rows, d_out;
+  CP2_TRY(d_rows.alloc(ctx, rows.size() * 8));
+  CP2_TRY(d_out.alloc(ctx, rows.size() * 32));
+  CP2_HIP(ctx, hipMemcpyAsync(d_rows.p, rows.data(), rows.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  CP2_HIP(ctx, cp2k::launch_gather_rows(t->nodes.p, static_cast<const uint64_t*>(d_rows.p), rows.size(), 32, d_out.p, ctx->stream));
+  std::vector<uint8_t> tmp(rows.size() * 32);
+  CP2_HIP(ctx, hipMemcpyAsync(tmp.data(), d_out.p, tmp.size(), hipMemcpyDeviceToHost, ctx->stream));
+  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < n; ++i) {
+    std::memcpy(out + i * max_depth * 32, &tmp[i * per * 32], max_depth * 32);
+    if (leaf_hashes) std::memcpy(leaf_hashes + i * 32, &tmp[(i * per + max_depth) * 32], 32);
+  }
+  return CP2_OK;
+}
+
+// the bytes of n cells of one slot (slotLoadCellData, slot.nim:57-68)
+static int trees_cells(cp2_slot_trees* t, size_t slot, const uint64_t* cell_idx, size_t n, uint8_t* out) {
+  cp2_ctx* ctx = t->ctx;
+  const size_t cs = t->cell_size;
+  if (n == 0) return CP2_OK;
+  switch (t->src) {
+    case CellSrc::Host:
+      for (size_t i = 0; i < n; ++i) std::memcpy(out + i * cs, t->h_cells + (slot * t->n_cells + cell_idx[i]) * cs, cs);
+      return CP2_OK;
+    case CellSrc::File: {
+      std::string fname = t->file_base + std::to_string(t->first_slot + slot) + ".dat";
+      FILE* f = std::fopen(fname.c_str(), "rb");
+      if (!f) { ctx->err = "cannot open " + fname; return CP2_ERR_IO; }
+      for (size_t i = 0; i < n; ++i) {
+        std::memset(out + i * cs, 0, cs);
+        if (std::fseek(f, (long)(cell_idx[i] * cs), SEEK_SET) == 0) (void)!std::fread(out + i * cs, 1, cs, f);
+      }
+      std::fclose(f);
+      return CP2_OK;
+    }
+    case CellSrc::Fake:
+    case CellSrc::Dev: {
+      std::vector<uint64_t> g(n);
+      for (size_t i = 0; i < n; ++i) g[i] = slot * t->n_cells + cell_idx[i];
+      DevBuf d_g, d_out;
+      CP2_TRY(d_g.alloc(ctx, n * 8));
+      CP2_TRY(d_out.alloc(ctx, n * cs));
+      CP2_HIP(ctx, hipMemcpyAsync(d_g.p, g.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+      if (t->src == CellSrc::Fake) {
+        CP2_HIP(ctx, cp2k::launch_gen_fake_cells(cp2_slot_seed(t->dataset_seed, t->first_slot), t->n_cells, 0,
+                                                 static_cast<const uint64_t*>(d_g.p), n, cs, d_out.p, ctx->stream));
+      } else if ((cs & 3) == 0) {
+        CP2_HIP(ctx, cp2k::launch_gather_rows(t->d_cells, static_cast<const uint64_t*>(d_g.p), n, cs, d_out.p, ctx->stream));
+      } else {
+        for (size_t i = 0; i < n; ++i)
+          CP2_HIP(ctx, hipMemcpyAsync(d_out.u8() + i * cs, t->d_cells + g[i] * cs, cs, hipMemcpyDeviceToDevice, ctx->stream));
+      }
+      CP2_HIP(ctx, hipMemcpyAsync(out, d_out.p, n * cs, hipMemcpyDeviceToHost, ctx->stream));
+      CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      return CP2_OK;
+    }
+  }
+  return CP2_ERR_INVALID;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dataset
+// ---------------------------------------------------------------------------------------------
+struct cp2_dataset {
+  cp2_ctx* ctx = nullptr;
+  cp2_config cfg{};
+  std::string file_base;
+  bool from_file = false;
+  uint64_t first_slot = 0, n_local = 0;
+  cp2_slot_trees* trees = nullptr;
+  bool have_roots = false;
+  std::vector<size_t> dsizes;                 // dataset-tree layer sizes
+  std::vector<uint8_t> dlayers;               // all dataset-tree layers, bottom first (host copy)
+};
+
+extern "C" int cp2_dataset_build(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local,
+                                 cp2_dataset** out) {
+  if (!ctx || !cfg || !out) return CP2_ERR_INVALID;
+  *out = nullptr;
+  if (n_local == 0 || first_slot + n_local > cfg->n_slots) return CP2_ERR_INVALID;
+  if (cfg->max_depth < 0 || cfg->max_log2_nslots < 0) return CP2_ERR_INVALID;
+  cp2_dataset* ds = new (std::nothrow) cp2_dataset();
+  if (!ds) return CP2_ERR_ALLOC;
+  ds->ctx = ctx;
+  ds->cfg = *cfg;
+  ds->from_file = cfg->file_base != nullptr;
+  if (ds->from_file) ds->file_base = cfg->file_base;
+  ds->cfg.file_base = nullptr;
+  ds->first_slot = first_slot;
+  ds->n_local = n_local;
+  int st;
+  if (ds->from_file)
+    st = trees_build_files(ctx, ds->file_base, first_slot, n_local, cfg->cell_size, cfg->block_size, cfg->n_cells, &ds->trees);
+  else
+    st = cp2_slot_trees_build_fake(ctx, cfg->seed, first_slot, n_local, cfg->cell_size, cfg->block_size, cfg->n_cells, &ds->trees);
+  if (st != CP2_OK) { delete ds; return st; }
+  *out = ds;
+  return CP2_OK;
+}
+
+extern "C" void cp2_dataset_free(cp2_dataset* ds) {
+  if (!ds) return;
+  cp2_slot_trees_free(ds->trees);
+  delete ds;
+}
+
+extern "C" int cp2_dataset_local_roots(cp2_dataset* ds, uint8_t* out) {
+  if (!ds || !out) return CP2_ERR_INVALID;
+  return cp2_slot_trees_roots(ds->trees, out);
+}
+
+extern "C" int cp2_dataset_set_roots(cp2_dataset* ds, const uint8_t* all_roots) {
+  if (!ds) return CP2_ERR_INVALID;
+  cp2_ctx* ctx = ds->ctx;
+  const size_t n = ds->cfg.n_slots;
+  std::vector<uint8_t> roots(n * 32);
+  if (all_roots) {
+    std::memcpy(roots.data(), all_roots, n * 32);
+  } else {
+    if (ds->first_slot != 0 || ds->n_local != n) return CP2_ERR_INVALID;   // roots of other ranks' slots are missing
+    CP2_TRY(cp2_slot_trees_roots(ds->trees, roots.data()));
+  }
+  // dataset tree over the slot roots (gen_input/bn254.nim:49-50); odd layers use keys 2/3
+  ds->dsizes = layer_sizes_of(n);
+  size_t total = cp2_merkle_total(n);
+  ds->dlayers.assign(total * 32, 0);
+  CP2_TRY(cp2_merkle_tree(ctx, roots.data(), n, ds->dlayers.data(), nullptr, nullptr));
+  ds->have_roots = true;
+  return CP2_OK;
+}
+
+extern "C" int cp2_dataset_root(cp2_dataset* ds, uint8_t out[32]) {
+  if (!ds || !out) return CP2_ERR_INVALID;
+  if (!ds->have_roots) CP2_TRY(cp2_dataset_set_roots(ds, nullptr));
+  std::memcpy(out, &ds->dlayers[ds->dlayers.size() - 32], 32);
+  return CP2_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// proof input
+// ---------------------------------------------------------------------------------------------
+struct cp2_proof_input {
+  cp2_config cfg{};
+  uint64_t slot_idx = 0;
+  uint8_t entropy[32], dataset_root[32], slot_root[32];
+  std::vector<uint64_t> indices;
+  std::vector<uint8_t> cell_data, paths, slot_proof;
+};
+
+extern "C" int cp2_proof_input_generate(cp2_dataset* ds, uint64_t slot_idx, const uint8_t entropy[32], cp2_proof_input** out) {
+  if (!ds || !entropy || !out) return CP2_ERR_INVALID;
+  *out = nullptr;
+  const cp2_config& cfg = ds->cfg;
+  if (slot_idx < ds->first_slot || slot_idx >= ds->first_slot + ds->n_local) return CP2_ERR_INVALID;
+  if (!is_pow2(cfg.n_cells)) return CP2_ERR_INVALID;                    // sample/bn254.nim:19-20
+  if (!ds->have_roots) CP2_TRY(cp2_dataset_set_roots(ds, nullptr));
+  if (ds->dsizes.size() - 1 > (size_t)cfg.max_log2_nslots) return CP2_ERR_INVALID;   // padMerkleProof assert
+  cp2_proof_input* p = new (std::nothrow) cp2_proof_input();
+  if (!p) return CP2_ERR_ALLOC;
+  p->cfg = cfg;
+  p->slot_idx = slot_idx;
+  std::memcpy(p->entropy, entropy, 32);
+  std::memcpy(p->dataset_root, &ds->dlayers[ds->dlayers.size() - 32], 32);
+  std::memcpy(p->slot_root, &ds->dlayers[slot_idx * 32], 32);          // layer 0 of the dataset tree = slot roots
+
+  // slotProof = padMerkleProof(merkleProof(dsetTree, slotIdx), maxLog2NSlots), gen_input/bn254.nim:51,72
+  p->slot_proof.assign((size_t)cfg.max_log2_nslots * 32, 0);
+  {
+    size_t k = slot_idx, m = cfg.n_slots, off = 0;
+    for (size_t i = 0; i + 1 < ds->dsizes.size(); ++i) {
+      size_t j = k ^ 1;
+      if (j < m) std::memcpy(&p->slot_proof[i * 32], &ds->dlayers[(off + j) * 32], 32);
+      off += ds->dsizes[i];
+      k >>= 1;
+      m = (m + 1) >> 1;
+    }
+  }
+  int st = CP2_OK;
+  const size_t ns = cfg.n_samples, local = slot_idx - ds->first_slot;
+  p->indices.resize(ns);
+  p->cell_data.resize(ns * cfg.cell_size);
+  p->paths.resize(ns * (size_t)cfg.max_depth * 32);
+  st = cp2_cell_indices(ds->ctx, p->entropy, p->slot_root, cfg.n_cells, ns, p->indices.data());   // :53
+  if (st == CP2_OK) st = cp2_slot_trees_paths(ds->trees, local, p->indices.data(), ns, (size_t)cfg.max_depth, p->paths.data(), nullptr);
+  if (st == CP2_OK) st = trees_cells(ds->trees, local, p->indices.data(), ns, p->cell_data.data());
+  if (st != CP2_OK) { delete p; return st; }
+  *out = p;
+  return CP2_OK;
+}
+
+extern "C" void cp2_proof_input_free(cp2_proof_input* p) { delete p; }
+
+extern "C" int cp2_proof_input_roots(const cp2_proof_input* p, uint8_t dataset_root[32], uint8_t slot_root[32], uint8_t entropy[32]) {
+  if (!p) return CP2_ERR_INVALID;
+  if (dataset_root) std::memcpy(dataset_root, p->dataset_root, 32);
+  if (slot_root) std::memcpy(slot_root, p->slot_root, 32);
+  if (entropy) std::memcpy(entropy, p->entropy, 32);
+  return CP2_OK;
+}
+extern "C" size_t cp2_proof_input_nsamples(const cp2_proof_input* p) { return p ? p->indices.size() : 0; }
+extern "C" const uint64_t* cp2_proof_input_cell_indices(const cp2_proof_input* p) { return p ? p->indices.data() : nullptr; }
+extern "C" const uint8_t* cp2_proof_input_cell_data(const cp2_proof_input* p) { return p ? p->cell_data.data() : nullptr; }
+extern "C" const uint8_t* cp2_proof_input_merkle_paths(const cp2_proof_input* p) { return p ? p->paths.data() : nullptr; }
+extern "C" const uint8_t* cp2_proof_input_slot_proof(const cp2_proof_input* p) { return p ? p->slot_proof.data() : nullptr; }
+
+// ---- JSON (json/bn254.nim:57-74, json/shared.nim:17-25, types/bn254.nim:29-43) -----------------
+namespace {
+
+// canonical decimal of a 256-bit little-endian integer: no leading zeros, "0" for zero (toDecimalF)
+void append_quoted_decimal(std::string& s, const uint8_t* le32) {
+  uint32_t w[8];
+  std::memcpy(w, le32, 32);
+  char buf[80];
+  int pos = 80;
+  bool nonzero = true;
+  while (nonzero) {
+    uint64_t rem = 0;
+    nonzero = false;
+    for (int i = 7; i >= 0; --i) {
+      uint64_t cur = (rem << 32) | w[i];
+      w[i] = (uint32_t)(cur / 1000000000u);
+      rem = cur % 1000000000u;
+      if (w[i]) nonzero = true;
+    }
+    for (int d = 0; d < 9; ++d) {
+      buf[--pos] = (char)('0' + rem % 10);
+      rem /= 10;
+    }
+  }
+  while (pos < 79 && buf[pos] == '0') ++pos;
+  s.push_back('"');
+  s.append(buf + pos, 80 - pos);
+  s.push_back('"');
+}
+
+// writeList specialised to field elements: first "<prefix>[ x", then "<indent>, x", close "<indent>]"
+void write_felt_list(std::string& s, const std::string& prefix, const uint8_t* felts, size_t n) {
+  std::string indent(prefix.size(), ' ');
+  for (size_t i = 0; i < n; ++i) {
+    s += (i == 0) ? prefix + "[ " : indent + ", ";
+    append_quoted_decimal(s, felts + 32 * i);
+    s.push_back('\n');
+  }
+  s += indent + "]\n";
+}
+
+}  // namespace
+
+extern "C" int cp2_proof_input_json(const cp2_proof_input* p, char** text, size_t* len) {
+  if (!p || !text) return CP2_ERR_INVALID;
+  const cp2_config& cfg = p->cfg;
+  std::string s;
+  s.reserve(1 << 20);
+  s += "{\n";
+  s += "  \"dataSetRoot\":      "; append_quoted_decimal(s, p->dataset_root); s += "\n";
+  s += ", \"entropy\":          "; append_quoted_decimal(s, p->entropy); s += "\n";
+  s += ", \"nCellsPerSlot\":    " + std::to_string(cfg.n_cells) + "\n";
+  s += ", \"nSlotsPerDataSet\": " + std::to_string(cfg.n_slots) + "\n";
+  s += ", \"slotIndex\":        " + std::to_string(p->slot_idx) + "\n";
+  s += ", \"slotRoot\":         "; append_quoted_decimal(s, p->slot_root); s += "\n";
+  s += ", \"slotProof\":\n";
+  write_felt_list(s, "    ", p->slot_proof.data(), (size_t)cfg.max_log2_nslots);
+  const size_t ns = p->indices.size();
+  const std::string outer = "    ", outer_indent(outer.size(), ' ');
+  s += ", \"cellData\":\n";
+  {
+    size_t nf = cp2_felts_per_bytes(cfg.cell_size);
+    std::vector<uint8_t> felts(nf * 32);
+    for (size_t i = 0; i < ns; ++i) {
+      cp2_bytes_to_felts(&p->cell_data[i * cfg.cell_size], cfg.cell_size, felts.data());   // json/bn254.nim:25
+      write_felt_list(s, (i == 0) ? outer + "[ " : outer_indent + ", ", felts.data(), nf);
+    }
+    s += outer_indent + "]\n";
+  }
+  s += ", \"merklePaths\":\n";
+  for (size_t i = 0; i < ns; ++i)
+    write_felt_list(s, (i == 0) ? outer + "[ " : outer_indent + ", ", &p->paths[i * (size_t)cfg.max_depth * 32], (size_t)cfg.max_depth);
+  s += outer_indent + "]\n";
+  s += "}\n";
+  char* buf = (char*)std::malloc(s.size() + 1);
+  if (!buf) return CP2_ERR_ALLOC;
+  std::memcpy(buf, s.data(), s.size());
+  buf[s.size()] = 0;
+  *text = buf;
+  if (len) *len = s.size();
+  return CP2_OK;
+}
+
+extern "C" void cp2_free_buffer(void* p) { std::free(p); }
+
+extern "C" int cp2_proof_input_write_json(const cp2_proof_input* p, const char* path) {
+  if (!p || !path) return CP2_ERR_INVALID;
+  char* text = nullptr;
+  size_t len = 0;
+  CP2_TRY(cp2_proof_input_json(p, &text, &len));
+  FILE* f = std::fopen(path, "wb");
+  if (!f) { std::free(text); return CP2_ERR_IO; }
+  size_t w = std::fwrite(text, 1, len, f);
+  int rc = std::fclose(f);
+  std::free(text);
+  return (w == len && rc == 0) ? CP2_OK : CP2_ERR_IO;
+}
+
+extern "C" int cp2_write_circom_main(const cp2_config* cfg, const char* path) {
+  if (!cfg || !path || cfg->cell_size == 0) return CP2_ERR_INVALID;
+  if (cfg->block_size % cfg->cell_size) return CP2_ERR_INVALID;
+  uint64_t cpb = cfg->block_size / cfg->cell_size;
+  if (!is_pow2(cpb)) return CP2_ERR_INVALID;                     // exactLog2 assert, misc.nim:25-28
+  int depth = 0;
+  while ((1ULL << depth) < cpb) ++depth;
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return CP2_ERR_IO;
+  std::fprintf(f, "pragma circom 2.0.0;\n");
+  std::fprintf(f, "include \"sample_cells.circom\";\n");
+  std::fprintf(f, "// SampleAndProven( maxDepth, maxLog2NSlots, blockTreeDepth, nFieldElemsPerCell, nSamples )\n");
+  std::fprintf(f, "component main {public [entropy,dataSetRoot,slotIndex]} = SampleAndProve(%d, %d, %d, %llu, %llu);\n",
+               cfg->max_depth, cfg->max_log2_nslots, depth, (unsigned long long)((cfg->cell_size + 30) / 31),
+               (unsigned long long)cfg->n_samples);
+  return std::fclose(f) == 0 ? CP2_OK : CP2_ERR_IO;
+}

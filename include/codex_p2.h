@@ -1,0 +1,195 @@
+/* codex_p2.h -- C ABI of libcodex_p2.so: the MI355X (gfx950) Poseidon2-BN254 proof-input engine.
+ *
+ * This is the drop-in boundary for the hot path of codex-storage/codex-storage-proofs-circuits'
+ * `reference/nim/proof_input` tool (BN254 / Poseidon2 only).  The reference has no FFI for this path:
+ * its seam is the set of nim-poseidon2 / constantine calls made from `reference/nim/proof_input/src`
+ * (SURVEY.md section 8b).  Each entry point below names the reference call it replaces
+ * (paths relative to the reference repository root).  INTEGRATION.md shows the Nim `importc` shim.
+ *
+ * Conventions
+ *   - A field element (Fr of BN254) crosses the ABI as 32 bytes, little-endian, canonical integer in
+ *     [0, r).  Inputs >= r are accepted and taken mod r.  Never Montgomery limbs.
+ *   - Every function returns CP2_OK (0) or a negative cp2_status; nothing aborts across the ABI
+ *     (the reference's `assert`s map to CP2_ERR_INVALID; the Nim shim turns non-zero into raiseAssert).
+ *   - Plain functions take HOST pointers and are synchronous: inputs are copied to the GPU, the HIP
+ *     kernels run, outputs are copied back before return.
+ *   - `_dev` functions take HIP DEVICE pointers (16-byte aligned), enqueue on the context's stream and
+ *     return without synchronising; use cp2_sync().
+ *   - One context per host thread; contexts are independent.  There is no CPU fallback: without a
+ *     usable gfx950 device cp2_init fails with CP2_ERR_NO_DEVICE.
+ */
+#ifndef CODEX_P2_H
+#define CODEX_P2_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CP2_FELT_BYTES 32
+
+typedef enum cp2_status {
+  CP2_OK = 0,
+  CP2_ERR_INVALID = -1,    /* bad argument (the reference would fail an assert)            */
+  CP2_ERR_NO_DEVICE = -2,  /* no usable HIP device / wrong architecture                    */
+  CP2_ERR_HIP = -3,        /* a HIP runtime call failed; see cp2_last_error                */
+  CP2_ERR_ALLOC = -4,      /* host or device allocation failed                             */
+  CP2_ERR_IO = -5,         /* file could not be read / written                             */
+  CP2_ERR_ALIGN = -6       /* a _dev pointer is not 16-byte aligned                        */
+} cp2_status;
+
+typedef struct cp2_ctx cp2_ctx;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int cp2_init(int device, cp2_ctx** out);
+void cp2_free(cp2_ctx* ctx);
+/* Use a caller-owned HIP stream (hipStream_t) for all work of this context; NULL = the context's own. */
+int cp2_set_stream(cp2_ctx* ctx, void* hip_stream);
+int cp2_sync(cp2_ctx* ctx);
+const char* cp2_strerror(int status);
+const char* cp2_last_error(const cp2_ctx* ctx);
+/* 1 when the library's kernels were built for the device of `ctx` (gfx950). */
+int cp2_device_is_native(const cp2_ctx* ctx);
+
+/* ---- a1: Poseidon2 t=3 permutation --------------------------------------------------------- */
+/* replaces nim-poseidon2 `perm` as specified by reference/haskell/src/Poseidon2/Permutation.hs:40-45.
+ * in/out: n states of 3 field elements (n x 96 bytes). */
+int cp2_permute_batch(cp2_ctx* ctx, const uint8_t* in, uint8_t* out, size_t n);
+int cp2_permute_batch_dev(cp2_ctx* ctx, const void* d_in, void* d_out, size_t n);
+
+/* ---- a6: keyed compression ----------------------------------------------------------------- */
+/* replaces `compress(x, y, key = toF(key))`, reference/nim/proof_input/src/merkle/bn254.nim:18,50,53.
+ * xy: n pairs (n x 64 bytes); key in {0,1,2,3}; out: n x 32 bytes. */
+int cp2_compress_batch(cp2_ctx* ctx, const uint8_t* xy, uint32_t key, uint8_t* out, size_t n);
+
+/* ---- a3: sponge over field elements --------------------------------------------------------- */
+/* replaces `Sponge.digest(seq[F], rate = 2)`, reference/nim/proof_input/src/sample/bn254.nim:23. */
+int cp2_sponge2_felts(cp2_ctx* ctx, const uint8_t* felts, size_t n, uint8_t out[32]);
+/* batched: nitems inputs of nf elements each -> nitems digests */
+int cp2_sponge2_felts_batch(cp2_ctx* ctx, const uint8_t* felts, size_t nf, size_t nitems, uint8_t* out);
+int cp2_sponge2_felts_batch_dev(cp2_ctx* ctx, const void* d_felts, size_t nf, size_t nitems, void* d_out);
+
+/* ---- a4: bytes -> field elements (host only, no device work) --------------------------------- */
+/* replaces the iterator `elements(bytes, F)`, reference/nim/proof_input/src/json/bn254.nim:11,25
+ * (10* byte padding, 31-byte little-endian chunks; reference/haskell/src/Slot.hs:243-270). */
+size_t cp2_felts_per_bytes(size_t len);
+int cp2_bytes_to_felts(const uint8_t* data, size_t len, uint8_t* out /* cp2_felts_per_bytes(len) x 32 */);
+
+/* ---- a5: hashCell ---------------------------------------------------------------------------- */
+/* replaces `Sponge.digest(cellData, rate = 2)` over bytes, reference/nim/proof_input/src/blocks/bn254.nim:27.
+ * cells: n_cells contiguous cells of cell_size bytes; out: n_cells x 32 bytes. */
+int cp2_hash_cells(cp2_ctx* ctx, const uint8_t* cells, size_t cell_size, size_t n_cells, uint8_t* out);
+int cp2_hash_cells_dev(cp2_ctx* ctx, const void* d_cells, size_t cell_size, size_t n_cells, void* d_out);
+/* one byte string of any length (same function with n_cells = 1) */
+int cp2_hash_bytes(cp2_ctx* ctx, const uint8_t* data, size_t len, uint8_t out[32]);
+
+/* ---- a7: Merkle tree -------------------------------------------------------------------------- */
+/* replaces `merkleTreeBN254(xs)`, reference/nim/proof_input/src/merkle/bn254.nim:62-63 (all layers,
+ * bottom first; keys 1/0 and odd keys 3/2; a singleton still gets one compression).
+ * cp2_merkle_total(n) = number of elements over all layers; layers_out holds that many x 32 bytes.
+ * layer_sizes (may be NULL) receives the element count of each layer; *n_layers their number. */
+size_t cp2_merkle_total(size_t n);
+size_t cp2_merkle_num_layers(size_t n);
+int cp2_merkle_tree(cp2_ctx* ctx, const uint8_t* leaves, size_t n, uint8_t* layers_out, size_t* layer_sizes,
+                    size_t* n_layers);
+/* nseg independent trees of n leaves each, laid out back to back; d_layers_out: nseg x cp2_merkle_total(n)
+ * elements, tree-major (tree s starts at element s * cp2_merkle_total(n)). */
+int cp2_merkle_trees_dev(cp2_ctx* ctx, const void* d_leaves, size_t n, size_t nseg, void* d_layers_out);
+/* replaces `Merkle.digest(xs)`, reference/nim/proof_input/src/merkle/bn254.nim:20 */
+int cp2_merkle_root(cp2_ctx* ctx, const uint8_t* leaves, size_t n, uint8_t out[32]);
+
+/* ---- a10: fake slot data ---------------------------------------------------------------------- */
+/* replaces `genFakeCell`, reference/nim/proof_input/src/slot.nim:23-32, for cells first..first+n-1.
+ * `seed` is the slot's own seed; cp2_slot_seed = parametricSlotSeed, dataset.nim:32. */
+uint64_t cp2_slot_seed(uint64_t dataset_seed, uint64_t slot_idx);
+int cp2_gen_fake_cells(cp2_ctx* ctx, uint64_t seed, uint64_t first, size_t n, size_t cell_size, uint8_t* out);
+int cp2_gen_fake_cells_dev(cp2_ctx* ctx, uint64_t seed, uint64_t first, size_t n, size_t cell_size, void* d_out);
+
+/* ---- a12: sampling ---------------------------------------------------------------------------- */
+/* replaces `cellIndices`, reference/nim/proof_input/src/sample/bn254.nim:16-27 (counters 1..n_samples).
+ * n_cells must be a power of two. */
+int cp2_cell_indices(cp2_ctx* ctx, const uint8_t entropy[32], const uint8_t slot_root[32], uint64_t n_cells,
+                     size_t n_samples, uint64_t* out);
+
+/* ---- a8/a9/a13: slot trees (device resident) --------------------------------------------------- */
+/* A batch of `n_slots` slot trees of identical geometry, as built by `buildSlotTreeFull`,
+ * reference/nim/proof_input/src/gen_input/bn254.nim:21-30: per block a tree over its cell hashes
+ * (bottom key 1), then per slot a tree over the block roots (bottom key 1 again). */
+typedef struct cp2_slot_trees cp2_slot_trees;
+
+/* slots first_slot..first_slot+n_slots-1 of a fake-data dataset (cells generated on the device) */
+int cp2_slot_trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_slot, size_t n_slots,
+                              size_t cell_size, size_t block_size, size_t n_cells, cp2_slot_trees** out);
+/* n_slots slots whose cells are already in device memory, slot-major (n_slots x n_cells x cell_size bytes) */
+int cp2_slot_trees_build_dev(cp2_ctx* ctx, const void* d_cells, size_t n_slots, size_t cell_size, size_t block_size,
+                             size_t n_cells, cp2_slot_trees** out);
+/* same from host memory (streamed through a pinned staging buffer) */
+int cp2_slot_trees_build_host(cp2_ctx* ctx, const uint8_t* cells, size_t n_slots, size_t cell_size,
+                              size_t block_size, size_t n_cells, cp2_slot_trees** out);
+void cp2_slot_trees_free(cp2_slot_trees* t);
+size_t cp2_slot_trees_count(const cp2_slot_trees* t);
+size_t cp2_slot_trees_depth(const cp2_slot_trees* t);   /* log2(cellsPerBlock) + log2(nBlocks) */
+/* roots of all slots in the batch (n_slots x 32 bytes): `treeRoot(bigTree)`, merkle.nim:14-17 */
+int cp2_slot_trees_roots(cp2_slot_trees* t, uint8_t* out);
+/* device pointer to the same roots (n_slots x 32 bytes, canonical), valid until free */
+const void* cp2_slot_trees_roots_dev(const cp2_slot_trees* t);
+/* merged bottom+top Merkle paths (merkleProof + mergeMerkleProofs, merkle.nim:21-42,86-100) of
+ * n cells of slot `slot` (index inside the batch), padded with zeros to max_depth (types.nim:27-37).
+ * out: n x max_depth x 32 bytes; leaf_hashes (may be NULL): n x 32 bytes. */
+int cp2_slot_trees_paths(cp2_slot_trees* t, size_t slot, const uint64_t* cell_idx, size_t n, size_t max_depth,
+                         uint8_t* out, uint8_t* leaf_hashes);
+
+/* ---- a14/a15: proof input ----------------------------------------------------------------------- */
+/* mirrors GlobalConfig + DataSetConfig, reference/nim/proof_input/src/types.nim:82-101 */
+typedef struct cp2_config {
+  int32_t max_depth;        /* GlobalConfig.maxDepth                                 */
+  int32_t max_log2_nslots;  /* GlobalConfig.maxLog2NSlots                            */
+  uint64_t cell_size;       /* GlobalConfig.cellSize                                 */
+  uint64_t block_size;      /* GlobalConfig.blockSize                                */
+  uint64_t n_slots;         /* DataSetConfig.nSlots                                  */
+  uint64_t n_cells;         /* DataSetConfig.nCells (power of two)                   */
+  uint64_t n_samples;       /* DataSetConfig.nSamples                                */
+  uint64_t seed;            /* DataSource FakeData seed (used when file_base == NULL) */
+  const char* file_base;    /* DataSource SlotFile base name: slot k = "<base><k>.dat" (dataset.nim:34) */
+} cp2_config;
+
+/* A dataset whose slot trees are built: slot roots + dataset tree (gen_input/bn254.nim:41-51). */
+typedef struct cp2_dataset cp2_dataset;
+/* Builds the trees of slots [first_slot, first_slot + n_local) on this GPU.  For a single GPU pass
+ * first_slot = 0, n_local = cfg->n_slots.  */
+int cp2_dataset_build(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local, cp2_dataset** out);
+void cp2_dataset_free(cp2_dataset* ds);
+/* roots of the local slots (n_local x 32 bytes) */
+int cp2_dataset_local_roots(cp2_dataset* ds, uint8_t* out);
+/* Supply the roots of ALL n_slots slots (after the multi-GPU gather; single GPU: pass NULL to use the
+ * local ones) and build the dataset-level tree on the GPU. */
+int cp2_dataset_set_roots(cp2_dataset* ds, const uint8_t* all_roots);
+int cp2_dataset_root(cp2_dataset* ds, uint8_t out[32]);
+
+/* SlotProofInput, reference/nim/proof_input/src/types.nim:52-60 */
+typedef struct cp2_proof_input cp2_proof_input;
+/* replaces `generateProofInputBN254`, reference/nim/proof_input/src/gen_input/bn254.nim:35-79, for a
+ * slot that is local to `ds`. */
+int cp2_proof_input_generate(cp2_dataset* ds, uint64_t slot_idx, const uint8_t entropy[32], cp2_proof_input** out);
+void cp2_proof_input_free(cp2_proof_input* p);
+/* accessors (all field elements canonical 32-byte LE) */
+int cp2_proof_input_roots(const cp2_proof_input* p, uint8_t dataset_root[32], uint8_t slot_root[32], uint8_t entropy[32]);
+size_t cp2_proof_input_nsamples(const cp2_proof_input* p);
+const uint64_t* cp2_proof_input_cell_indices(const cp2_proof_input* p);
+const uint8_t* cp2_proof_input_cell_data(const cp2_proof_input* p);     /* nSamples x cellSize bytes      */
+const uint8_t* cp2_proof_input_merkle_paths(const cp2_proof_input* p);  /* nSamples x maxDepth x 32 bytes */
+const uint8_t* cp2_proof_input_slot_proof(const cp2_proof_input* p);    /* maxLog2NSlots x 32 bytes       */
+/* replaces `exportProofInputBN254`, reference/nim/proof_input/src/json/bn254.nim:57-78: byte-exact JSON */
+int cp2_proof_input_write_json(const cp2_proof_input* p, const char* path);
+/* the same text into a malloc'ed buffer (caller frees with cp2_free_buffer) */
+int cp2_proof_input_json(const cp2_proof_input* p, char** text, size_t* len);
+void cp2_free_buffer(void* p);
+/* replaces `writeCircomMainComponent`, reference/nim/proof_input/src/cli.nim:186-204 */
+int cp2_write_circom_main(const cp2_config* cfg, const char* path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CODEX_P2_H */
