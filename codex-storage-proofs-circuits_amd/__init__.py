@@ -70,6 +70,7 @@ def load_library():
         "cp2_init": (i32, [i32, pvp]),
         "cp2_free": (None, [vp]),
         "cp2_set_stream": (i32, [vp, vp]),
+        "cp2_reset_stream": (i32, [vp]),
         "cp2_sync": (i32, [vp]),
         "cp2_strerror": (cp, [i32]),
         "cp2_last_error": (cp, [vp]),
@@ -190,6 +191,9 @@ class Context:
     # -- plumbing
     def set_stream(self, stream_ptr):
         self._ck(self.L.cp2_set_stream(self.h, ctypes.c_void_p(stream_ptr)), "cp2_set_stream")
+
+    def reset_stream(self):
+        self._ck(self.L.cp2_reset_stream(self.h), "cp2_reset_stream")
 
     def sync(self):
         self._ck(self.L.cp2_sync(self.h), "cp2_sync")

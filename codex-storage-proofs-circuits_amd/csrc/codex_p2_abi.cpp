@@ -54,7 +54,13 @@ extern "C" void cp2_free(cp2_ctx* ctx) {
 
 extern "C" int cp2_set_stream(cp2_ctx* ctx, void* hip_stream) {
   if (!ctx) return CP2_ERR_INVALID;
-  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  ctx->stream = (hipStream_t)hip_stream;
+  return CP2_OK;
+}
+
+extern "C" int cp2_reset_stream(cp2_ctx* ctx) {
+  if (!ctx) return CP2_ERR_INVALID;
+  ctx->stream = ctx->own_stream;
   return CP2_OK;
 }
 

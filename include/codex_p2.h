@@ -45,8 +45,11 @@ typedef struct cp2_ctx cp2_ctx;
 /* ---- context ------------------------------------------------------------------------------ */
 int cp2_init(int device, cp2_ctx** out);
 void cp2_free(cp2_ctx* ctx);
-/* Use a caller-owned HIP stream (hipStream_t) for all work of this context; NULL = the context's own. */
+/* Use a caller-owned HIP stream (hipStream_t) for all work of this context.  The handle is used as is:
+ * NULL is HIP's legacy default stream (what torch.cuda.current_stream().cuda_stream returns by default).
+ * cp2_reset_stream goes back to the context's own non-blocking stream. */
 int cp2_set_stream(cp2_ctx* ctx, void* hip_stream);
+int cp2_reset_stream(cp2_ctx* ctx);
 int cp2_sync(cp2_ctx* ctx);
 const char* cp2_strerror(int status);
 const char* cp2_last_error(const cp2_ctx* ctx);
@@ -94,8 +97,10 @@ size_t cp2_merkle_total(size_t n);
 size_t cp2_merkle_num_layers(size_t n);
 int cp2_merkle_tree(cp2_ctx* ctx, const uint8_t* leaves, size_t n, uint8_t* layers_out, size_t* layer_sizes,
                     size_t* n_layers);
-/* nseg independent trees of n leaves each, laid out back to back; d_layers_out: nseg x cp2_merkle_total(n)
- * elements, tree-major (tree s starts at element s * cp2_merkle_total(n)). */
+/* nseg independent trees of n leaves each (d_leaves: nseg x n elements, tree after tree).
+ * d_layers_out: nseg x cp2_merkle_total(n) elements, LAYER-major: layer k of all trees is contiguous
+ * (it starts at element nseg * (size_0 + ... + size_{k-1})), tree s at offset s * size_k inside it.
+ * d_layers_out may equal d_leaves (the leaves are then layer 0 in place). */
 int cp2_merkle_trees_dev(cp2_ctx* ctx, const void* d_leaves, size_t n, size_t nseg, void* d_layers_out);
 /* replaces `Merkle.digest(xs)`, reference/nim/proof_input/src/merkle/bn254.nim:20 */
 int cp2_merkle_root(cp2_ctx* ctx, const uint8_t* leaves, size_t n, uint8_t out[32]);

@@ -397,64 +397,60 @@ def circom_main(cfg):
 # --------------------------------------------------------------------------------------
 
 def circuit_root_from_path(leaf, path_bits, last_bits, mask_bits, path):
-    """circuit/codex/merkle.circom:44-114 RootFromMerklePath.
+    """circuit/codex/merkle.circom:44-114 RootFromMerklePath, signal for signal.
 
-    path_bits: index bits (LSB first); last_bits: bits of (nLeaves-1); mask_bits[i] = 1 while
-    i < ceil(log2 nLeaves) (merkle.circom:69-72).  Returns the recomputed root."""
+    path_bits / last_bits: bits of the leaf index / of the last index, LSB first (length depth);
+    mask_bits: depth+1 bits [1,..,1,0,..,0]; path: depth siblings.  Returns recRoot."""
     depth = len(path)
+    assert len(path_bits) == depth and len(last_bits) == depth and len(mask_bits) == depth + 1
+    mc = [1] + list(mask_bits[1:])                       # maskBitsCorrected, merkle.circom:60-62
     aux = [0] * (depth + 1)
     aux[0] = leaf
-    # isLast[i] = 1 iff index>>i == last>>i  (merkle.circom:74-91)
-    is_last = [0] * (depth + 1)
+    is_last = [0] * (depth + 1)                          # merkle.circom:73-80
     is_last[depth] = 1
     for i in range(depth - 1, -1, -1):
         is_last[i] = is_last[i + 1] * (1 if path_bits[i] == last_bits[i] else 0)
-    for i in range(depth):
+    for i in range(depth):                               # merkle.circom:85-103
         bottom = 1 if i == 0 else 0
         odd = is_last[i] * (1 - path_bits[i])
-        key = bottom + 2 * odd
-        L, Rr = (path[i], aux[i]) if path_bits[i] else (aux[i], path[i])
-        if odd:
-            Rr = 0
-        aux[i + 1] = compress(L, Rr, key)
-    # the root is aux[k] where k = number of mask bits set
-    k = sum(mask_bits)
-    return aux[k]
+        L, Rr = aux[i], path[i]
+        sw = ((Rr - L) * path_bits[i]) % R_MOD
+        aux[i + 1] = compress((L + sw) % R_MOD, (Rr - sw) % R_MOD, bottom + 2 * odd)
+    return sum((mc[i] - mc[i + 1]) * aux[i + 1] for i in range(depth)) % R_MOD   # merkle.circom:106-112
 
 
 def circuit_check(p, cfg):
-    """Re-derives what SampleAndProve constrains: every sampled cell hashes up to slotRoot through
-    a bottom tree of depth log2(cellsPerBlock) and a middle tree, the slot root hashes up to
-    dataSetRoot, and each cell index equals the sampled index.  Returns True or raises."""
+    """What `SampleAndProve` constrains (circuit/codex/sample_cells.circom:58-148 with
+    single_cell.circom:30-73): the dataset-root check, then per sample the index derivation, the cell hash,
+    the bottom (block) tree and the middle tree up to slotRoot.  Returns True or raises AssertionError."""
     cpb = cfg["blockSize"] // cfg["cellSize"]
     bot_depth = ceiling_log2(cpb)
-    max_depth = cfg["maxDepth"]
-    n_cells = p["nCells"]
-    log2n = ceiling_log2(n_cells)
-    for counter, q in enumerate(p["proofInputs"], start=1):
-        idx = cell_index(p["entropy"], p["slotRoot"], n_cells, counter)
-        assert idx == q["merkleProof"]["leafIndex"], "sample index mismatch"
-        leaf = sponge2(bytes_to_felts(q["cellData"]))
+    max_depth, max_slots_log = cfg["maxDepth"], cfg["maxLog2NSlots"]
+    n_cells, n_slots = p["nCells"], p["nSlots"]
+    # --- top: sample_cells.circom:95-109 (ToBits(slotIndex), CeilingLog2(nSlots): bits of nSlots-1, mask)
+    sidx = p["slotIndex"]
+    sbits = [(sidx >> i) & 1 for i in range(max_slots_log)]
+    lbits = [((n_slots - 1) >> i) & 1 for i in range(max_slots_log)]
+    mask = [1 if ((n_slots - 1) >> i) != 0 else 0 for i in range(max_slots_log)] + [0]   # lib/log2.circom:108-130
+    sp = p["slotProof"]["merklePath"]
+    assert len(sp) == max_slots_log
+    assert circuit_root_from_path(p["slotRoot"], sbits, lbits, mask, sp) == p["dataSetRoot"], "dataset root mismatch"
+    # --- samples: sample_cells.circom:114-146
+    lgmask = [1 if (1 << i) < n_cells else 0 for i in range(max_depth + 1)]               # lib/log2.circom:76-78
+    assert lgmask[0] == 1 and lgmask[max_depth] == 0
+    last_bits = lgmask[:max_depth]
+    assert len(p["proofInputs"]) == cfg["nSamples"]
+    for cnt, q in enumerate(p["proofInputs"]):
+        h = sponge2([p["entropy"], p["slotRoot"], cnt + 1])                                # :23-48
+        index_bits = [lgmask[i] * ((h >> i) & 1) for i in range(max_depth)]
+        felts = bytes_to_felts(q["cellData"])
+        assert len(felts) == (cfg["cellSize"] + 30) // 31
+        leaf = sponge2(felts)                                                               # single_cell.circom:63-65
         path = q["merkleProof"]["merklePath"]
         assert len(path) == max_depth
-        bits = [(idx >> i) & 1 for i in range(max_depth)]
-        last = n_cells - 1
-        lbits = [(last >> i) & 1 for i in range(max_depth)]
-        # bottom tree: full tree of cpb leaves (single_cell.circom:41-52)
-        bot_root = circuit_root_from_path(leaf, bits[:bot_depth], [1] * bot_depth, [1] * bot_depth, path[:bot_depth])
-        mid_bits = bits[bot_depth:]
-        mid_last = lbits[bot_depth:]
-        mid_mask = [1 if i < log2n - bot_depth else 0 for i in range(max_depth - bot_depth)]
-        root = circuit_root_from_path(bot_root, mid_bits, mid_last, mid_mask, path[bot_depth:])
-        assert root == p["slotRoot"], "slot root mismatch for sample %d" % counter
-    # dataset tree (sample_cells.circom:95-109)
-    ml = len(p["slotProof"]["merklePath"])
-    sidx = p["slotIndex"]
-    last = p["nSlots"] - 1
-    sbits = [(sidx >> i) & 1 for i in range(ml)]
-    lbits = [(last >> i) & 1 for i in range(ml)]
-    lg = ceiling_log2(p["nSlots"]) if p["nSlots"] > 1 else 1  # a 1-slot dataset still has one (key 3) level
-    mask = [1 if i < lg else 0 for i in range(ml)]
-    root = circuit_root_from_path(p["slotRoot"], sbits, lbits, mask, p["slotProof"]["merklePath"])
-    assert root == p["dataSetRoot"], "dataset root mismatch"
+        bot = circuit_root_from_path(leaf, index_bits[:bot_depth], last_bits[:bot_depth],
+                                     lgmask[:bot_depth] + [0], path[:bot_depth])           # single_cell.circom:41-60
+        mid = circuit_root_from_path(bot, index_bits[bot_depth:], last_bits[bot_depth:],
+                                     lgmask[bot_depth:max_depth] + [0], path[bot_depth:])
+        assert mid == p["slotRoot"], "slot root mismatch for sample %d" % (cnt + 1)        # single_cell.circom:71
     return True

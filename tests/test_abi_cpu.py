@@ -1,0 +1,92 @@
+"""CPU suite, part 2: the C-ABI library builds for gfx950, loads, exports every declared symbol, its
+host-only entry points agree with the oracle, and it FAILS LOUDLY without a GPU (no fallback)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+
+def _have_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_library_builds_and_exports_every_header_symbol(pkg):
+    L = pkg.load_library()
+    names = pkg.exported_symbols()
+    assert len(names) >= 50
+    for n in names:
+        assert hasattr(L, n), "include/codex_p2.h declares %s but the library does not export it" % n
+    # and the binding covers the whole header
+    assert set(names) == set(L._cp2_signatures.keys())
+
+
+def test_code_object_is_gfx950_only(pkg):
+    import re
+    blob = open(pkg.LIB_PATH, "rb").read()
+    targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob))
+    assert targets == {b"gfx950"}, targets
+
+
+def test_no_gpu_means_loud_failure(pkg):
+    if _have_gpu():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.CodexP2Error) as e:
+        pkg.Context(0)
+    assert e.value.status == -2   # CP2_ERR_NO_DEVICE
+
+
+def test_product_never_imports_the_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkgdir = os.path.join(root, "codex-storage-proofs-circuits_amd")
+    for dirpath, _, files in os.walk(pkgdir):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h", ".inc")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "p2_oracle" not in text and "libp2oracle" not in text, f
+                assert "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_host_only_entry_points_match_oracle(pkg, oracle):
+    C, P = oracle
+    L = pkg.load_library()
+    for n in (0, 1, 30, 31, 32, 62, 2048):
+        assert L.cp2_felts_per_bytes(n) == len(P.bytes_to_felts(bytes(n)))
+        data = np.frombuffer(bytes((i * 7 + 3) & 0xFF for i in range(n)), dtype=np.uint8).copy()
+        out = np.zeros((L.cp2_felts_per_bytes(n), 32), dtype=np.uint8)
+        assert L.cp2_bytes_to_felts(ctypes.c_void_p(data.ctypes.data) if n else None, n, ctypes.c_void_p(out.ctypes.data)) == 0
+        assert pkg.array_to_felts(out) == P.bytes_to_felts(data.tobytes())
+    for n in (1, 2, 3, 5, 32, 33, 1 << 17):
+        layers = P.merkle_tree(list(range(n))) if n <= 33 else None
+        if layers:
+            assert L.cp2_merkle_num_layers(n) == len(layers)
+            assert L.cp2_merkle_total(n) == sum(len(l) for l in layers)
+        assert L.cp2_merkle_total(n) == C.lib().p2o_merkle_total(n)
+    assert L.cp2_slot_seed(12345, 3) == P.slot_seed(12345, 3)
+
+
+def test_circom_main_text(pkg, golden, tmp_path):
+    for name, m in golden("proof_inputs.json")["inputs"].items():
+        c = m["config"]
+        cfg = pkg.make_config(**c)
+        path = str(tmp_path / (name + ".circom"))
+        pkg.write_circom_main(cfg, path)
+        assert open(path).read() == m["circom_main"]
+    bad = pkg.make_config(cellSize=2048, blockSize=2048 * 3)
+    with pytest.raises(pkg.CodexP2Error):
+        pkg.write_circom_main(bad, str(tmp_path / "x.circom"))       # exactLog2 assert, misc.nim:25-28
+
+
+def test_shard_ranges_cover_everything(entry):
+    import importlib
+    entry.load_package()
+    d = importlib.import_module("codex_storage_proofs_circuits_amd.distributed")
+    for n in (1, 7, 8, 11, 4096, 32768):
+        for world in (1, 2, 3, 8):
+            got = []
+            for r in range(world):
+                f, c = d.shard_range(n, r, world)
+                got += list(range(f, f + c))
+            assert got == list(range(n))
