@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on its config: Poseidon2-BN254 permutations/s per GPU.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: the batched permutation kernel over 2^24 states
+(BASELINE.json configs[1], 1.5 GiB in + 1.5 GiB out, already resident in HBM when the clock starts).
+With N ranks every rank runs the same batch on its own GPU (weak scaling, no data-path collective: the
+permutation has no exchange step); value = all states of all ranks / max-over-ranks time.
+
+The JSON line also carries
+  roofline      the dominant kernel (k_permute_batch) against the HBM roof BASELINE.json prescribes:
+                achieved = 192 algorithmic B/permutation x 2^24 / average launch time (HIP events on the
+                launch stream).  The kernel is VALU-integer bound, so `frac` is small by nature;
+                `valu` reports the instruction-issue view next to it.
+  cpu_baseline  the C oracle (a port of the same algorithm, NOT the Nim binary: no Nim toolchain exists)
+                timed on this box's host cores on a bounded sample, rank 0 at N=1 only.
+  extra         config 3 (8 GiB slot -> slot root: sponge + trees) and, for N>1, the config-5 exchange
+                (RCCL all-gather of slot roots -> dataset root) on a small dataset.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0             # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_PERM = 192               # 96 B in + 96 B out per permutation (config 2)
+N_STATES = 1 << 24                 # BASELINE.json configs[1]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--states", type=int, default=N_STATES, help="states per step per GPU (default 2^24)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config-3 / config-5 extra legs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (see the docstring)" % args.gpus)
+        raise SystemExit("WORLD_SIZE=%d but --gpus=%d" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+
+    pkg = g.load_package()
+    ctx = pkg.Context(local_rank)                        # raises without a gfx950 GPU: no fallback
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+
+    n = args.states
+    gen = torch.Generator(device=dev).manual_seed(0xC0DE + rank)
+    x = torch.randint(0, 256, (n, 96), dtype=torch.uint8, device=dev, generator=gen)
+    for off in (31, 63, 95):
+        x[:, off] &= 0x1F                                # < 2^253 < r: canonical, effectively uniform
+    y = torch.empty_like(x)
+
+    def step():
+        ctx.permute_batch_dev(x.data_ptr(), y.data_ptr(), n)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record(stream)
+    for i in range(args.steps):
+        step()
+        ev[i + 1].record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    total_perms = n * args.steps * world
+    value = total_perms / elapsed
+
+    # ---- sanity: the result of the timed kernel is the reference permutation (a few states, vs the oracle)
+    C, P = g.load_oracle()
+    import numpy as np
+    idx = torch.tensor([0, 1, n // 2, n - 1], device=dev)
+    assert np.array_equal(y[idx].cpu().numpy(), C.permute_batch(x[idx].cpu().numpy())), "bench output != oracle"
+
+    avg_ms = sum(kernel_ms) / len(kernel_ms)
+    achieved = BYTES_PER_PERM * n / (avg_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 correction + WRITE_SIZE, separate rocprofv3
+    # passes; summary committed under profiles/).  It is a property of the 2^24-state launch only.
+    traffic, valu = None, None
+    tpath = os.path.join(ROOT, "profiles", "r01_permute_batch_traffic.json")
+    if os.path.exists(tpath) and n == N_STATES:
+        try:
+            prof = json.load(open(tpath))
+            traffic = prof.get("hbm_bytes_per_launch")
+            ipw = prof.get("valu_insts_per_wave")
+            if ipw:
+                # the real ceiling: VALU issue.  Measured (tools/ubench_valu.hip): the VOP3 integer ops this kernel
+                # is made of (v_mad_u64_u32 and friends) issue once per 4 cycles per SIMD; 1024 SIMDs at 2.4 GHz.
+                wave_insts = ipw * n / 64
+                peak = 1024 * 2.4e9 / 4
+                valu = {"bound": "valu-issue", "achieved": wave_insts / (avg_ms * 1e-3), "peak": peak,
+                        "unit": "wave-instructions/s", "frac": round(wave_insts / (avg_ms * 1e-3) / peak, 4),
+                        "valu_insts_per_permutation": ipw, "source": "SQ_INSTS_VALU, profiles/r01_permute_batch_traffic.json"}
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                "kernel": "k_permute_batch", "avg_launch_ms": round(avg_ms, 4),
+                "algorithmic_bytes_per_launch": BYTES_PER_PERM * n,
+                "note": "VALU-integer bound by construction (about 6.1e4 VALU instructions per permutation against 192 B); see DESIGN.md"}
+
+    out = {
+        "metric": "Poseidon2-BN254 permutations/sec per GPU; full proof-input witnesses/sec",
+        "value": value, "unit": "permutations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32x9 (29-bit limbs, Montgomery mod BN254 r)", "data": "synthetic",
+        "config": {"workload": "configs[1]: batched Poseidon2 t=3 permutation, 2^%d random canonical Fr states per GPU per step, bit-exact vs oracle"
+                               % (n.bit_length() - 1), "states_per_gpu": n, "parallelism": "independent shards, %d rank(s)" % world},
+        "per_gpu_value": value / world,
+        "roofline": roofline,
+    }
+    if valu:
+        out["valu_roofline"] = valu
+
+    # ---- extra legs (outside the timed region) -------------------------------------------------------
+    extra = {}
+    if not args.no_extra:
+        try:
+            extra.update(slot_root_leg(torch, ctx, pkg, C, dev, stream))
+        except Exception as e:   # never lose the headline line to an extra leg
+            extra["slot_root_error"] = repr(e)
+        if world > 1:
+            try:
+                extra.update(dataset_leg(torch, dist, ctx, pkg, C, dev, rank, world))
+            except Exception as e:
+                extra["dataset_error"] = repr(e)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(C, np)
+    if extra:
+        out["extra"] = extra
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def slot_root_leg(torch, ctx, pkg, C, dev, stream):
+    """Config 3: one 8 GiB fake slot resident in HBM -> cell hashes (34 perms/cell) -> block + slot trees."""
+    n_cells, cs, bs = 1 << 22, 2048, 65536
+    buf = torch.empty((n_cells, cs), dtype=torch.uint8, device=dev)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    e[0].record(stream)
+    ctx.gen_fake_cells_dev(C.slot_seed(12345, 0), 0, n_cells, cs, buf.data_ptr())
+    e[1].record(stream)
+    trees = ctx.slot_trees_dev(buf.data_ptr(), 1, cs, bs, n_cells)     # warm-up pass
+    torch.cuda.synchronize()
+    trees.free()
+    e[2].record(stream)
+    trees = ctx.slot_trees_dev(buf.data_ptr(), 1, cs, bs, n_cells)
+    e[3].record(stream)
+    torch.cuda.synchronize()
+    root = trees.roots()[0]
+    gen_ms, build_ms = e[0].elapsed_time(e[1]), e[2].elapsed_time(e[3])
+    perms = 35 * n_cells - 1
+    alg_bytes = n_cells * cs + 2 * 32 * n_cells      # cells read once, leaf layer written and read back
+    del buf
+    return {"slot_root": {"workload": "configs[2]: cellSize=2048, nCells=2^22 (8 GiB) sponge+tree, 1 GPU",
+                          "build_ms": round(build_ms, 2), "perms": perms, "perms_per_s": perms / (build_ms * 1e-3),
+                          "algorithmic_GBps": round(alg_bytes / (build_ms * 1e-3) / 1e9, 2),
+                          "fake_data_gen_ms": round(gen_ms, 2), "slot_root_hex": root.tobytes()[::-1].hex()}}
+
+
+def dataset_leg(torch, dist, ctx, pkg, C, dev, rank, world):
+    """Config 5's exchange step at a small scale: slots sharded over ranks, RCCL all-gather of 32-byte slot
+    roots, dataset tree on every rank; every rank must get the same root."""
+    import importlib
+    d = importlib.import_module("codex_storage_proofs_circuits_amd.distributed")
+    n_slots = 64 * world
+    cfg = pkg.make_config(maxDepth=32, maxLog2NSlots=max(1, (n_slots - 1).bit_length()), cellSize=2048, blockSize=65536,
+                          nSlots=n_slots, nCells=1 << 12, nSamples=100, seed=12345)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    root, all_roots, (first, count) = d.dataset_root_sharded(d.HipBackend(pkg, ctx), cfg, rank, world, dist, dev)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    r = torch.from_numpy(root.copy()).to(dev)
+    rs = [torch.empty_like(r) for _ in range(world)]
+    dist.all_gather(rs, r)
+    same = all(torch.equal(rs[0], q) for q in rs)
+    perms = n_slots * (35 * (1 << 12) - 1) + n_slots - 1
+    return {"dataset": {"workload": "configs[4] shape scaled: %d slots x 2^12 cells sharded over %d GPUs, RCCL all-gather of slot roots -> dataset root" % (n_slots, world),
+                        "seconds": round(dt, 4), "perms_per_s": perms / dt, "all_ranks_agree": bool(same),
+                        "dataset_root_hex": root.tobytes()[::-1].hex()}}
+
+
+def cpu_baseline(C, np):
+    """The oracle timed on this box's host cores on a bounded sample of the same workload (config 2 shape)."""
+    # a one-GPU box's CPU share is 16 cores even though more are visible; never oversubscribe it
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
+    rng = np.random.default_rng(0xC0DE)
+    n1 = 1 << 17
+    x = rng.integers(0, 256, size=(n1, 96), dtype=np.uint8)
+    x[:, 31] &= 0x1F
+    x[:, 63] &= 0x1F
+    x[:, 95] &= 0x1F
+    t = time.perf_counter()
+    C.permute_batch(x, threads=1)
+    single = n1 / (time.perf_counter() - t)
+    nm = min(1 << 21, n1 * 2 * cores)
+    xm = np.tile(x, (nm // n1, 1))
+    t = time.perf_counter()
+    C.permute_batch(xm, threads=cores)
+    multi = nm / (time.perf_counter() - t)
+    return {"value": multi, "unit": "permutations/s", "cores": cores, "kind": "port",
+            "sample": "C oracle (oracle/p2_oracle.c, 4x64-bit Montgomery; NOT the Nim reference binary, which cannot be built here): "
+                      "%d states on %d threads; single-thread rate on %d states reported beside it" % (nm, cores, n1),
+            "single_thread_value": single}
+
+
+if __name__ == "__main__":
+    main()
