@@ -370,3 +370,51 @@ def test_config4_shape_many_slots_batched(pkg, ctx, oracle):
                          for i in range(3)]}
     c3 = dict(c, nSamples=3)
     assert P.circuit_check(p, c3)
+
+
+# ---- host layer: the cli twin and the C++ mirror of the Nim interface ------------------------------------
+def test_cli_twin_params_sh_defaults(pkg, golden, tmp_path):
+    """workflow/prove.sh:26 / workflow/setup.sh:13 with workflow/cli_args.sh's flags: byte-exact input.json."""
+    import subprocess
+    m = golden("proof_inputs.json")["inputs"]["params_default"]
+    args = ["--depth=32", "--maxslots=256", "--cellsize=2048", "--blocksize=65536", "--nsamples=5", "--entropy=1234567",
+            "--seed=12345", "--nslots=11", "--ncells=512", "--index=3", "--field=bn254", "--hash=poseidon2"]
+    out, circ = str(tmp_path / "input.json"), str(tmp_path / "proof_main.circom")
+    r = subprocess.run([pkg.CLI_PATH] + args + ["-v", "--output=" + out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "nCells     = 512" in r.stdout and r.stdout.rstrip().endswith("done")
+    assert open(out).read() == golden("input_params_default.json")
+    r = subprocess.run([pkg.CLI_PATH] + args + ["--circom=" + circ], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and open(circ).read() == m["circom_main"]
+    # short options and ':' separators (std/parseopt forms), testMain.hs small configuration
+    m2 = golden("proof_inputs.json")["inputs"]["testmain_small"]
+    out2 = str(tmp_path / "small.json")
+    r = subprocess.run([pkg.CLI_PATH, "-d:16", "-N=32", "-c128", "-b:4096", "-n=10", "-e:1234567", "-S12345", "-s=5", "-K:256",
+                        "-i3", "-F:bn254", "-H=poseidon2", "-o=" + out2], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert open(out2).read() == golden("input_testmain_small.json")
+    # the reference's default field is Goldilocks (cli.nim:48): out of scope here, must fail loudly, not fall back
+    r = subprocess.run([pkg.CLI_PATH, "--output=" + out2], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "bn254" in r.stderr
+
+
+def test_cpp_mirror_of_nim_interface(pkg, oracle):
+    import os
+    import subprocess
+    C, P = oracle
+    exe = os.path.join(os.path.dirname(pkg.LIB_PATH), "api_selftest")
+    r = subprocess.run([exe, "12"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().split("\n")
+    assert lines[-1] == "ALL OK"
+    vals = {l.split(" ")[0]: l.split(" ")[1] for l in lines if " 0x" in l}
+    for n in range(1, 13):
+        assert int(vals["root[%d]" % n], 16) == P.merkle_root([100 + i for i in range(n)])
+    cfg = dict(cellSize=64, blockSize=512, nCells=16, seed=12345)
+    mini, big = P.build_slot_tree_full(cfg, 2)
+    assert int(vals["slotRoot"], 16) == big[-1][0]
+    want = P.pad_merkle_proof(P.merge_merkle_proofs(P.merkle_proof(mini[1], 5), P.merkle_proof(big, 1)), 8)
+    assert int(vals["cellHash[13]"], 16) == want["leafValue"]
+    assert [int(vals["path[%d]" % i], 16) for i in range(8)] == want["merklePath"]
+    idx_line = [l for l in lines if l.startswith("cellIndices")][0]
+    assert [int(v) for v in idx_line.split()[1:]] == P.cell_indices(1234567, big[-1][0], 16, 6)
