@@ -1,0 +1,139 @@
+## codex_p2.nim -- Nim binding of libcodex_p2.so (include/codex_p2.h).
+##
+## Drop-in replacement of the nim-poseidon2 / constantine call sites used by
+## reference/nim/proof_input/src for --field=bn254 --hash=poseidon2 (SURVEY.md section 8b).
+## NOTE: written against the C ABI by hand; there is no Nim compiler in the build image, so this file has
+## never been compiled.  It is deliberately thin and mechanical: one `importc` per C entry point, plus the
+## handful of procs whose names the reference's modules import.
+##
+## Usage inside the reference tree: replace
+##   import poseidon2/types, poseidon2/io, poseidon2/sponge, poseidon2/compress, poseidon2/merkle
+## in src/types/bn254.nim, src/blocks/bn254.nim, src/merkle/bn254.nim, src/sample/bn254.nim,
+## src/json/bn254.nim by `import codex_p2`, and build with
+##   nim c -d:release --passL:"-L<repo>/codex-storage-proofs-circuits_amd -lcodex_p2" src/cli.nim
+
+const libName = "libcodex_p2.so"
+
+type
+  F* = array[32, byte]          ## canonical little-endian field element (NOT constantine's Montgomery limbs)
+  Cp2Ctx = distinct pointer
+  Cp2Dataset = distinct pointer
+  Cp2ProofInput = distinct pointer
+  Cp2Config* {.bycopy.} = object
+    maxDepth*, maxLog2NSlots*: int32
+    cellSize*, blockSize*, nSlots*, nCells*, nSamples*, seed*: uint64
+    fileBase*: cstring
+
+{.push cdecl, dynlib: libName.}
+proc cp2_init(device: cint, ctx: ptr Cp2Ctx): cint {.importc.}
+proc cp2_free(ctx: Cp2Ctx) {.importc.}
+proc cp2_strerror(status: cint): cstring {.importc.}
+proc cp2_last_error(ctx: Cp2Ctx): cstring {.importc.}
+proc cp2_permute_batch(ctx: Cp2Ctx, inp, outp: ptr byte, n: csize_t): cint {.importc.}
+proc cp2_compress_batch(ctx: Cp2Ctx, xy: ptr byte, key: uint32, outp: ptr byte, n: csize_t): cint {.importc.}
+proc cp2_sponge2_felts(ctx: Cp2Ctx, felts: ptr byte, n: csize_t, outp: ptr byte): cint {.importc.}
+proc cp2_felts_per_bytes(len: csize_t): csize_t {.importc.}
+proc cp2_bytes_to_felts(data: ptr byte, len: csize_t, outp: ptr byte): cint {.importc.}
+proc cp2_hash_cells(ctx: Cp2Ctx, cells: ptr byte, cellSize, nCells: csize_t, outp: ptr byte): cint {.importc.}
+proc cp2_merkle_total(n: csize_t): csize_t {.importc.}
+proc cp2_merkle_num_layers(n: csize_t): csize_t {.importc.}
+proc cp2_merkle_tree(ctx: Cp2Ctx, leaves: ptr byte, n: csize_t, layersOut: ptr byte,
+                     layerSizes: ptr csize_t, nLayers: ptr csize_t): cint {.importc.}
+proc cp2_merkle_root(ctx: Cp2Ctx, leaves: ptr byte, n: csize_t, outp: ptr byte): cint {.importc.}
+proc cp2_gen_fake_cells(ctx: Cp2Ctx, seed, first: uint64, n, cellSize: csize_t, outp: ptr byte): cint {.importc.}
+proc cp2_cell_indices(ctx: Cp2Ctx, entropy, slotRoot: ptr byte, nCells: uint64, nSamples: csize_t,
+                      outp: ptr uint64): cint {.importc.}
+proc cp2_dataset_build(ctx: Cp2Ctx, cfg: ptr Cp2Config, firstSlot, nLocal: uint64, ds: ptr Cp2Dataset): cint {.importc.}
+proc cp2_dataset_free(ds: Cp2Dataset) {.importc.}
+proc cp2_proof_input_generate(ds: Cp2Dataset, slotIdx: uint64, entropy: ptr byte, p: ptr Cp2ProofInput): cint {.importc.}
+proc cp2_proof_input_free(p: Cp2ProofInput) {.importc.}
+proc cp2_proof_input_write_json(p: Cp2ProofInput, path: cstring): cint {.importc.}
+proc cp2_write_circom_main(cfg: ptr Cp2Config, path: cstring): cint {.importc.}
+{.pop.}
+
+var gCtx: Cp2Ctx
+
+proc ctx(): Cp2Ctx =
+  ## one engine context per process (the reference is single threaded, cli.nim:208-237)
+  if pointer(gCtx) == nil:
+    let st = cp2_init(0, addr gCtx)
+    if st != 0: raiseAssert("cp2_init: " & $cp2_strerror(st))
+  gCtx
+
+proc check(st: cint, what: string) =
+  ## nothing aborts across the C ABI; keep the reference's behaviour (assert -> AssertionDefect) on this side
+  if st != 0: raiseAssert(what & ": " & $cp2_strerror(st) & " " & $cp2_last_error(ctx()))
+
+# ---- the nim-poseidon2 / constantine names the reference imports -------------------------------------
+const zero*: F = default(F)
+
+func toF*(x: int): F =
+  ## poseidon2/io toF (types/bn254.nim:27, sample/bn254.nim:22)
+  var v = uint64(x)
+  for i in 0 ..< 8: result[i] = byte((v shr (8 * i)) and 0xff)
+
+proc compress*(x, y: F, key: F = zero): F =
+  ## poseidon2/compress (merkle/bn254.nim:18,50,53); key is one of 0,1,2,3
+  var xy: array[64, byte]
+  for i in 0 ..< 32: (xy[i] = x[i]; xy[32 + i] = y[i])
+  check(cp2_compress_batch(ctx(), addr xy[0], uint32(key[0]), addr result[0], 1), "compress")
+
+type Sponge* = object
+type Merkle* = object
+
+proc digest*(_: type Sponge, input: openArray[F], rate: static int = 2): F =
+  ## Sponge.digest(seq[F], rate = 2)  (sample/bn254.nim:23)
+  static: doAssert rate == 2
+  check(cp2_sponge2_felts(ctx(), cast[ptr byte](unsafeAddr input[0]), csize_t(input.len), addr result[0]), "Sponge.digest")
+
+proc digest*(_: type Sponge, input: openArray[byte], rate: static int = 2): F =
+  ## Sponge.digest(bytes, rate = 2)  (blocks/bn254.nim:27): 10* byte padding, 31-byte chunks, rate-2 sponge
+  static: doAssert rate == 2
+  check(cp2_hash_cells(ctx(), unsafeAddr input[0], csize_t(input.len), 1, addr result[0]), "Sponge.digest(bytes)")
+
+proc digest*(_: type Merkle, xs: openArray[F]): F =
+  ## Merkle.digest (merkle/bn254.nim:20)
+  check(cp2_merkle_root(ctx(), cast[ptr byte](unsafeAddr xs[0]), csize_t(xs.len), addr result[0]), "Merkle.digest")
+
+iterator elements*(bytes: openArray[byte], _: type F): F =
+  ## poseidon2/io elements (json/bn254.nim:11,25)
+  let n = int(cp2_felts_per_bytes(csize_t(bytes.len)))
+  var buf = newSeq[F](n)
+  check(cp2_bytes_to_felts(unsafeAddr bytes[0], csize_t(bytes.len), cast[ptr byte](addr buf[0])), "elements")
+  for f in buf: yield f
+
+func toDecimal*(a: F): string =
+  ## constantine io_fields.toDecimal (types/bn254.nim:30): base-10 digits of the canonical integer
+  var w: array[8, uint32]
+  for i in 0 ..< 8:
+    w[i] = uint32(a[4*i]) or (uint32(a[4*i+1]) shl 8) or (uint32(a[4*i+2]) shl 16) or (uint32(a[4*i+3]) shl 24)
+  var digits: seq[char]
+  var nonzero = true
+  while nonzero:
+    var rem: uint64 = 0
+    nonzero = false
+    for i in countdown(7, 0):
+      let cur = (rem shl 32) or uint64(w[i])
+      w[i] = uint32(cur div 10)
+      rem = cur mod 10
+      if w[i] != 0: nonzero = true
+    digits.add(char(ord('0') + int(rem)))
+  for i in countdown(digits.high, 0): result.add(digits[i])
+
+func bit*(a: F, i: int): uint64 = uint64((a[i shr 3] shr (i and 7)) and 1)   ## constantine `bit` (types/bn254.nim:51)
+func toBig*(a: F): F = a                                                      ## already canonical
+
+# ---- the whole-path entry points (gen_input/bn254.nim:78, json/bn254.nim:77, cli.nim:186) -------------------
+proc generateAndExportProofInputBN254*(cfg: var Cp2Config, slotIdx: int, entropy: F, fname: string) =
+  ## generateProofInputBN254 + exportProofInputBN254 in one call: builds every slot tree once on the GPU
+  var ds: Cp2Dataset
+  check(cp2_dataset_build(ctx(), addr cfg, 0, cfg.nSlots, addr ds), "cp2_dataset_build")
+  defer: cp2_dataset_free(ds)
+  var p: Cp2ProofInput
+  var e = entropy
+  check(cp2_proof_input_generate(ds, uint64(slotIdx), addr e[0], addr p), "cp2_proof_input_generate")
+  defer: cp2_proof_input_free(p)
+  check(cp2_proof_input_write_json(p, cstring(fname)), "cp2_proof_input_write_json")
+
+proc writeCircomMainComponentP2*(cfg: var Cp2Config, fname: string) =
+  check(cp2_write_circom_main(addr cfg, cstring(fname)), "cp2_write_circom_main")
