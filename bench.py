@@ -153,6 +153,11 @@ def main():
             extra.update(slot_root_leg(torch, ctx, pkg, C, dev, stream))
         except Exception as e:   # never lose the headline line to an extra leg
             extra["slot_root_error"] = repr(e)
+        if world == 1:
+            try:
+                extra.update(witness_leg(torch, ctx, pkg))
+            except Exception as e:
+                extra["witness_error"] = repr(e)
         if world > 1:
             try:
                 extra.update(dataset_leg(torch, dist, ctx, pkg, C, dev, rank, world))
@@ -193,6 +198,42 @@ def slot_root_leg(torch, ctx, pkg, C, dev, stream):
                           "build_ms": round(build_ms, 2), "perms": perms, "perms_per_s": perms / (build_ms * 1e-3),
                           "algorithmic_GBps": round(alg_bytes / (build_ms * 1e-3) / 1e9, 2),
                           "fake_data_gen_ms": round(gen_ms, 2), "slot_root_hex": root.tobytes()[::-1].hex()}}
+
+
+def witness_leg(torch, ctx, pkg):
+    """Config 4 (the metric's second half): nSamples=100, maxDepth=32, 4096 slots batched on one GPU.
+    4096 x 8 GiB does not fit HBM, so nCells = 2^12 per slot (8 MiB), 32 GiB of fake data
+    generated and hashed on the device; one witness = one SlotProofInput serialised as input.json."""
+    n_slots, n_cells = 4096, 1 << 12
+    cfg = pkg.make_config(maxDepth=32, maxLog2NSlots=12, cellSize=2048, blockSize=65536, nSlots=n_slots, nCells=n_cells,
+                          nSamples=100, seed=12345)
+    ctx.reset_stream()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ds = ctx.dataset(cfg)                 # every slot tree, built once (sync on return)
+    ds.set_roots(None)                    # dataset tree over the 4096 slot roots
+    t1 = time.perf_counter()
+    pis = ds.proof_inputs(list(range(n_slots)), 1234567)
+    t2 = time.perf_counter()
+    threads = 16
+    try:
+        threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        pass
+    nbytes = pkg.write_json_batch(ctx, pis, None, threads=threads)
+    t3 = time.perf_counter()
+    perms = n_slots * (35 * n_cells - 1) + (n_slots - 1) + 200 * n_slots
+    root_hex = ds.root().tobytes()[::-1].hex()
+    for p in pis:
+        p.free()
+    ds.free()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    return {"witnesses": {"workload": "configs[3]: nSamples=100, maxDepth=32, 4096 slots x 2^12 cells (32 GiB fake data) batched, 1 GPU",
+                          "build_trees_s": round(t1 - t0, 3), "generate_4096_proof_inputs_s": round(t2 - t1, 3),
+                          "json_serialise_s": round(t3 - t2, 3), "json_threads": threads, "json_bytes": nbytes,
+                          "witnesses_per_s_without_json": n_slots / (t2 - t0), "witnesses_per_s_with_json": n_slots / (t3 - t0),
+                          "perms": perms, "perms_per_s_build": (perms - 200 * n_slots) / (t1 - t0),
+                          "dataset_root_hex": root_hex}}
 
 
 def dataset_leg(torch, dist, ctx, pkg, C, dev, rank, world):

@@ -110,6 +110,8 @@ def load_library():
         "cp2_dataset_set_roots": (i32, [vp, vp]),
         "cp2_dataset_root": (i32, [vp, vp]),
         "cp2_proof_input_generate": (i32, [vp, u64, vp, pvp]),
+        "cp2_proof_inputs_generate_batch": (i32, [vp, vp, sz, vp, pvp]),
+        "cp2_proof_inputs_write_json_batch": (i32, [pvp, sz, ctypes.POINTER(cp), i32, ctypes.POINTER(u64)]),
         "cp2_proof_input_free": (None, [vp]),
         "cp2_proof_input_roots": (i32, [vp, vp, vp, vp]),
         "cp2_proof_input_nsamples": (sz, [vp]),
@@ -416,6 +418,27 @@ class Dataset:
         h = ctypes.c_void_p()
         self.ctx._ck(self.ctx.L.cp2_proof_input_generate(self.h, slot_idx, _p(e), ctypes.byref(h)), "cp2_proof_input_generate")
         return ProofInput(self.ctx, h, self.cfg)
+
+
+    def proof_inputs(self, slot_indices, entropy):
+        """Batched generateProofInput for many slots of this dataset (one sampling / gather / fetch)."""
+        e = _u8(entropy if not isinstance(entropy, int) else felt_bytes(entropy))
+        idx = np.ascontiguousarray(np.asarray(slot_indices, dtype=np.uint64))
+        hs = (ctypes.c_void_p * idx.size)()
+        self.ctx._ck(self.ctx.L.cp2_proof_inputs_generate_batch(self.h, _p(idx), idx.size, _p(e), hs), "cp2_proof_inputs_generate_batch")
+        return [ProofInput(self.ctx, ctypes.c_void_p(h), self.cfg) for h in hs]
+
+
+def write_json_batch(ctx, proof_inputs, paths=None, threads=1):
+    """Serialise (and write, when paths are given) many proof inputs on host threads; returns total text bytes."""
+    n = len(proof_inputs)
+    hs = (ctypes.c_void_p * n)(*[p.h for p in proof_inputs])
+    ps = None
+    if paths is not None:
+        ps = (ctypes.c_char_p * n)(*[(q.encode() if q else None) for q in paths])
+    total = ctypes.c_uint64()
+    ctx._ck(ctx.L.cp2_proof_inputs_write_json_batch(hs, n, ps, threads, ctypes.byref(total)), "cp2_proof_inputs_write_json_batch")
+    return total.value
 
 
 class ProofInput:

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "internal.hpp"
@@ -327,34 +328,39 @@ extern "C" int cp2_slot_trees_paths(cp2_slot_trees* t, size_t slot, const uint64
   return CP2_OK;
 }
 
-// the bytes of n cells of one slot (slotLoadCellData, slot.nim:57-68)
-static int trees_cells(cp2_slot_trees* t, size_t slot, const uint64_t* cell_idx, size_t n, uint8_t* out) {
+// the bytes of n cells given by global index g = local_slot * n_cells + cell (slotLoadCellData, slot.nim:57-68)
+static int trees_cells_global(cp2_slot_trees* t, const uint64_t* g, size_t n, uint8_t* out) {
   cp2_ctx* ctx = t->ctx;
   const size_t cs = t->cell_size;
   if (n == 0) return CP2_OK;
   switch (t->src) {
     case CellSrc::Host:
-      for (size_t i = 0; i < n; ++i) std::memcpy(out + i * cs, t->h_cells + (slot * t->n_cells + cell_idx[i]) * cs, cs);
+      for (size_t i = 0; i < n; ++i) std::memcpy(out + i * cs, t->h_cells + g[i] * cs, cs);
       return CP2_OK;
     case CellSrc::File: {
-      std::string fname = t->file_base + std::to_string(t->first_slot + slot) + ".dat";
-      FILE* f = std::fopen(fname.c_str(), "rb");
-      if (!f) { ctx->err = "cannot open " + fname; return CP2_ERR_IO; }
+      FILE* f = nullptr;
+      size_t open_slot = ~(size_t)0;
       for (size_t i = 0; i < n; ++i) {
+        size_t slot = g[i] / t->n_cells, cell = g[i] % t->n_cells;
+        if (slot != open_slot) {
+          if (f) std::fclose(f);
+          std::string fname = t->file_base + std::to_string(t->first_slot + slot) + ".dat";
+          f = std::fopen(fname.c_str(), "rb");
+          if (!f) { ctx->err = "cannot open " + fname; return CP2_ERR_IO; }
+          open_slot = slot;
+        }
         std::memset(out + i * cs, 0, cs);
-        if (std::fseek(f, (long)(cell_idx[i] * cs), SEEK_SET) == 0) (void)!std::fread(out + i * cs, 1, cs, f);
+        if (std::fseek(f, (long)(cell * cs), SEEK_SET) == 0) (void)!std::fread(out + i * cs, 1, cs, f);
       }
-      std::fclose(f);
+      if (f) std::fclose(f);
       return CP2_OK;
     }
     case CellSrc::Fake:
     case CellSrc::Dev: {
-      std::vector<uint64_t> g(n);
-      for (size_t i = 0; i < n; ++i) g[i] = slot * t->n_cells + cell_idx[i];
       DevBuf d_g, d_out;
       CP2_TRY(d_g.alloc(ctx, n * 8));
       CP2_TRY(d_out.alloc(ctx, n * cs));
-      CP2_HIP(ctx, hipMemcpyAsync(d_g.p, g.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+      CP2_HIP(ctx, hipMemcpyAsync(d_g.p, g, n * 8, hipMemcpyHostToDevice, ctx->stream));
       if (t->src == CellSrc::Fake) {
         CP2_HIP(ctx, cp2k::launch_gen_fake_cells(cp2_slot_seed(t->dataset_seed, t->first_slot), t->n_cells, 0,
                                                  static_cast<const uint64_t*>(d_g.p), n, cs, d_out.p, ctx->stream));
@@ -461,45 +467,104 @@ struct cp2_proof_input {
   std::vector<uint8_t> cell_data, paths, slot_proof;
 };
 
-extern "C" int cp2_proof_input_generate(cp2_dataset* ds, uint64_t slot_idx, const uint8_t entropy[32], cp2_proof_input** out) {
-  if (!ds || !entropy || !out) return CP2_ERR_INVALID;
-  *out = nullptr;
+// slotProof = padMerkleProof(merkleProof(dsetTree, slotIdx), maxLog2NSlots), gen_input/bn254.nim:51,72
+static void fill_slot_proof(const cp2_dataset* ds, uint64_t slot_idx, std::vector<uint8_t>& out) {
+  out.assign((size_t)ds->cfg.max_log2_nslots * 32, 0);
+  size_t k = slot_idx, m = ds->cfg.n_slots, off = 0;
+  for (size_t i = 0; i + 1 < ds->dsizes.size(); ++i) {
+    size_t j = k ^ 1;
+    if (j < m) std::memcpy(&out[i * 32], &ds->dlayers[(off + j) * 32], 32);
+    off += ds->dsizes[i];
+    k >>= 1;
+    m = (m + 1) >> 1;
+  }
+}
+
+// generateProofInput (gen_input/bn254.nim:35-79) for `n` slots of the dataset at once: one sampling launch,
+// one path gather, one cell fetch for all of them.
+extern "C" int cp2_proof_inputs_generate_batch(cp2_dataset* ds, const uint64_t* slot_idx, size_t n, const uint8_t entropy[32],
+                                               cp2_proof_input** out) {
+  if (!ds || !entropy || (n && (!slot_idx || !out))) return CP2_ERR_INVALID;
+  for (size_t i = 0; i < n; ++i) out[i] = nullptr;
+  if (n == 0) return CP2_OK;
   const cp2_config& cfg = ds->cfg;
-  if (slot_idx < ds->first_slot || slot_idx >= ds->first_slot + ds->n_local) return CP2_ERR_INVALID;
+  cp2_ctx* ctx = ds->ctx;
+  cp2_slot_trees* t = ds->trees;
+  for (size_t i = 0; i < n; ++i)
+    if (slot_idx[i] < ds->first_slot || slot_idx[i] >= ds->first_slot + ds->n_local) return CP2_ERR_INVALID;
   if (!is_pow2(cfg.n_cells)) return CP2_ERR_INVALID;                    // sample/bn254.nim:19-20
   if (!ds->have_roots) CP2_TRY(cp2_dataset_set_roots(ds, nullptr));
   if (ds->dsizes.size() - 1 > (size_t)cfg.max_log2_nslots) return CP2_ERR_INVALID;   // padMerkleProof assert
-  cp2_proof_input* p = new (std::nothrow) cp2_proof_input();
-  if (!p) return CP2_ERR_ALLOC;
-  p->cfg = cfg;
-  p->slot_idx = slot_idx;
-  std::memcpy(p->entropy, entropy, 32);
-  std::memcpy(p->dataset_root, &ds->dlayers[ds->dlayers.size() - 32], 32);
-  std::memcpy(p->slot_root, &ds->dlayers[slot_idx * 32], 32);          // layer 0 of the dataset tree = slot roots
+  if (cp2_slot_trees_depth(t) > (size_t)cfg.max_depth) return CP2_ERR_INVALID;        // padMerkleProof assert
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t ns = cfg.n_samples, md = (size_t)cfg.max_depth, cs = cfg.cell_size, total = n * ns;
 
-  // slotProof = padMerkleProof(merkleProof(dsetTree, slotIdx), maxLog2NSlots), gen_input/bn254.nim:51,72
-  p->slot_proof.assign((size_t)cfg.max_log2_nslots * 32, 0);
-  {
-    size_t k = slot_idx, m = cfg.n_slots, off = 0;
-    for (size_t i = 0; i + 1 < ds->dsizes.size(); ++i) {
-      size_t j = k ^ 1;
-      if (j < m) std::memcpy(&p->slot_proof[i * 32], &ds->dlayers[(off + j) * 32], 32);
-      off += ds->dsizes[i];
-      k >>= 1;
-      m = (m + 1) >> 1;
+  // ---- sampling: cellIndices for every (slot, counter), sample/bn254.nim:16-27
+  std::vector<uint64_t> indices(total);
+  if (total) {
+    std::vector<uint8_t> felts(total * 96, 0), dig(total * 32);
+    for (size_t i = 0; i < n; ++i) {
+      const uint8_t* root = &ds->dlayers[slot_idx[i] * 32];
+      for (size_t c = 0; c < ns; ++c) {
+        uint8_t* f = &felts[(i * ns + c) * 96];
+        std::memcpy(f, entropy, 32);
+        std::memcpy(f + 32, root, 32);
+        uint64_t counter = c + 1;
+        std::memcpy(f + 64, &counter, 8);
+      }
+    }
+    CP2_TRY(cp2_sponge2_felts_batch(ctx, felts.data(), 3, total, dig.data()));
+    for (size_t k = 0; k < total; ++k) {
+      uint64_t lo;
+      std::memcpy(&lo, &dig[32 * k], 8);
+      indices[k] = lo & (cfg.n_cells - 1);
     }
   }
-  int st = CP2_OK;
-  const size_t ns = cfg.n_samples, local = slot_idx - ds->first_slot;
-  p->indices.resize(ns);
-  p->cell_data.resize(ns * cfg.cell_size);
-  p->paths.resize(ns * (size_t)cfg.max_depth * 32);
-  st = cp2_cell_indices(ds->ctx, p->entropy, p->slot_root, cfg.n_cells, ns, p->indices.data());   // :53
-  if (st == CP2_OK) st = cp2_slot_trees_paths(ds->trees, local, p->indices.data(), ns, (size_t)cfg.max_depth, p->paths.data(), nullptr);
-  if (st == CP2_OK) st = trees_cells(ds->trees, local, p->indices.data(), ns, p->cell_data.data());
-  if (st != CP2_OK) { delete p; return st; }
-  *out = p;
+  // ---- paths (one gather) and cells (one fetch)
+  std::vector<uint8_t> paths(total * md * 32), cells(total * cs);
+  if (total) {
+    std::vector<uint64_t> rows(total * md);
+    std::vector<uint64_t> gcell(total);
+    for (size_t i = 0; i < n; ++i) {
+      size_t local = slot_idx[i] - ds->first_slot;
+      for (size_t c = 0; c < ns; ++c) {
+        path_rows(t, local, indices[i * ns + c], md, &rows[(i * ns + c) * md]);
+        gcell[i * ns + c] = local * t->n_cells + indices[i * ns + c];
+      }
+    }
+    DevBuf d_rows, d_out;
+    CP2_TRY(d_rows.alloc(ctx, rows.size() * 8));
+    CP2_TRY(d_out.alloc(ctx, rows.size() * 32));
+    CP2_HIP(ctx, hipMemcpyAsync(d_rows.p, rows.data(), rows.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    CP2_HIP(ctx, cp2k::launch_gather_rows(t->nodes.p, static_cast<const uint64_t*>(d_rows.p), rows.size(), 32, d_out.p, ctx->stream));
+    CP2_HIP(ctx, hipMemcpyAsync(paths.data(), d_out.p, paths.size(), hipMemcpyDeviceToHost, ctx->stream));
+    CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CP2_TRY(trees_cells_global(t, gcell.data(), total, cells.data()));
+  }
+  // ---- split
+  for (size_t i = 0; i < n; ++i) {
+    cp2_proof_input* p = new (std::nothrow) cp2_proof_input();
+    if (!p) {
+      for (size_t j = 0; j < i; ++j) { delete out[j]; out[j] = nullptr; }
+      return CP2_ERR_ALLOC;
+    }
+    p->cfg = cfg;
+    p->slot_idx = slot_idx[i];
+    std::memcpy(p->entropy, entropy, 32);
+    std::memcpy(p->dataset_root, &ds->dlayers[ds->dlayers.size() - 32], 32);
+    std::memcpy(p->slot_root, &ds->dlayers[slot_idx[i] * 32], 32);      // layer 0 of the dataset tree = slot roots
+    fill_slot_proof(ds, slot_idx[i], p->slot_proof);
+    p->indices.assign(indices.begin() + i * ns, indices.begin() + (i + 1) * ns);
+    p->cell_data.assign(cells.begin() + i * ns * cs, cells.begin() + (i + 1) * ns * cs);
+    p->paths.assign(paths.begin() + i * ns * md * 32, paths.begin() + (i + 1) * ns * md * 32);
+    out[i] = p;
+  }
   return CP2_OK;
+}
+
+extern "C" int cp2_proof_input_generate(cp2_dataset* ds, uint64_t slot_idx, const uint8_t entropy[32], cp2_proof_input** out) {
+  if (!out) return CP2_ERR_INVALID;
+  return cp2_proof_inputs_generate_batch(ds, &slot_idx, 1, entropy, out);
 }
 
 extern "C" void cp2_proof_input_free(cp2_proof_input* p) { delete p; }
@@ -522,26 +587,28 @@ namespace {
 
 // canonical decimal of a 256-bit little-endian integer: no leading zeros, "0" for zero (toDecimalF)
 void append_quoted_decimal(std::string& s, const uint8_t* le32) {
-  uint32_t w[8];
+  uint64_t w[4];
   std::memcpy(w, le32, 32);
   char buf[80];
   int pos = 80;
-  bool nonzero = true;
+  const uint64_t CH = 10000000000000000000ULL;   // 10^19
+  bool nonzero = (w[0] | w[1] | w[2] | w[3]) != 0;
+  if (!nonzero) buf[--pos] = '0';
   while (nonzero) {
-    uint64_t rem = 0;
-    nonzero = false;
-    for (int i = 7; i >= 0; --i) {
-      uint64_t cur = (rem << 32) | w[i];
-      w[i] = (uint32_t)(cur / 1000000000u);
-      rem = cur % 1000000000u;
-      if (w[i]) nonzero = true;
+    unsigned __int128 rem = 0;
+    for (int i = 3; i >= 0; --i) {
+      unsigned __int128 cur = (rem << 64) | w[i];
+      w[i] = (uint64_t)(cur / CH);
+      rem = cur % CH;
     }
-    for (int d = 0; d < 9; ++d) {
-      buf[--pos] = (char)('0' + rem % 10);
-      rem /= 10;
+    nonzero = (w[0] | w[1] | w[2] | w[3]) != 0;
+    uint64_t r = (uint64_t)rem;
+    if (nonzero) {
+      for (int d = 0; d < 19; ++d) { buf[--pos] = (char)('0' + r % 10); r /= 10; }
+    } else {
+      while (r) { buf[--pos] = (char)('0' + r % 10); r /= 10; }
     }
   }
-  while (pos < 79 && buf[pos] == '0') ++pos;
   s.push_back('"');
   s.append(buf + pos, 80 - pos);
   s.push_back('"');
@@ -560,11 +627,10 @@ void write_felt_list(std::string& s, const std::string& prefix, const uint8_t* f
 
 }  // namespace
 
-extern "C" int cp2_proof_input_json(const cp2_proof_input* p, char** text, size_t* len) {
-  if (!p || !text) return CP2_ERR_INVALID;
+static void proof_input_text(const cp2_proof_input* p, std::string& s) {
   const cp2_config& cfg = p->cfg;
-  std::string s;
-  s.reserve(1 << 20);
+  s.clear();
+  s.reserve((p->indices.size() * (cp2_felts_per_bytes(cfg.cell_size) + (size_t)cfg.max_depth) + 64) * 90);
   s += "{\n";
   s += "  \"dataSetRoot\":      "; append_quoted_decimal(s, p->dataset_root); s += "\n";
   s += ", \"entropy\":          "; append_quoted_decimal(s, p->entropy); s += "\n";
@@ -591,6 +657,12 @@ extern "C" int cp2_proof_input_json(const cp2_proof_input* p, char** text, size_
     write_felt_list(s, (i == 0) ? outer + "[ " : outer_indent + ", ", &p->paths[i * (size_t)cfg.max_depth * 32], (size_t)cfg.max_depth);
   s += outer_indent + "]\n";
   s += "}\n";
+}
+
+extern "C" int cp2_proof_input_json(const cp2_proof_input* p, char** text, size_t* len) {
+  if (!p || !text) return CP2_ERR_INVALID;
+  std::string s;
+  proof_input_text(p, s);
   char* buf = (char*)std::malloc(s.size() + 1);
   if (!buf) return CP2_ERR_ALLOC;
   std::memcpy(buf, s.data(), s.size());
@@ -600,19 +672,56 @@ extern "C" int cp2_proof_input_json(const cp2_proof_input* p, char** text, size_
   return CP2_OK;
 }
 
+static int write_text_file(const std::string& s, const char* path) {
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return CP2_ERR_IO;
+  size_t w = std::fwrite(s.data(), 1, s.size(), f);
+  int rc = std::fclose(f);
+  return (w == s.size() && rc == 0) ? CP2_OK : CP2_ERR_IO;
+}
+
+// Serialise (and optionally write) many proof inputs on `threads` host threads.  paths == NULL or
+// paths[i] == NULL: serialise only.  total_bytes (may be NULL) receives the summed text length.
+extern "C" int cp2_proof_inputs_write_json_batch(const cp2_proof_input* const* ps, size_t n, const char* const* paths,
+                                                 int threads, uint64_t* total_bytes) {
+  if (n && !ps) return CP2_ERR_INVALID;
+  for (size_t i = 0; i < n; ++i)
+    if (!ps[i]) return CP2_ERR_INVALID;
+  if (threads < 1) threads = 1;
+  if ((size_t)threads > n) threads = n ? (int)n : 1;
+  std::vector<int> status(threads, CP2_OK);
+  std::vector<uint64_t> bytes(threads, 0);
+  auto work = [&](int t) {
+    std::string s;
+    for (size_t i = t; i < n; i += threads) {
+      proof_input_text(ps[i], s);
+      bytes[t] += s.size();
+      if (paths && paths[i]) {
+        int st = write_text_file(s, paths[i]);
+        if (st != CP2_OK) status[t] = st;
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+  work(0);
+  for (auto& th : pool) th.join();
+  uint64_t tot = 0;
+  for (int t = 0; t < threads; ++t) {
+    tot += bytes[t];
+    if (status[t] != CP2_OK) return status[t];
+  }
+  if (total_bytes) *total_bytes = tot;
+  return CP2_OK;
+}
+
 extern "C" void cp2_free_buffer(void* p) { std::free(p); }
 
 extern "C" int cp2_proof_input_write_json(const cp2_proof_input* p, const char* path) {
   if (!p || !path) return CP2_ERR_INVALID;
-  char* text = nullptr;
-  size_t len = 0;
-  CP2_TRY(cp2_proof_input_json(p, &text, &len));
-  FILE* f = std::fopen(path, "wb");
-  if (!f) { std::free(text); return CP2_ERR_IO; }
-  size_t w = std::fwrite(text, 1, len, f);
-  int rc = std::fclose(f);
-  std::free(text);
-  return (w == len && rc == 0) ? CP2_OK : CP2_ERR_IO;
+  std::string s;
+  proof_input_text(p, s);
+  return write_text_file(s, path);
 }
 
 extern "C" int cp2_write_circom_main(const cp2_config* cfg, const char* path) {

@@ -178,6 +178,10 @@ typedef struct cp2_proof_input cp2_proof_input;
 /* replaces `generateProofInputBN254`, reference/nim/proof_input/src/gen_input/bn254.nim:35-79, for a
  * slot that is local to `ds`. */
 int cp2_proof_input_generate(cp2_dataset* ds, uint64_t slot_idx, const uint8_t entropy[32], cp2_proof_input** out);
+/* The same for n slots of `ds` at once (config 4: thousands of slots sharing one dataset tree): one
+ * sampling launch, one path gather and one cell fetch for all of them.  out[0..n) receive the objects. */
+int cp2_proof_inputs_generate_batch(cp2_dataset* ds, const uint64_t* slot_idx, size_t n, const uint8_t entropy[32],
+                                    cp2_proof_input** out);
 void cp2_proof_input_free(cp2_proof_input* p);
 /* accessors (all field elements canonical 32-byte LE) */
 int cp2_proof_input_roots(const cp2_proof_input* p, uint8_t dataset_root[32], uint8_t slot_root[32], uint8_t entropy[32]);
@@ -191,6 +195,10 @@ int cp2_proof_input_write_json(const cp2_proof_input* p, const char* path);
 /* the same text into a malloc'ed buffer (caller frees with cp2_free_buffer) */
 int cp2_proof_input_json(const cp2_proof_input* p, char** text, size_t* len);
 void cp2_free_buffer(void* p);
+/* Serialise n proof inputs on `threads` host threads and write paths[i] (paths == NULL or paths[i] == NULL:
+ * serialise only).  total_bytes (may be NULL) receives the summed text length. */
+int cp2_proof_inputs_write_json_batch(const cp2_proof_input* const* ps, size_t n, const char* const* paths, int threads,
+                                      uint64_t* total_bytes);
 /* replaces `writeCircomMainComponent`, reference/nim/proof_input/src/cli.nim:186-204 */
 int cp2_write_circom_main(const cp2_config* cfg, const char* path);
 

@@ -418,3 +418,24 @@ def test_cpp_mirror_of_nim_interface(pkg, oracle):
     assert [int(vals["path[%d]" % i], 16) for i in range(8)] == want["merklePath"]
     idx_line = [l for l in lines if l.startswith("cellIndices")][0]
     assert [int(v) for v in idx_line.split()[1:]] == P.cell_indices(1234567, big[-1][0], 16, 6)
+
+
+def test_batched_proof_inputs_equal_single(pkg, ctx, golden, tmp_path):
+    """cp2_proof_inputs_generate_batch == n x cp2_proof_input_generate; threaded JSON writer == single writer."""
+    m = golden("proof_inputs.json")["inputs"]["testmain_small"]
+    cfg = pkg.make_config(**m["config"])
+    ds = ctx.dataset(cfg)
+    slots = [3, 0, 4, 3]
+    batch = ds.proof_inputs(slots, m["entropy"])
+    single = [ds.proof_input(s, m["entropy"]).json() for s in slots]
+    assert [p.json() for p in batch] == single
+    assert single[0] == golden("input_testmain_small.json")
+    paths = [str(tmp_path / ("w%d.json" % i)) for i in range(len(slots))]
+    total = pkg.write_json_batch(ctx, batch, paths, threads=3)
+    assert total == sum(len(s) for s in single)
+    assert [open(p).read() for p in paths] == single
+    assert pkg.write_json_batch(ctx, batch, None, threads=2) == total
+    assert ds.proof_inputs([], 1) == []
+    import pytest as _pt
+    with _pt.raises(Exception):
+        ds.proof_inputs([5], 1)
