@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 
 namespace fr {
 
@@ -79,62 +80,103 @@ __device__ __forceinline__ Fe norm_full(const Fe& a) {
   return r;
 }
 
+#include "fr_tie.inc"
+
+template <int A0, int M0, int... I>
+__device__ __forceinline__ void tie_cols(uint64_t& acc, uint32_t (&a)[NL], uint32_t (&m)[NL], std::integer_sequence<int, I...>,
+                                         std::integer_sequence<int>) {
+  tie(acc, a[A0 + I]...);
+}
+template <int A0, int M0, int... I, int J0, int... J>
+__device__ __forceinline__ void tie_cols(uint64_t& acc, uint32_t (&a)[NL], uint32_t (&m)[NL], std::integer_sequence<int, I...>,
+                                         std::integer_sequence<int, J0, J...>) {
+  tie(acc, a[A0 + I]..., m[M0 + J0], m[M0 + J]...);
+}
+
 // Montgomery product a*b/R (finely integrated product scanning, 17 columns).
-__device__ __forceinline__ Fe mont_mul(const Fe& a, const Fe& b) {
+__device__ __forceinline__ Fe mont_mul(const Fe& a_in, const Fe& b) {
   Fe r;
-  uint32_t m[NL];
+  uint32_t a[NL], m[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) a[i] = a_in.l[i];
   uint64_t acc = 0;
+  auto lo_col = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (k > 0) tie_cols<0, 0>(acc, a, m, std::make_integer_sequence<int, k + 1>{}, std::make_integer_sequence<int, k>{});
 #pragma unroll
-  for (int k = 0; k < NL; ++k) {
-#pragma unroll
-    for (int i = 0; i <= k; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+    for (int i = 0; i <= k; ++i) acc += (uint64_t)a[i] * b.l[k - i];
 #pragma unroll
     for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * FR_N[k - i];
     m[k] = ((uint32_t)acc * FR_NPRIME) & MASK;
     acc += (uint64_t)m[k] * FR_N[0];
     acc >>= 29;
-  }
+  };
+  auto hi_col = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    constexpr int lo = k - NL + 1, cnt = NL - lo;
+    tie_cols<lo, lo>(acc, a, m, std::make_integer_sequence<int, cnt>{}, std::make_integer_sequence<int, cnt>{});
 #pragma unroll
-  for (int k = NL; k < 2 * NL - 1; ++k) {
+    for (int i = lo; i < NL; ++i) acc += (uint64_t)a[i] * b.l[k - i];
 #pragma unroll
-    for (int i = k - NL + 1; i < NL; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
-#pragma unroll
-    for (int i = k - NL + 1; i < NL; ++i) acc += (uint64_t)m[i] * FR_N[k - i];
+    for (int i = lo; i < NL; ++i) acc += (uint64_t)m[i] * FR_N[k - i];
     r.l[k - NL] = (uint32_t)acc & MASK;
     acc >>= 29;
-  }
+  };
+  lo_col(std::integral_constant<int, 0>{}); lo_col(std::integral_constant<int, 1>{}); lo_col(std::integral_constant<int, 2>{});
+  lo_col(std::integral_constant<int, 3>{}); lo_col(std::integral_constant<int, 4>{}); lo_col(std::integral_constant<int, 5>{});
+  lo_col(std::integral_constant<int, 6>{}); lo_col(std::integral_constant<int, 7>{}); lo_col(std::integral_constant<int, 8>{});
+  hi_col(std::integral_constant<int, 9>{}); hi_col(std::integral_constant<int, 10>{}); hi_col(std::integral_constant<int, 11>{});
+  hi_col(std::integral_constant<int, 12>{}); hi_col(std::integral_constant<int, 13>{}); hi_col(std::integral_constant<int, 14>{});
+  hi_col(std::integral_constant<int, 15>{}); hi_col(std::integral_constant<int, 16>{});
   r.l[NL - 1] = (uint32_t)acc;
   return r;
 }
 
+template <int LO, int... I, int... J>
+__device__ __forceinline__ void tie_sq(uint64_t& acc, uint32_t (&a)[NL], uint32_t (&d)[NL], uint32_t (&m)[NL],
+                                       std::integer_sequence<int, I...>, std::integer_sequence<int, J...>) {
+  tie(acc, a[LO + I]..., d[LO + I]..., m[LO + J]...);
+}
+
 // Montgomery square a*a/R: 45 products instead of 81 (cross terms against the doubled operand).
-__device__ __forceinline__ Fe mont_sqr(const Fe& a) {
+__device__ __forceinline__ Fe mont_sqr(const Fe& a_in) {
   Fe r;
-  uint32_t m[NL], d[NL];
+  uint32_t a[NL], m[NL], d[NL];
 #pragma unroll
-  for (int i = 0; i < NL; ++i) d[i] = a.l[i] << 1;   // limbs < 2.47 U  =>  doubled < 2^32
+  for (int i = 0; i < NL; ++i) a[i] = a_in.l[i];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) d[i] = a[i] << 1;   // limbs < 2.47 U  =>  doubled < 2^32
   uint64_t acc = 0;
+  auto lo_col = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (k > 0) tie_sq<0>(acc, a, d, m, std::make_integer_sequence<int, k + 1>{}, std::make_integer_sequence<int, k>{});
 #pragma unroll
-  for (int k = 0; k < NL; ++k) {
-#pragma unroll
-    for (int i = 0; 2 * i < k; ++i) acc += (uint64_t)a.l[i] * d[k - i];
-    if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+    for (int i = 0; 2 * i < k; ++i) acc += (uint64_t)a[i] * d[k - i];
+    if constexpr ((k & 1) == 0) acc += (uint64_t)a[k / 2] * a[k / 2];
 #pragma unroll
     for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * FR_N[k - i];
     m[k] = ((uint32_t)acc * FR_NPRIME) & MASK;
     acc += (uint64_t)m[k] * FR_N[0];
     acc >>= 29;
-  }
+  };
+  auto hi_col = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    constexpr int lo = k - NL + 1, cnt = NL - lo;
+    tie_sq<lo>(acc, a, d, m, std::make_integer_sequence<int, cnt>{}, std::make_integer_sequence<int, cnt>{});
 #pragma unroll
-  for (int k = NL; k < 2 * NL - 1; ++k) {
+    for (int i = lo; 2 * i < k; ++i) acc += (uint64_t)a[i] * d[k - i];
+    if constexpr ((k & 1) == 0) acc += (uint64_t)a[k / 2] * a[k / 2];
 #pragma unroll
-    for (int i = k - NL + 1; 2 * i < k; ++i) acc += (uint64_t)a.l[i] * d[k - i];
-    if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
-#pragma unroll
-    for (int i = k - NL + 1; i < NL; ++i) acc += (uint64_t)m[i] * FR_N[k - i];
+    for (int i = lo; i < NL; ++i) acc += (uint64_t)m[i] * FR_N[k - i];
     r.l[k - NL] = (uint32_t)acc & MASK;
     acc >>= 29;
-  }
+  };
+  lo_col(std::integral_constant<int, 0>{}); lo_col(std::integral_constant<int, 1>{}); lo_col(std::integral_constant<int, 2>{});
+  lo_col(std::integral_constant<int, 3>{}); lo_col(std::integral_constant<int, 4>{}); lo_col(std::integral_constant<int, 5>{});
+  lo_col(std::integral_constant<int, 6>{}); lo_col(std::integral_constant<int, 7>{}); lo_col(std::integral_constant<int, 8>{});
+  hi_col(std::integral_constant<int, 9>{}); hi_col(std::integral_constant<int, 10>{}); hi_col(std::integral_constant<int, 11>{});
+  hi_col(std::integral_constant<int, 12>{}); hi_col(std::integral_constant<int, 13>{}); hi_col(std::integral_constant<int, 14>{});
+  hi_col(std::integral_constant<int, 15>{}); hi_col(std::integral_constant<int, 16>{});
   r.l[NL - 1] = (uint32_t)acc;
   return r;
 }
