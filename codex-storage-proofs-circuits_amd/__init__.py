@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcodex_p2.so")
+LIB_PATH = os.environ.get("CODEX_P2_LIB") or os.path.join(_HERE, "libcodex_p2.so")   # env override: kernel-variant A/B runs
 CLI_PATH = os.path.join(_HERE, "cli")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "codex_p2.h")
 

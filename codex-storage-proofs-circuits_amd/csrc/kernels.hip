@@ -16,6 +16,13 @@ using fr::Fe;
 using p2::State;
 
 constexpr int TPB = 256;
+// minimum waves per SIMD the register allocator must leave room for (tuning knobs)
+#ifndef CP2_PERM_WAVES
+#define CP2_PERM_WAVES 1
+#endif
+#ifndef CP2_HASH_WAVES
+#define CP2_HASH_WAVES 4
+#endif
 
 __device__ __forceinline__ Fe load_fe_canonical(const uint4* p) {
   uint4 a = p[0], b = p[1];
@@ -44,7 +51,7 @@ __device__ __forceinline__ Fe key_fe(uint32_t key) {   // nodeKey, Merkle.hs:162
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(TPB) k_permute_batch(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n) {
+__global__ void __launch_bounds__(TPB, CP2_PERM_WAVES) k_permute_batch(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n) {
   __shared__ uint32_t qtab[fr::QTAB_WORDS];
   fr::qtab_fill(qtab, threadIdx.x, TPB);
   __syncthreads();
@@ -137,7 +144,7 @@ __device__ __forceinline__ Fe chunk_limbs(const uint32_t* row, int j) {
   return r;
 }
 
-__global__ void __launch_bounds__(TPB) k_hash_cells(const uint8_t* __restrict__ cells, size_t cell_size,
+__global__ void __launch_bounds__(TPB, CP2_HASH_WAVES) k_hash_cells(const uint8_t* __restrict__ cells, size_t cell_size,
                                                       size_t n_cells, uint4* __restrict__ out) {
   __shared__ uint32_t qtab[fr::QTAB_WORDS];
   __shared__ uint32_t stage[TPB / 64][64 * TILE_WORDS];

@@ -40,6 +40,18 @@ KERNEL32(k_sub_u32,        "v_sub_u32 %0, %1, %0")
 KERNEL32(k_xor,            "v_xor_b32 %0, %1, %0")
 KERNEL32(k_lshlrev,        "v_lshlrev_b32 %0, 3, %0")
 KERNEL32(k_cndmask,        "v_cndmask_b32 %0, %1, %0, vcc")
+KERNEL32(k_and_b32,        "v_and_b32 %0, %1, %0")
+KERNEL32(k_and_lit,        "v_and_b32 %0, 0x1fffffff, %0")
+KERNEL32(k_or_b32,         "v_or_b32 %0, %1, %0")
+KERNEL32(k_mov_b32,        "v_mov_b32 %0, %1")
+KERNEL32(k_lshrrev_reg,    "v_lshrrev_b32 %0, %1, %0")
+KERNEL32(k_lshrrev_imm,    "v_lshrrev_b32 %0, 29, %0")
+KERNEL32(k_min_u32,        "v_min_u32 %0, %1, %0")
+KERNEL32(k_bfe_u32,        "v_bfe_u32 %0, %0, 3, 20")
+KERNEL32(k_lshl_add_u32,   "v_lshl_add_u32 %0, %1, 3, %0")
+KERNEL32(k_add_f32,        "v_add_f32 %0, %1, %0")
+KERNEL32(k_mul_f32,        "v_mul_f32 %0, %1, %0")
+KERNEL32(k_subrev,         "v_subrev_u32 %0, %1, %0")
 KERNEL32(k_add3_u32,       "v_add3_u32 %0, %1, %2, %0")
 KERNEL32(k_add_co,         "v_add_co_u32 %0, vcc, %1, %0")
 KERNEL32(k_addc_co,        "v_addc_co_u32 %0, vcc, %1, %0, vcc")
@@ -92,7 +104,7 @@ int main(int argc, char** argv) {
   printf("device %s CUs=%d clock=%d kHz\n", prop.name, prop.multiProcessorCount, prop.clockRate);
   const int cus = prop.multiProcessorCount;
   std::vector<Entry> es = {
-    {"v_fma_f32", k_fma_f32, 1}, {"v_add_u32", k_add_u32, 1}, {"v_fma_f32 2op", k_fma_f32_2op, 1}, {"v_fmac_f32", k_fmac_f32, 1}, {"v_mul_lo_u32 self", k_mul_lo_self, 1}, {"v_sub_u32", k_sub_u32, 1}, {"v_xor_b32", k_xor, 1}, {"v_lshlrev_b32", k_lshlrev, 1}, {"v_cndmask_b32", k_cndmask, 1}, {"v_add3_u32", k_add3_u32, 1},
+    {"v_fma_f32", k_fma_f32, 1}, {"v_add_u32", k_add_u32, 1}, {"v_fma_f32 2op", k_fma_f32_2op, 1}, {"v_fmac_f32", k_fmac_f32, 1}, {"v_mul_lo_u32 self", k_mul_lo_self, 1}, {"v_sub_u32", k_sub_u32, 1}, {"v_xor_b32", k_xor, 1}, {"v_lshlrev_b32", k_lshlrev, 1}, {"v_cndmask_b32", k_cndmask, 1}, {"v_and_b32", k_and_b32, 1}, {"v_and_b32 literal", k_and_lit, 1}, {"v_or_b32", k_or_b32, 1}, {"v_mov_b32", k_mov_b32, 1}, {"v_lshrrev_b32 reg", k_lshrrev_reg, 1}, {"v_lshrrev_b32 imm", k_lshrrev_imm, 1}, {"v_min_u32", k_min_u32, 1}, {"v_bfe_u32", k_bfe_u32, 1}, {"v_lshl_add_u32", k_lshl_add_u32, 1}, {"v_add_f32", k_add_f32, 1}, {"v_mul_f32", k_mul_f32, 1}, {"v_subrev_u32", k_subrev, 1}, {"v_add3_u32", k_add3_u32, 1},
     {"v_add_co_u32", k_add_co, 1}, {"v_addc_co_u32", k_addc_co, 1},
     {"v_mul_lo_u32", k_mul_lo_u32, 1}, {"v_mul_hi_u32", k_mul_hi_u32, 1},
     {"v_mul_u32_u24", k_mul_u32_u24, 1}, {"v_mul_hi_u32_u24", k_mul_hi_u32_u24, 1},
@@ -113,7 +125,7 @@ int main(int argc, char** argv) {
   for (int i = 0; i < 400; ++i) k_fma_f32<<<cus * 8, 256>>>(out, cyc, 1, 2);
   CK(hipDeviceSynchronize());
   int occs[] = {1, 2, 4, 8};
-  printf("cycles per wave-instruction per SIMD (in-kernel s_memtime; wall-derived clock in GHz)\n");
+  printf("cycles per wave-instruction per SIMD: in-kernel s_memtime / wall-derived at 2.4 GHz (cycle-count over wall, GHz)\n");
   printf("%-20s", "instr");
   for (int o : occs) printf("   w/SIMD=%d  (GHz)", o);
   printf("\n");
@@ -133,7 +145,7 @@ int main(int argc, char** argv) {
       double avg = sum / (grid * 4);                       // cycles per wave for ITER*8 instrs
       double per_simd = avg / ((double)ITER * 8) / o;      // o waves share a SIMD
       double ghz = avg / (ms * 1e-3) * 1e-9;               // approx: kernel wall ~ wave lifetime
-      printf("   %8.2f (%4.2f)", per_simd, ghz);
+      double wall_cyc = ms * 1e-3 * 2.4e9 / ((double)ITER * 8 * o); printf("   %5.2f/%5.2f(%4.2f)", per_simd, wall_cyc, ghz);
     }
     printf("\n");
     fflush(stdout);
