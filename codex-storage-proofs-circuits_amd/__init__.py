@@ -9,6 +9,7 @@ The directory name contains '-', so import it through `__graft_entry__.load_pack
 import ctypes
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -99,6 +100,10 @@ def load_library():
         "cp2_slot_trees_build_dev": (i32, [vp, vp, sz, sz, sz, sz, pvp]),
         "cp2_slot_trees_build_host": (i32, [vp, vp, sz, sz, sz, sz, pvp]),
         "cp2_slot_trees_free": (None, [vp]),
+        "cp2_slot_trees_save": (i32, [vp, cp]),
+        "cp2_slot_trees_load": (i32, [vp, cp, pvp]),
+        "cp2_slot_trees_attach_cells": (i32, [vp, vp, vp]),
+        "cp2_dataset_build_cached": (i32, [vp, ctypes.POINTER(Config), u64, u64, cp, pvp]),
         "cp2_slot_trees_count": (sz, [vp]),
         "cp2_slot_trees_depth": (sz, [vp]),
         "cp2_slot_trees_roots": (i32, [vp, vp]),
@@ -181,6 +186,9 @@ class Context:
             self.h = None
 
     def __del__(self):
+        # at interpreter shutdown the HIP runtime may already be gone: leak rather than call into it
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -321,9 +329,14 @@ class Context:
         t._keep = c   # the library keeps the host pointer for sampled-cell retrieval
         return t
 
+    def slot_trees_load(self, path):
+        h = ctypes.c_void_p()
+        self._ck(self.L.cp2_slot_trees_load(self.h, path.encode(), ctypes.byref(h)), "cp2_slot_trees_load")
+        return SlotTrees(self, h)
+
     # -- dataset / proof input
-    def dataset(self, cfg, first_slot=0, n_local=None):
-        return Dataset(self, cfg, first_slot, cfg.n_slots if n_local is None else n_local)
+    def dataset(self, cfg, first_slot=0, n_local=None, cache=None):
+        return Dataset(self, cfg, first_slot, cfg.n_slots if n_local is None else n_local, cache)
 
 
 def make_config(maxDepth=32, maxLog2NSlots=8, cellSize=2048, blockSize=65536, nSlots=11, nCells=256, nSamples=5,
@@ -347,6 +360,8 @@ class SlotTrees:
             self.h = None
 
     def __del__(self):
+        if sys.is_finalizing():
+            return
         try:
             self.free()
         except Exception:
@@ -359,6 +374,9 @@ class SlotTrees:
     @property
     def depth(self):
         return self.ctx.L.cp2_slot_trees_depth(self.h)
+
+    def save(self, path):
+        self.ctx._ck(self.ctx.L.cp2_slot_trees_save(self.h, path.encode()), "cp2_slot_trees_save")
 
     def roots(self):
         out = np.empty((self.count, 32), dtype=np.uint8)
@@ -378,10 +396,14 @@ class SlotTrees:
 
 
 class Dataset:
-    def __init__(self, ctx, cfg, first_slot, n_local):
+    def __init__(self, ctx, cfg, first_slot, n_local, cache=None):
         self.ctx, self.cfg = ctx, cfg
         h = ctypes.c_void_p()
-        ctx._ck(ctx.L.cp2_dataset_build(ctx.h, ctypes.byref(cfg), first_slot, n_local, ctypes.byref(h)), "cp2_dataset_build")
+        if cache:
+            ctx._ck(ctx.L.cp2_dataset_build_cached(ctx.h, ctypes.byref(cfg), first_slot, n_local, cache.encode(), ctypes.byref(h)),
+                    "cp2_dataset_build_cached")
+        else:
+            ctx._ck(ctx.L.cp2_dataset_build(ctx.h, ctypes.byref(cfg), first_slot, n_local, ctypes.byref(h)), "cp2_dataset_build")
         self.h, self.first_slot, self.n_local = h, first_slot, n_local
 
     def free(self):
@@ -390,6 +412,8 @@ class Dataset:
             self.h = None
 
     def __del__(self):
+        if sys.is_finalizing():
+            return
         try:
             self.free()
         except Exception:
@@ -451,6 +475,8 @@ class ProofInput:
             self.h = None
 
     def __del__(self):
+        if sys.is_finalizing():
+            return
         try:
             self.free()
         except Exception:

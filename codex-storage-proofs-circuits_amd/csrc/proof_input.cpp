@@ -253,6 +253,90 @@ static int trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t fir
   return CP2_OK;
 }
 
+// ---- persisted slot trees ---------------------------------------------------
+// File = header + every node of the layer-major buffer (canonical 32-byte elements).  A later run with new
+// entropy then needs only 2 permutations per sample plus gathers instead of re-hashing every slot
+// (the reference re-hashes all slots per run AND the proving slot once per sample, gen_input/bn254.nim:42,57).
+namespace {
+struct TreeFileHeader {
+  char magic[8];            // "CP2TREE1"
+  uint64_t n_slots, cell_size, block_size, n_cells;
+  uint64_t src;             // CellSrc
+  uint64_t dataset_seed, first_slot;
+  uint64_t file_base_len;   // bytes following the header
+  uint64_t n_nodes;
+};
+}  // namespace
+
+extern "C" int cp2_slot_trees_save(cp2_slot_trees* t, const char* path) {
+  if (!t || !path) return CP2_ERR_INVALID;
+  cp2_ctx* ctx = t->ctx;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  TreeFileHeader h{};
+  std::memcpy(h.magic, "CP2TREE1", 8);
+  h.n_slots = t->n_slots; h.cell_size = t->cell_size; h.block_size = t->block_size; h.n_cells = t->n_cells;
+  h.src = (uint64_t)t->src; h.dataset_seed = t->dataset_seed; h.first_slot = t->first_slot;
+  h.file_base_len = t->file_base.size();
+  h.n_nodes = t->nodes.bytes / 32;
+  std::vector<uint8_t> host(t->nodes.bytes);
+  CP2_HIP(ctx, hipMemcpyAsync(host.data(), t->nodes.p, host.size(), hipMemcpyDeviceToHost, ctx->stream));
+  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return CP2_ERR_IO;
+  bool ok = std::fwrite(&h, sizeof h, 1, f) == 1 &&
+            (h.file_base_len == 0 || std::fwrite(t->file_base.data(), 1, h.file_base_len, f) == h.file_base_len) &&
+            std::fwrite(host.data(), 1, host.size(), f) == host.size();
+  ok = (std::fclose(f) == 0) && ok;
+  return ok ? CP2_OK : CP2_ERR_IO;
+}
+
+extern "C" int cp2_slot_trees_load(cp2_ctx* ctx, const char* path, cp2_slot_trees** out) {
+  if (!ctx || !path || !out) return CP2_ERR_INVALID;
+  *out = nullptr;
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return CP2_ERR_IO;
+  TreeFileHeader h{};
+  if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, "CP2TREE1", 8) != 0 || h.file_base_len > 4096 ||
+      trees_check_geometry(h.cell_size, h.block_size, h.n_cells, h.n_slots) != CP2_OK || h.src > (uint64_t)CellSrc::File) {
+    std::fclose(f);
+    return CP2_ERR_IO;
+  }
+  std::string base(h.file_base_len, '\0');
+  if (h.file_base_len && std::fread(&base[0], 1, h.file_base_len, f) != h.file_base_len) { std::fclose(f); return CP2_ERR_IO; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { std::fclose(f); return CP2_ERR_HIP; }
+  cp2_slot_trees* t = trees_new(ctx, h.n_slots, h.cell_size, h.block_size, h.n_cells);
+  if (!t) { std::fclose(f); return CP2_ERR_ALLOC; }
+  t->src = (CellSrc)h.src;
+  t->dataset_seed = h.dataset_seed;
+  t->first_slot = h.first_slot;
+  t->file_base = base;
+  int st = trees_layout(t);
+  if (st == CP2_OK && t->nodes.bytes / 32 != h.n_nodes) st = CP2_ERR_IO;
+  std::vector<uint8_t> host;
+  if (st == CP2_OK) {
+    host.resize(t->nodes.bytes);
+    if (std::fread(host.data(), 1, host.size(), f) != host.size()) st = CP2_ERR_IO;
+  }
+  std::fclose(f);
+  if (st == CP2_OK) {
+    hipError_t e = hipMemcpyAsync(t->nodes.p, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ctx->err = hipGetErrorString(e); st = CP2_ERR_HIP; }
+  }
+  if (st != CP2_OK) { delete t; return st; }
+  *out = t;
+  return CP2_OK;
+}
+
+// trees loaded from a cache that were built from caller memory have no cell source until one is attached
+extern "C" int cp2_slot_trees_attach_cells(cp2_slot_trees* t, const uint8_t* host_cells, const void* dev_cells) {
+  if (!t || (host_cells && dev_cells)) return CP2_ERR_INVALID;
+  if (host_cells) { t->src = CellSrc::Host; t->h_cells = host_cells; t->d_cells = nullptr; }
+  else if (dev_cells) { t->src = CellSrc::Dev; t->d_cells = static_cast<const uint8_t*>(dev_cells); t->h_cells = nullptr; }
+  else return CP2_ERR_INVALID;
+  return CP2_OK;
+}
+
 extern "C" void cp2_slot_trees_free(cp2_slot_trees* t) {
   if (!t) return;
   (void)hipSetDevice(t->ctx->device);
@@ -335,6 +419,7 @@ static int trees_cells_global(cp2_slot_trees* t, const uint64_t* g, size_t n, ui
   if (n == 0) return CP2_OK;
   switch (t->src) {
     case CellSrc::Host:
+      if (!t->h_cells) return CP2_ERR_INVALID;   // loaded from a cache: attach the cells first
       for (size_t i = 0; i < n; ++i) std::memcpy(out + i * cs, t->h_cells + g[i] * cs, cs);
       return CP2_OK;
     case CellSrc::File: {
@@ -361,6 +446,7 @@ static int trees_cells_global(cp2_slot_trees* t, const uint64_t* g, size_t n, ui
       CP2_TRY(d_g.alloc(ctx, n * 8));
       CP2_TRY(d_out.alloc(ctx, n * cs));
       CP2_HIP(ctx, hipMemcpyAsync(d_g.p, g, n * 8, hipMemcpyHostToDevice, ctx->stream));
+      if (t->src == CellSrc::Dev && !t->d_cells) return CP2_ERR_INVALID;   // loaded from a cache: attach the cells first
       if (t->src == CellSrc::Fake) {
         CP2_HIP(ctx, cp2k::launch_gen_fake_cells(cp2_slot_seed(t->dataset_seed, t->first_slot), t->n_cells, 0,
                                                  static_cast<const uint64_t*>(d_g.p), n, cs, d_out.p, ctx->stream));
@@ -416,6 +502,42 @@ extern "C" int cp2_dataset_build(cp2_ctx* ctx, const cp2_config* cfg, uint64_t f
   if (st != CP2_OK) { delete ds; return st; }
   *out = ds;
   return CP2_OK;
+}
+
+// Same as cp2_dataset_build, but the slot trees are read from `cache_path` when that file exists and matches
+// the configuration, and written there after a build otherwise.
+extern "C" int cp2_dataset_build_cached(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local,
+                                        const char* cache_path, cp2_dataset** out) {
+  if (!ctx || !cfg || !out || !cache_path) return CP2_ERR_INVALID;
+  *out = nullptr;
+  if (n_local == 0 || first_slot + n_local > cfg->n_slots) return CP2_ERR_INVALID;
+  cp2_slot_trees* t = nullptr;
+  if (cp2_slot_trees_load(ctx, cache_path, &t) == CP2_OK) {
+    const bool from_file = cfg->file_base != nullptr;
+    bool match = t->n_slots == n_local && t->cell_size == cfg->cell_size && t->block_size == cfg->block_size &&
+                 t->n_cells == cfg->n_cells && t->first_slot == first_slot &&
+                 (from_file ? (t->src == CellSrc::File && t->file_base == cfg->file_base)
+                            : (t->src == CellSrc::Fake && t->dataset_seed == cfg->seed));
+    if (match) {
+      cp2_dataset* ds = new (std::nothrow) cp2_dataset();
+      if (!ds) { cp2_slot_trees_free(t); return CP2_ERR_ALLOC; }
+      ds->ctx = ctx;
+      ds->cfg = *cfg;
+      ds->from_file = from_file;
+      if (from_file) ds->file_base = cfg->file_base;
+      ds->cfg.file_base = nullptr;
+      ds->first_slot = first_slot;
+      ds->n_local = n_local;
+      ds->trees = t;
+      *out = ds;
+      return CP2_OK;
+    }
+    cp2_slot_trees_free(t);
+  }
+  CP2_TRY(cp2_dataset_build(ctx, cfg, first_slot, n_local, out));
+  int st = cp2_slot_trees_save((*out)->trees, cache_path);
+  if (st != CP2_OK) { cp2_dataset_free(*out); *out = nullptr; }
+  return st;
 }
 
 extern "C" void cp2_dataset_free(cp2_dataset* ds) {

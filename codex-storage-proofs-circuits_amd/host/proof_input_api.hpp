@@ -7,6 +7,7 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -291,7 +292,10 @@ inline SlotProofInput generateProofInputBN254(Engine& e, const HashConfig& hashC
   doAssert(slotIdx >= 0 && slotIdx < dsetCfg.nSlots, "slot index out of range");
   cp2_config cfg = toEngineConfig(globCfg, dsetCfg);
   cp2_dataset* ds = nullptr;
-  e.check(cp2_dataset_build(e.ctx(), &cfg, 0, cfg.n_slots, &ds), "buildSlotTree (all slots)");
+  // optional tree cache (not in the reference, which recomputes every tree on every run): CODEX_P2_CACHE=<file>
+  const char* cache = std::getenv("CODEX_P2_CACHE");
+  if (cache && *cache) e.check(cp2_dataset_build_cached(e.ctx(), &cfg, 0, cfg.n_slots, cache, &ds), "buildSlotTree (cached)");
+  else e.check(cp2_dataset_build(e.ctx(), &cfg, 0, cfg.n_slots, &ds), "buildSlotTree (all slots)");
   std::shared_ptr<cp2_dataset> ds_guard(ds, cp2_dataset_free);
   cp2_proof_input* pi = nullptr;
   e.check(cp2_proof_input_generate(ds, (uint64_t)slotIdx, entropy.data(), &pi), "generateProofInput");

@@ -134,6 +134,13 @@ int cp2_slot_trees_build_dev(cp2_ctx* ctx, const void* d_cells, size_t n_slots, 
 int cp2_slot_trees_build_host(cp2_ctx* ctx, const uint8_t* cells, size_t n_slots, size_t cell_size,
                               size_t block_size, size_t n_cells, cp2_slot_trees** out);
 void cp2_slot_trees_free(cp2_slot_trees* t);
+/* Persisted trees (the reference recomputes every tree on every run and once more per
+ * sample, gen_input/bn254.nim:42,57).  The file holds the geometry, the data-source description and every
+ * node; loading it skips all cell hashing.  Trees built from caller memory (build_dev / build_host) load
+ * without a cell source: paths work, sampled-cell retrieval needs cp2_slot_trees_attach_cells first. */
+int cp2_slot_trees_save(cp2_slot_trees* t, const char* path);
+int cp2_slot_trees_load(cp2_ctx* ctx, const char* path, cp2_slot_trees** out);
+int cp2_slot_trees_attach_cells(cp2_slot_trees* t, const uint8_t* host_cells, const void* dev_cells);
 size_t cp2_slot_trees_count(const cp2_slot_trees* t);
 size_t cp2_slot_trees_depth(const cp2_slot_trees* t);   /* log2(cellsPerBlock) + log2(nBlocks) */
 /* roots of all slots in the batch (n_slots x 32 bytes): `treeRoot(bigTree)`, merkle.nim:14-17 */
@@ -165,6 +172,9 @@ typedef struct cp2_dataset cp2_dataset;
 /* Builds the trees of slots [first_slot, first_slot + n_local) on this GPU.  For a single GPU pass
  * first_slot = 0, n_local = cfg->n_slots.  */
 int cp2_dataset_build(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local, cp2_dataset** out);
+/* cp2_dataset_build with the slot trees cached in `cache_path` (read when present and matching, else built and written) */
+int cp2_dataset_build_cached(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local,
+                             const char* cache_path, cp2_dataset** out);
 void cp2_dataset_free(cp2_dataset* ds);
 /* roots of the local slots (n_local x 32 bytes) */
 int cp2_dataset_local_roots(cp2_dataset* ds, uint8_t* out);

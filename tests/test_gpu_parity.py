@@ -439,3 +439,40 @@ def test_batched_proof_inputs_equal_single(pkg, ctx, golden, tmp_path):
     import pytest as _pt
     with _pt.raises(Exception):
         ds.proof_inputs([5], 1)
+
+
+def test_slot_tree_cache_round_trip(pkg, ctx, golden, tmp_path):
+    """Persisted trees: a dataset restored from the cache file yields byte-identical proof inputs
+    without hashing a single cell; a cache written for another configuration is ignored and rebuilt."""
+    import os
+    import subprocess
+    m = golden("proof_inputs.json")["inputs"]["testmain_small"]
+    cache = str(tmp_path / "trees.cp2")
+    cfg = pkg.make_config(**m["config"])
+    a = ctx.dataset(cfg, cache=cache)
+    assert os.path.getsize(cache) > 32 * 5 * 256 * 3 // 2
+    text_a = a.proof_input(m["slotIndex"], m["entropy"]).json()
+    b = ctx.dataset(cfg, cache=cache)                      # second time: loaded
+    assert b.proof_input(m["slotIndex"], m["entropy"]).json() == text_a == golden("input_testmain_small.json")
+    assert b.proof_input(1, 777).json() == a.proof_input(1, 777).json()
+    other = pkg.make_config(**dict(m["config"], seed=999))
+    c = ctx.dataset(other, cache=cache)                    # mismatch -> rebuilt and overwritten
+    assert c.proof_input(0, 1).json() == ctx.dataset(other).proof_input(0, 1).json()
+    # standalone trees: save / load, roots and paths identical
+    t = ctx.slot_trees_fake(5, 0, 2, 128, 1024, 32)
+    p2 = str(tmp_path / "t.cp2")
+    t.save(p2)
+    u = ctx.slot_trees_load(p2)
+    assert np.array_equal(t.roots(), u.roots())
+    assert np.array_equal(t.paths(1, [0, 31], 8)[0], u.paths(1, [0, 31], 8)[0])
+    with pytest.raises(Exception):
+        ctx.slot_trees_load(str(tmp_path / "missing.cp2"))
+    # the cli twin honours CODEX_P2_CACHE
+    out = str(tmp_path / "cli.json")
+    args = [pkg.CLI_PATH, "-d:16", "-N=32", "-c128", "-b:4096", "-n=10", "-e:1234567", "-S12345", "-s=5", "-K:256", "-i3",
+            "-F:bn254", "-H=poseidon2", "-o=" + out]
+    env = dict(os.environ, CODEX_P2_CACHE=str(tmp_path / "cli.cp2"))
+    for _ in range(2):
+        r = subprocess.run(args, capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr
+        assert open(out).read() == golden("input_testmain_small.json")
