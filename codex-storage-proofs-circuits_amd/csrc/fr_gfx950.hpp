@@ -18,11 +18,44 @@
 // What the reference computes with this arithmetic: Permutation.hs:14-45 (field ops of
 // zikkurat-algebra / constantine there).  Nothing here is derived from those libraries' code.
 #pragma once
-#include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <utility>
 
+// CP2_HOST_CHECK: the same source compiled for the HOST by tests/host_check (g++ with sanitizers): the 64-bit
+// column accumulator becomes a 128-bit shadow that traps on overflow, and every documented limb bound is
+// asserted.  This is how the lazy-reduction bounds below are validated off the GPU; the product build never
+// defines it.
+#ifdef CP2_HOST_CHECK
+#include <cstdio>
+#include <cstdlib>
+#define __device__
+#define __forceinline__ inline
+#define __constant__ static const
+static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+#define CP2_BOUND(cond, what)                                                       \
+  do {                                                                              \
+    if (!(cond)) { std::fprintf(stderr, "BOUND VIOLATION: %s (%s:%d)\n", what, __FILE__, __LINE__); std::abort(); } \
+  } while (0)
+#else
+#include <hip/hip_runtime.h>
+#define CP2_BOUND(cond, what) ((void)0)
+#endif
+
 namespace fr {
+
+#ifdef CP2_HOST_CHECK
+struct acc_t {   // 64-bit accumulator with a 128-bit shadow: any carry out of bit 63 aborts
+  unsigned __int128 v = 0;
+  acc_t() = default;
+  acc_t(uint64_t x) : v(x) {}
+  acc_t& operator+=(uint64_t x) { v += x; CP2_BOUND((v >> 64) == 0, "column accumulator overflowed 64 bits"); return *this; }
+  acc_t& operator>>=(int s) { v >>= s; return *this; }
+  explicit operator uint32_t() const { return (uint32_t)v; }
+  explicit operator uint64_t() const { return (uint64_t)v; }
+};
+#else
+using acc_t = uint64_t;
+#endif
 
 #include "p2_consts_dev.inc"
 
@@ -52,7 +85,10 @@ __device__ __forceinline__ Fe fe_zero() {
 __device__ __forceinline__ Fe add_lazy(const Fe& a, const Fe& b) {
   Fe r;
 #pragma unroll
-  for (int i = 0; i < NL; ++i) r.l[i] = a.l[i] + b.l[i];
+  for (int i = 0; i < NL; ++i) {
+    CP2_BOUND((uint64_t)a.l[i] + b.l[i] < ((uint64_t)1 << 32), "add_lazy: limb overflowed 32 bits");
+    r.l[i] = a.l[i] + b.l[i];
+  }
   return r;
 }
 
@@ -80,15 +116,19 @@ __device__ __forceinline__ Fe norm_full(const Fe& a) {
   return r;
 }
 
+#ifdef CP2_HOST_CHECK
+template <typename... T> inline void tie(acc_t&, T&...) {}
+#else
 #include "fr_tie.inc"
+#endif
 
 template <int A0, int M0, int... I>
-__device__ __forceinline__ void tie_cols(uint64_t& acc, uint32_t (&a)[NL], uint32_t (&m)[NL], std::integer_sequence<int, I...>,
+__device__ __forceinline__ void tie_cols(acc_t& acc, uint32_t (&a)[NL], uint32_t (&m)[NL], std::integer_sequence<int, I...>,
                                          std::integer_sequence<int>) {
   tie(acc, a[A0 + I]...);
 }
 template <int A0, int M0, int... I, int J0, int... J>
-__device__ __forceinline__ void tie_cols(uint64_t& acc, uint32_t (&a)[NL], uint32_t (&m)[NL], std::integer_sequence<int, I...>,
+__device__ __forceinline__ void tie_cols(acc_t& acc, uint32_t (&a)[NL], uint32_t (&m)[NL], std::integer_sequence<int, I...>,
                                          std::integer_sequence<int, J0, J...>) {
   tie(acc, a[A0 + I]..., m[M0 + J0], m[M0 + J]...);
 }
@@ -99,7 +139,10 @@ __device__ __forceinline__ Fe mont_mul(const Fe& a_in, const Fe& b) {
   uint32_t a[NL], m[NL];
 #pragma unroll
   for (int i = 0; i < NL; ++i) a[i] = a_in.l[i];
-  uint64_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i)   // La * Lb < 6.1 U^2 (column sum < 2^64); checked limb by limb against the worst partner
+    CP2_BOUND((uint64_t)a_in.l[i] < ((uint64_t)5 << 29) && (uint64_t)b.l[i] < ((uint64_t)5 << 29), "mont_mul operand limb >= 5U");
+  acc_t acc = 0;
   auto lo_col = [&](auto kc) {
     constexpr int k = decltype(kc)::value;
     if constexpr (k > 0) tie_cols<0, 0>(acc, a, m, std::make_integer_sequence<int, k + 1>{}, std::make_integer_sequence<int, k>{});
@@ -133,7 +176,7 @@ __device__ __forceinline__ Fe mont_mul(const Fe& a_in, const Fe& b) {
 }
 
 template <int LO, int... I, int... J>
-__device__ __forceinline__ void tie_sq(uint64_t& acc, uint32_t (&a)[NL], uint32_t (&d)[NL], uint32_t (&m)[NL],
+__device__ __forceinline__ void tie_sq(acc_t& acc, uint32_t (&a)[NL], uint32_t (&d)[NL], uint32_t (&m)[NL],
                                        std::integer_sequence<int, I...>, std::integer_sequence<int, J...>) {
   tie(acc, a[LO + I]..., d[LO + I]..., m[LO + J]...);
 }
@@ -145,8 +188,11 @@ __device__ __forceinline__ Fe mont_sqr(const Fe& a_in) {
 #pragma unroll
   for (int i = 0; i < NL; ++i) a[i] = a_in.l[i];
 #pragma unroll
-  for (int i = 0; i < NL; ++i) d[i] = a[i] << 1;   // limbs < 2.47 U  =>  doubled < 2^32
-  uint64_t acc = 0;
+  for (int i = 0; i < NL; ++i) {
+    CP2_BOUND((uint64_t)a[i] * 100 < (uint64_t)247 << 29, "mont_sqr operand limb >= 2.47U");
+    d[i] = a[i] << 1;   // limbs < 2.47 U  =>  doubled < 2^32
+  }
+  acc_t acc = 0;
   auto lo_col = [&](auto kc) {
     constexpr int k = decltype(kc)::value;
     if constexpr (k > 0) tie_sq<0>(acc, a, d, m, std::make_integer_sequence<int, k + 1>{}, std::make_integer_sequence<int, k>{});
@@ -212,6 +258,9 @@ __device__ __forceinline__ Fe reduce_lazy(const Fe& a, const uint32_t* tab) {
   uint32_t t = a.l[NL - 1] + (a.l[NL - 2] >> 29);
   // q = floor(t / (0x30644e + 1)) via 2^32 / 3171407 = 1354.27...; under-estimates only
   uint32_t q = __umulhi(t, 1354u);
+  CP2_BOUND(q < (uint32_t)QTAB_ROWS, "reduce_lazy: q outside the table (value >= 32N)");
+#pragma unroll
+  for (int i = 0; i < NL - 1; ++i) CP2_BOUND((uint64_t)a.l[i] < ((uint64_t)6 << 29), "reduce_lazy input limb >= 6U");
   const uint32_t* row = tab + q * NL;
   Fe r;
   uint32_t c = 0;
@@ -222,6 +271,7 @@ __device__ __forceinline__ Fe reduce_lazy(const Fe& a, const uint32_t* tab) {
     c = d >> 29;
   }
   r.l[NL - 1] = a.l[NL - 1] + row[NL - 1] + c;
+  CP2_BOUND(r.l[NL - 1] < (1u << 24), "reduce_lazy: result not below 2N (top limb)");
   return r;
 }
 

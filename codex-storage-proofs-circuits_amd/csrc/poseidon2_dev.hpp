@@ -17,6 +17,13 @@ struct State {
   Fe x, y, z;
 };
 
+// the S-box keeps its output below 1.1 N (top limb < 1.1 * 0x30644f): asserted in the host check build
+__device__ __forceinline__ Fe sbox_checked(const Fe& x) {
+  Fe r = fr::sbox(x);
+  CP2_BOUND(r.l[fr::NL - 1] < 3488548u, "sbox output >= 1.1N");
+  return r;
+}
+
 __device__ __forceinline__ Fe rc(int idx) {
   Fe r;
 #pragma unroll
@@ -26,9 +33,9 @@ __device__ __forceinline__ Fe rc(int idx) {
 
 // Permutation.hs:28-33.  in: limbs < U+8;  out: limbs < U+8, values < 4.3 N
 __device__ __forceinline__ void external_round(State& s, int rc_base) {
-  Fe x = fr::sbox(fr::add_lazy(s.x, rc(rc_base + 0)));
-  Fe y = fr::sbox(fr::add_lazy(s.y, rc(rc_base + 1)));
-  Fe z = fr::sbox(fr::add_lazy(s.z, rc(rc_base + 2)));
+  Fe x = sbox_checked(fr::add_lazy(s.x, rc(rc_base + 0)));
+  Fe y = sbox_checked(fr::add_lazy(s.y, rc(rc_base + 1)));
+  Fe z = sbox_checked(fr::add_lazy(s.z, rc(rc_base + 2)));
   Fe sum = fr::add_lazy(fr::add_lazy(x, y), z);
   s.x = fr::norm(fr::add_lazy(x, sum));
   s.y = fr::norm(fr::add_lazy(y, sum));
@@ -38,7 +45,7 @@ __device__ __forceinline__ void external_round(State& s, int rc_base) {
 // Permutation.hs:19-26.  y and z never pass through an S-box in these 56 rounds, so they are
 // brought back below 2N every round by reduce_lazy (values grow ~4x per round otherwise).
 __device__ __forceinline__ void internal_round(State& s, int rc_idx, const uint32_t* qtab) {
-  Fe x = fr::sbox(fr::add_lazy(s.x, rc(rc_idx)));
+  Fe x = sbox_checked(fr::add_lazy(s.x, rc(rc_idx)));
   Fe sum = fr::add_lazy(fr::add_lazy(x, s.y), s.z);              // x' + y + z        limbs < 3U
   s.x = fr::norm(fr::add_lazy(x, sum));                           // 2x' + y + z       < 6.2 N
   s.y = fr::reduce_lazy(fr::add_lazy(s.y, sum), qtab);            // x' + 2y + z       < 7.1 N -> < 2N

@@ -1,0 +1,101 @@
+// Host build of the DEVICE arithmetic (csrc/fr_gfx950.hpp + csrc/poseidon2_dev.hpp with CP2_HOST_CHECK):
+// runs the very same source on the CPU with a 128-bit shadow accumulator and asserted limb bounds, under
+// -fsanitize=address,undefined, on random and adversarial states, and compares every result with the C oracle.
+// Usage: host_check <n_random> ; exits non-zero on any mismatch or bound violation.
+#define CP2_HOST_CHECK 1
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../codex-storage-proofs-circuits_amd/csrc/poseidon2_dev.hpp"
+extern "C" {
+#include "../../oracle/p2_oracle.h"
+}
+
+using fr::Fe;
+
+static uint32_t g_qtab[fr::QTAB_WORDS];
+
+static Fe load_canonical(const uint8_t* p) {
+  uint32_t w[8];
+  std::memcpy(w, p, 32);
+  return fr::to_mont(fr::from_words(w));
+}
+static void store_canonical(uint8_t* p, const Fe& v) {
+  uint32_t w[8];
+  fr::to_canonical_words(v, w);
+  std::memcpy(p, w, 32);
+}
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ULL;
+static uint64_t rnd() {   // splitmix64
+  uint64_t z = (rng_state += 0x9E3779B97F4A7C15ULL);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+static int check_state(const uint8_t in[96]) {
+  p2::State s;
+  s.x = load_canonical(in);
+  s.y = load_canonical(in + 32);
+  s.z = load_canonical(in + 64);
+  p2::permute(s, g_qtab);
+  uint8_t got[96], want[96];
+  store_canonical(got, s.x);
+  store_canonical(got + 32, s.y);
+  store_canonical(got + 64, s.z);
+  p2o_permute(in, want);
+  if (std::memcmp(got, want, 96) != 0) {
+    std::fprintf(stderr, "MISMATCH for input ");
+    for (int i = 0; i < 96; ++i) std::fprintf(stderr, "%02x", in[i]);
+    std::fprintf(stderr, "\n");
+    return 1;
+  }
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  size_t n_random = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 2000;
+  for (int i = 0; i < fr::QTAB_WORDS; ++i) fr::qtab_fill(g_qtab, i, fr::QTAB_WORDS);
+  int bad = 0;
+  size_t count = 0;
+  // adversarial field elements: 0, 1, r-1, r, r+1, 2^256-1, all-ones limbs, powers of two around limb borders
+  std::vector<std::vector<uint8_t>> special;
+  auto push_int = [&](std::initializer_list<uint64_t> limbs) {
+    std::vector<uint8_t> v(32, 0);
+    int k = 0;
+    for (uint64_t l : limbs) { std::memcpy(&v[8 * k], &l, 8); ++k; }
+    special.push_back(v);
+  };
+  push_int({0, 0, 0, 0});
+  push_int({1, 0, 0, 0});
+  push_int({0x43e1f593f0000000ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL});   // r-1
+  push_int({0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL});   // r
+  push_int({0x43e1f593f0000002ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL});   // r+1
+  push_int({~0ULL, ~0ULL, ~0ULL, ~0ULL});
+  push_int({~0ULL, ~0ULL, ~0ULL, 0x3fffffffffffffffULL});
+  push_int({0x1fffffff1fffffffULL, 0x1fffffff1fffffffULL, 0x1fffffff1fffffffULL, 0x1fffffff1fffffffULL});
+  for (int b = 28; b < 256; b += 29) { std::vector<uint8_t> v(32, 0); v[b / 8] = (uint8_t)(1u << (b % 8)); special.push_back(v); }
+  for (size_t a = 0; a < special.size(); ++a)
+    for (size_t b = 0; b < special.size(); ++b)
+      for (size_t c = 0; c < special.size(); c += 3) {
+        uint8_t in[96];
+        std::memcpy(in, special[a].data(), 32);
+        std::memcpy(in + 32, special[b].data(), 32);
+        std::memcpy(in + 64, special[(c + a + b) % special.size()].data(), 32);
+        bad += check_state(in);
+        ++count;
+      }
+  for (size_t i = 0; i < n_random; ++i) {
+    uint8_t in[96];
+    for (int k = 0; k < 12; ++k) { uint64_t r = rnd(); std::memcpy(in + 8 * k, &r, 8); }
+    if (i & 1) { in[31] &= 0x1f; in[63] &= 0x1f; in[95] &= 0x1f; }   // half canonical, half arbitrary 256-bit
+    bad += check_state(in);
+    ++count;
+  }
+  std::printf("host_check: %zu states, %d mismatches, no bound violations\n", count, bad);
+  return bad ? 1 : 0;
+}
