@@ -152,37 +152,59 @@ extern "C" int cp2_slot_trees_build_dev(cp2_ctx* ctx, const void* d_cells, size_
   return CP2_OK;
 }
 
-// upload + hash `n` cells from host memory into leaf slots [leaf0, leaf0+n), double-buffered
-static int hash_host_cells(cp2_slot_trees* t, const uint8_t* cells, size_t n, size_t leaf0, DevBuf stage[2], size_t chunk,
-                           hipEvent_t done[2]) {
-  cp2_ctx* ctx = t->ctx;
-  size_t i = 0;
-  for (size_t c0 = 0; c0 < n; c0 += chunk, ++i) {
-    size_t m = std::min(chunk, n - c0);
-    int b = (int)(i & 1);
-    CP2_HIP(ctx, hipEventSynchronize(done[b]));   // the kernel that last read this buffer has finished
-    CP2_HIP(ctx, hipMemcpyAsync(stage[b].p, cells + c0 * t->cell_size, m * t->cell_size, hipMemcpyHostToDevice, ctx->stream));
-    CP2_HIP(ctx, cp2k::launch_hash_cells(stage[b].p, t->cell_size, m, t->nodes.u8() + (leaf0 + c0) * 32, ctx->stream));
-    CP2_HIP(ctx, hipEventRecord(done[b], ctx->stream));
-  }
-  return CP2_OK;
-}
+// ---- streaming ingestion ----------------------------------------------------
+// Three overlapped stages over two slots of a ring: the host fills a PINNED buffer (fread or memcpy),
+// a dedicated copy stream moves it to the device, the context's stream hashes it.  While chunk i is copied and
+// hashed the host is already filling chunk i+1, so disk, PCIe and the GPU work concurrently
+// (the reference re-opens the slot file and reads one cell per call, slot.nim:57-68).
+struct IngestPipe {
+  static constexpr size_t CHUNK_BYTES = (size_t)64 << 20;
+  cp2_ctx* ctx = nullptr;
+  hipStream_t copy = nullptr;
+  void* pinned[2] = {nullptr, nullptr};
+  DevBuf dev[2];
+  hipEvent_t copied[2] = {nullptr, nullptr}, hashed[2] = {nullptr, nullptr};
+  size_t chunk = 0, turn = 0;
 
-struct HostStage {
-  DevBuf buf[2];
-  hipEvent_t done[2] = {nullptr, nullptr};
-  size_t chunk = 0;
-  ~HostStage() {
-    for (auto& e : done)
-      if (e) (void)hipEventDestroy(e);
-  }
-  int init(cp2_ctx* ctx, size_t cell_size, size_t max_cells) {
-    chunk = std::max<size_t>(1, std::min(max_cells, (STAGE_BYTES / 8) / cell_size));
+  ~IngestPipe() {
+    if (!ctx) return;
+    (void)hipStreamSynchronize(ctx->stream);
     for (int b = 0; b < 2; ++b) {
-      CP2_TRY(buf[b].alloc(ctx, chunk * cell_size));
-      CP2_HIP(ctx, hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
-      CP2_HIP(ctx, hipEventRecord(done[b], ctx->stream));
+      if (copied[b]) (void)hipEventDestroy(copied[b]);
+      if (hashed[b]) (void)hipEventDestroy(hashed[b]);
+      if (pinned[b]) (void)hipHostFree(pinned[b]);
     }
+    if (copy) (void)hipStreamDestroy(copy);
+  }
+  int init(cp2_ctx* c, size_t cell_size, size_t max_cells) {
+    ctx = c;
+    chunk = std::max<size_t>(1, std::min(max_cells, CHUNK_BYTES / cell_size));
+    CP2_HIP(ctx, hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+      CP2_HIP(ctx, hipHostMalloc(&pinned[b], chunk * cell_size, hipHostMallocDefault));
+      CP2_TRY(dev[b].alloc(ctx, chunk * cell_size));
+      CP2_HIP(ctx, hipEventCreateWithFlags(&copied[b], hipEventDisableTiming));
+      CP2_HIP(ctx, hipEventCreateWithFlags(&hashed[b], hipEventDisableTiming));
+      CP2_HIP(ctx, hipEventRecord(hashed[b], ctx->stream));
+    }
+    return CP2_OK;
+  }
+  // the pinned buffer the host may fill next (blocks until the kernel that last used this ring slot is done)
+  int acquire(uint8_t** buf) {
+    int b = (int)(turn & 1);
+    CP2_HIP(ctx, hipEventSynchronize(hashed[b]));
+    *buf = static_cast<uint8_t*>(pinned[b]);
+    return CP2_OK;
+  }
+  // ship the filled buffer: m cells -> leaf hashes at `leaves_out`
+  int submit(size_t m, size_t cell_size, uint8_t* leaves_out) {
+    int b = (int)(turn & 1);
+    CP2_HIP(ctx, hipMemcpyAsync(dev[b].p, pinned[b], m * cell_size, hipMemcpyHostToDevice, copy));
+    CP2_HIP(ctx, hipEventRecord(copied[b], copy));
+    CP2_HIP(ctx, hipStreamWaitEvent(ctx->stream, copied[b], 0));
+    CP2_HIP(ctx, cp2k::launch_hash_cells(dev[b].p, cell_size, m, leaves_out, ctx->stream));
+    CP2_HIP(ctx, hipEventRecord(hashed[b], ctx->stream));
+    ++turn;
     return CP2_OK;
   }
 };
@@ -197,18 +219,28 @@ extern "C" int cp2_slot_trees_build_host(cp2_ctx* ctx, const uint8_t* cells, siz
   if (!t) return CP2_ERR_ALLOC;
   t->src = CellSrc::Host;
   t->h_cells = cells;
-  HostStage hs;
   int st = trees_layout(t);
-  if (st == CP2_OK) st = hs.init(ctx, cell_size, n_slots * n_cells);
-  if (st == CP2_OK) st = hash_host_cells(t, cells, n_slots * n_cells, 0, hs.buf, hs.chunk, hs.done);
-  if (st == CP2_OK) st = trees_build_layers(t);
-  if (st == CP2_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = CP2_ERR_HIP;
+  {
+    IngestPipe pipe;
+    const size_t total = n_slots * n_cells;
+    if (st == CP2_OK) st = pipe.init(ctx, cell_size, total);
+    for (size_t c0 = 0; st == CP2_OK && c0 < total; c0 += pipe.chunk) {
+      size_t m = std::min(pipe.chunk, total - c0);
+      uint8_t* buf = nullptr;
+      st = pipe.acquire(&buf);
+      if (st != CP2_OK) break;
+      std::memcpy(buf, cells + c0 * cell_size, m * cell_size);
+      st = pipe.submit(m, cell_size, t->nodes.u8() + c0 * 32);
+    }
+    if (st == CP2_OK) st = trees_build_layers(t);
+    if (st == CP2_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = CP2_ERR_HIP;
+  }
   if (st != CP2_OK) { delete t; return st; }
   *out = t;
   return CP2_OK;
 }
 
-// slot files "<base><k>.dat" (dataset.nim:34), streamed through the staging buffers; short files read as zeros
+// slot files "<base><k>.dat" (dataset.nim:34) streamed through the ingestion pipe; short files read as zeros
 static int trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t first_slot, size_t n_slots, size_t cell_size,
                              size_t block_size, size_t n_cells, cp2_slot_trees** out) {
   *out = nullptr;
@@ -219,35 +251,28 @@ static int trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t fir
   t->src = CellSrc::File;
   t->file_base = base;
   t->first_slot = first_slot;
-  HostStage hs;
   int st = trees_layout(t);
-  if (st == CP2_OK) st = hs.init(ctx, cell_size, n_cells);
-  std::vector<uint8_t> host[2];
-  if (st == CP2_OK) {
-    host[0].resize(hs.chunk * cell_size);
-    host[1].resize(hs.chunk * cell_size);
-  }
-  size_t turn = 0;
-  for (size_t s = 0; st == CP2_OK && s < n_slots; ++s) {
-    std::string fname = base + std::to_string(first_slot + s) + ".dat";
-    FILE* f = std::fopen(fname.c_str(), "rb");
-    if (!f) { ctx->err = "cannot open " + fname; st = CP2_ERR_IO; break; }
-    for (size_t c0 = 0; st == CP2_OK && c0 < n_cells; c0 += hs.chunk, ++turn) {
-      size_t m = std::min(hs.chunk, n_cells - c0);
-      int b = (int)(turn & 1);
-      if (hipEventSynchronize(hs.done[b]) != hipSuccess) { st = CP2_ERR_HIP; break; }
-      size_t got = std::fread(host[b].data(), 1, m * cell_size, f);
-      if (got < m * cell_size) std::memset(host[b].data() + got, 0, m * cell_size - got);
-      hipError_t e = hipMemcpyAsync(hs.buf[b].p, host[b].data(), m * cell_size, hipMemcpyHostToDevice, ctx->stream);
-      if (e == hipSuccess)
-        e = cp2k::launch_hash_cells(hs.buf[b].p, cell_size, m, t->nodes.u8() + (s * n_cells + c0) * 32, ctx->stream);
-      if (e == hipSuccess) e = hipEventRecord(hs.done[b], ctx->stream);
-      if (e != hipSuccess) { ctx->err = hipGetErrorString(e); st = CP2_ERR_HIP; }
+  {
+    IngestPipe pipe;
+    if (st == CP2_OK) st = pipe.init(ctx, cell_size, n_cells);
+    for (size_t s = 0; st == CP2_OK && s < n_slots; ++s) {
+      std::string fname = base + std::to_string(first_slot + s) + ".dat";
+      FILE* f = std::fopen(fname.c_str(), "rb");
+      if (!f) { ctx->err = "cannot open " + fname; st = CP2_ERR_IO; break; }
+      for (size_t c0 = 0; st == CP2_OK && c0 < n_cells; c0 += pipe.chunk) {
+        size_t m = std::min(pipe.chunk, n_cells - c0);
+        uint8_t* buf = nullptr;
+        st = pipe.acquire(&buf);
+        if (st != CP2_OK) break;
+        size_t got = std::fread(buf, 1, m * cell_size, f);
+        if (got < m * cell_size) std::memset(buf + got, 0, m * cell_size - got);
+        st = pipe.submit(m, cell_size, t->nodes.u8() + (s * n_cells + c0) * 32);
+      }
+      std::fclose(f);
     }
-    std::fclose(f);
+    if (st == CP2_OK) st = trees_build_layers(t);
+    if (st == CP2_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = CP2_ERR_HIP;
   }
-  if (st == CP2_OK) st = trees_build_layers(t);
-  if (st == CP2_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = CP2_ERR_HIP;
   if (st != CP2_OK) { delete t; return st; }
   *out = t;
   return CP2_OK;

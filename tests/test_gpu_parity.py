@@ -476,3 +476,27 @@ def test_slot_tree_cache_round_trip(pkg, ctx, golden, tmp_path):
         r = subprocess.run(args, capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0, r.stderr
         assert open(out).read() == golden("input_testmain_small.json")
+
+
+def test_streaming_ingestion_multi_chunk(pkg, ctx, oracle, tmp_path):
+    """Host and file sources larger than one 64 MiB pipeline chunk (several ring turns) against the device path."""
+    import torch
+    C, _ = oracle
+    cs, bs, nc, ns = 2048, 65536, 1 << 15, 3            # 64 MiB per slot, 192 MiB in all
+    d = torch.empty((ns * nc, cs), dtype=torch.uint8, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    for s in range(ns):
+        ctx.gen_fake_cells_dev(C.slot_seed(4711, s), 0, nc, cs, d[s * nc].data_ptr())
+    torch.cuda.synchronize()
+    ctx.reset_stream()
+    want = ctx.slot_trees_fake(4711, 0, ns, cs, bs, nc).roots()
+    cells = d.cpu().numpy()
+    assert np.array_equal(ctx.slot_trees_host(cells, ns, cs, bs, nc).roots(), want)
+    base = str(tmp_path / "slot")
+    for s in range(ns):
+        cells[s * nc:(s + 1) * nc].tofile("%s%d.dat" % (base, s))
+    cfg = pkg.make_config(maxDepth=32, maxLog2NSlots=2, cellSize=cs, blockSize=bs, nSlots=ns, nCells=nc, nSamples=3, file=base)
+    ds = ctx.dataset(cfg)
+    assert np.array_equal(ds.local_roots(), want)
+    fake = ctx.dataset(pkg.make_config(maxDepth=32, maxLog2NSlots=2, cellSize=cs, blockSize=bs, nSlots=ns, nCells=nc, nSamples=3, seed=4711))
+    assert ds.proof_input(2, 5).json() == fake.proof_input(2, 5).json()
