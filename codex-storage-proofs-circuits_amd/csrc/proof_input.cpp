@@ -7,9 +7,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -20,6 +22,19 @@
 using namespace cp2i;
 
 namespace {
+// CP2_TRACE=1: stage timings of the batched proof-input path on stderr (the reference's only tracing is shell
+// `time` around whole steps, workflow/prove.sh:30-37)
+struct StageTimer {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  StageTimer() : on(std::getenv("CP2_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  void lap(const char* what) {
+    if (!on) return;
+    auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[cp2 trace] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
 constexpr uint64_t NO_ROW = ~0ULL;
 constexpr size_t STAGE_BYTES = (size_t)1 << 31;   // device staging buffer for generated / uploaded cells
 
@@ -606,12 +621,21 @@ extern "C" int cp2_dataset_root(cp2_dataset* ds, uint8_t out[32]) {
 // ---------------------------------------------------------------------------------------------
 // proof input
 // ---------------------------------------------------------------------------------------------
+// cell bytes and Merkle paths of a whole batch live in one uninitialised allocation that every proof input of
+// the batch shares (no zero-fill, one device-to-host copy, no per-slot copies)
+struct BatchStore {
+  std::unique_ptr<uint8_t[]> cells, paths;
+};
+
 struct cp2_proof_input {
   cp2_config cfg{};
   uint64_t slot_idx = 0;
   uint8_t entropy[32], dataset_root[32], slot_root[32];
   std::vector<uint64_t> indices;
-  std::vector<uint8_t> cell_data, paths, slot_proof;
+  std::vector<uint8_t> slot_proof;
+  std::shared_ptr<BatchStore> store;
+  const uint8_t* cell_data = nullptr;   // nSamples x cellSize, inside store->cells
+  const uint8_t* paths = nullptr;       // nSamples x maxDepth x 32, inside store->paths
 };
 
 // slotProof = padMerkleProof(merkleProof(dsetTree, slotIdx), maxLog2NSlots), gen_input/bn254.nim:51,72
@@ -646,6 +670,7 @@ extern "C" int cp2_proof_inputs_generate_batch(cp2_dataset* ds, const uint64_t* 
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   const size_t ns = cfg.n_samples, md = (size_t)cfg.max_depth, cs = cfg.cell_size, total = n * ns;
 
+  StageTimer trace;
   // ---- sampling: cellIndices for every (slot, counter), sample/bn254.nim:16-27
   std::vector<uint64_t> indices(total);
   if (total) {
@@ -667,8 +692,15 @@ extern "C" int cp2_proof_inputs_generate_batch(cp2_dataset* ds, const uint64_t* 
       indices[k] = lo & (cfg.n_cells - 1);
     }
   }
+  trace.lap("sampling");
   // ---- paths (one gather) and cells (one fetch)
-  std::vector<uint8_t> paths(total * md * 32), cells(total * cs);
+  auto store = std::make_shared<BatchStore>();
+  store->paths.reset(new (std::nothrow) uint8_t[std::max<size_t>(total * md * 32, 1)]);
+  store->cells.reset(new (std::nothrow) uint8_t[std::max<size_t>(total * cs, 1)]);
+  if (!store->paths || !store->cells) return CP2_ERR_ALLOC;
+  uint8_t* paths = store->paths.get();
+  uint8_t* cells = store->cells.get();
+  trace.lap("host buffers");
   if (total) {
     std::vector<uint64_t> rows(total * md);
     std::vector<uint64_t> gcell(total);
@@ -684,9 +716,11 @@ extern "C" int cp2_proof_inputs_generate_batch(cp2_dataset* ds, const uint64_t* 
     CP2_TRY(d_out.alloc(ctx, rows.size() * 32));
     CP2_HIP(ctx, hipMemcpyAsync(d_rows.p, rows.data(), rows.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     CP2_HIP(ctx, cp2k::launch_gather_rows(t->nodes.p, static_cast<const uint64_t*>(d_rows.p), rows.size(), 32, d_out.p, ctx->stream));
-    CP2_HIP(ctx, hipMemcpyAsync(paths.data(), d_out.p, paths.size(), hipMemcpyDeviceToHost, ctx->stream));
+    CP2_HIP(ctx, hipMemcpyAsync(paths, d_out.p, total * md * 32, hipMemcpyDeviceToHost, ctx->stream));
     CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    CP2_TRY(trees_cells_global(t, gcell.data(), total, cells.data()));
+    trace.lap("path rows + gather + D2H");
+    CP2_TRY(trees_cells_global(t, gcell.data(), total, cells));
+    trace.lap("cells fetch + D2H");
   }
   // ---- split
   for (size_t i = 0; i < n; ++i) {
@@ -702,10 +736,12 @@ extern "C" int cp2_proof_inputs_generate_batch(cp2_dataset* ds, const uint64_t* 
     std::memcpy(p->slot_root, &ds->dlayers[slot_idx[i] * 32], 32);      // layer 0 of the dataset tree = slot roots
     fill_slot_proof(ds, slot_idx[i], p->slot_proof);
     p->indices.assign(indices.begin() + i * ns, indices.begin() + (i + 1) * ns);
-    p->cell_data.assign(cells.begin() + i * ns * cs, cells.begin() + (i + 1) * ns * cs);
-    p->paths.assign(paths.begin() + i * ns * md * 32, paths.begin() + (i + 1) * ns * md * 32);
+    p->store = store;
+    p->cell_data = cells + i * ns * cs;
+    p->paths = paths + i * ns * md * 32;
     out[i] = p;
   }
+  trace.lap("split into proof inputs");
   return CP2_OK;
 }
 
@@ -725,8 +761,8 @@ extern "C" int cp2_proof_input_roots(const cp2_proof_input* p, uint8_t dataset_r
 }
 extern "C" size_t cp2_proof_input_nsamples(const cp2_proof_input* p) { return p ? p->indices.size() : 0; }
 extern "C" const uint64_t* cp2_proof_input_cell_indices(const cp2_proof_input* p) { return p ? p->indices.data() : nullptr; }
-extern "C" const uint8_t* cp2_proof_input_cell_data(const cp2_proof_input* p) { return p ? p->cell_data.data() : nullptr; }
-extern "C" const uint8_t* cp2_proof_input_merkle_paths(const cp2_proof_input* p) { return p ? p->paths.data() : nullptr; }
+extern "C" const uint8_t* cp2_proof_input_cell_data(const cp2_proof_input* p) { return p ? p->cell_data : nullptr; }
+extern "C" const uint8_t* cp2_proof_input_merkle_paths(const cp2_proof_input* p) { return p ? p->paths : nullptr; }
 extern "C" const uint8_t* cp2_proof_input_slot_proof(const cp2_proof_input* p) { return p ? p->slot_proof.data() : nullptr; }
 
 // ---- JSON (json/bn254.nim:57-74, json/shared.nim:17-25, types/bn254.nim:29-43) -----------------
@@ -794,14 +830,14 @@ static void proof_input_text(const cp2_proof_input* p, std::string& s) {
     size_t nf = cp2_felts_per_bytes(cfg.cell_size);
     std::vector<uint8_t> felts(nf * 32);
     for (size_t i = 0; i < ns; ++i) {
-      cp2_bytes_to_felts(&p->cell_data[i * cfg.cell_size], cfg.cell_size, felts.data());   // json/bn254.nim:25
+      cp2_bytes_to_felts(p->cell_data + i * cfg.cell_size, cfg.cell_size, felts.data());   // json/bn254.nim:25
       write_felt_list(s, (i == 0) ? outer + "[ " : outer_indent + ", ", felts.data(), nf);
     }
     s += outer_indent + "]\n";
   }
   s += ", \"merklePaths\":\n";
   for (size_t i = 0; i < ns; ++i)
-    write_felt_list(s, (i == 0) ? outer + "[ " : outer_indent + ", ", &p->paths[i * (size_t)cfg.max_depth * 32], (size_t)cfg.max_depth);
+    write_felt_list(s, (i == 0) ? outer + "[ " : outer_indent + ", ", p->paths + i * (size_t)cfg.max_depth * 32, (size_t)cfg.max_depth);
   s += outer_indent + "]\n";
   s += "}\n";
 }
