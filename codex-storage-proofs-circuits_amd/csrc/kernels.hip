@@ -21,7 +21,7 @@ constexpr int TPB = 256;
 #define CP2_PERM_WAVES 1
 #endif
 #ifndef CP2_HASH_WAVES
-#define CP2_HASH_WAVES 4
+#define CP2_HASH_WAVES 3
 #endif
 
 __device__ __forceinline__ Fe load_fe_canonical(const uint4* p) {
@@ -122,32 +122,44 @@ __global__ void __launch_bounds__(TPB) k_sponge2_felts(const uint4* __restrict__
 // The byte stream a lane absorbs is  cell || 0x01 || 0-pad to 31*nfelts || sponge pad, where the
 // sponge's "1" pad element is itself the chunk {0x01,0,...} and the optional "0" element a zero
 // chunk (Slot.hs:243-250 then Sponge.hs:36-39).  So the whole padded input is one byte stream cut
-// into 31-byte little-endian chunks, two per permutation.
+// into 31-byte little-endian chunks, two per permutation (62 bytes).
 //
-// Staging: each wave copies 124 bytes (= 4 chunks = 2 permutations) of each of its 64 cells into
-// LDS with lane-linear dword loads (31 consecutive lanes read one cell's 124 contiguous bytes), then
-// every lane reads back its own row; row stride 31 dwords is odd, so both sides are bank-conflict free.
-constexpr int TILE_WORDS = 31;            // 124 bytes
-constexpr int TILE_BYTES = 124;
+// Staging: the stream is fetched in whole 128-byte lines, each exactly once.  Per stage a wave copies one
+// line of each of its 64 cells into a per-cell LDS ring: lane-linear dword loads, 32 consecutive lanes read
+// one full line (perfectly coalesced), and the ring row stride of 49 dwords is odd, so the per-lane reads
+// are bank-conflict free.  The sponge consumes 62 bytes per permutation, the producer adds 128 per stage,
+// so at most 60 bytes wait in the ring when the next line lands: 188 <= 192 ring bytes.  (The first
+// version staged 124-byte tiles, which touches most lines twice: FETCH_SIZE showed 2x the algorithmic
+// bytes, calibrated with tools/fetch_calib.hip.)
+constexpr int RING_WORDS = 48;             // 192 bytes per cell
+constexpr int RING_STRIDE = 49;            // odd row stride
+constexpr int LINE_WORDS = 32;             // 128 bytes
 
-__device__ __forceinline__ Fe chunk_limbs(const uint32_t* row, int j) {
-  // chunk j of the row = bits [248j, 248j+248) -> 9 raw limbs (8 x 29 bits + 16 bits)
-  Fe r;
+// two 31-byte chunks from a 17-dword window whose first chunk starts SH bits into w[0] (SH = 0 or 16)
+template <int SH>
+__device__ __forceinline__ void chunk_pair(const uint32_t (&w)[17], Fe& a, Fe& b) {
 #pragma unroll
   for (int i = 0; i < fr::NL; ++i) {
-    const int bit = 248 * j + 29 * i, k = bit / 32, s = bit % 32;
     const int width = (i == fr::NL - 1) ? 16 : 29;
-    uint32_t v = row[k] >> s;
-    if (s + width > 32) v |= row[k + 1] << (32 - s);
-    r.l[i] = v & ((1u << width) - 1);
+    {
+      const int bit = SH + 29 * i, k = bit / 32, sh = bit % 32;
+      uint32_t v = w[k] >> sh;
+      if (sh + width > 32) v |= w[k + 1] << (32 - sh);
+      a.l[i] = v & ((1u << width) - 1);
+    }
+    {
+      const int bit = SH + 248 + 29 * i, k = bit / 32, sh = bit % 32;
+      uint32_t v = w[k] >> sh;
+      if (sh + width > 32) v |= w[k + 1] << (32 - sh);
+      b.l[i] = v & ((1u << width) - 1);
+    }
   }
-  return r;
 }
 
 __global__ void __launch_bounds__(TPB, CP2_HASH_WAVES) k_hash_cells(const uint8_t* __restrict__ cells, size_t cell_size,
-                                                      size_t n_cells, uint4* __restrict__ out) {
+                                                                      size_t n_cells, uint4* __restrict__ out) {
   __shared__ uint32_t qtab[fr::QTAB_WORDS];
-  __shared__ uint32_t stage[TPB / 64][64 * TILE_WORDS];
+  __shared__ uint32_t ring[TPB / 64][64 * RING_STRIDE];
   fr::qtab_fill(qtab, threadIdx.x, TPB);
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -156,7 +168,8 @@ __global__ void __launch_bounds__(TPB, CP2_HASH_WAVES) k_hash_cells(const uint8_
   const size_t nfelts = (cell_size + 31) / 31;            // chunks of cell || 0x01
   const size_t total = (nfelts + 2) & ~(size_t)1;          // + sponge pad, even
   const size_t sponge_pad_pos = 31 * nfelts;               // byte position of the sponge's "1"
-  const size_t ntiles = (total + 3) / 4;
+  const size_t stream_len = 31 * total;                    // multiple of 62
+  const size_t nlines = (stream_len + 127) / 128;
   const bool aligned4 = ((cell_size & 3) == 0) && ((reinterpret_cast<uintptr_t>(cells) & 3) == 0);
 
   State s;
@@ -164,22 +177,25 @@ __global__ void __launch_bounds__(TPB, CP2_HASH_WAVES) k_hash_cells(const uint8_
   s.y = fr::fe_zero();
   s.z = fr::fe_const(fr::FR_CIV_RATE2_MONT);
 
-  uint32_t* my_stage = stage[wave];
+  uint32_t* my_ring = ring[wave];
+  const uint32_t* my_row = my_ring + lane * RING_STRIDE;
+  size_t cons = 0;                                          // bytes absorbed so far (wave-uniform)
 #pragma unroll 1
-  for (size_t tile = 0; tile < ntiles; ++tile) {
-    __syncthreads();   // previous tile fully consumed (also orders the qtab fill on the first pass)
-#pragma unroll 1
-    for (int k = 0; k < TILE_WORDS; ++k) {
+  for (size_t line = 0; line < nlines; ++line) {
+    __syncthreads();   // every lane is done reading what this stage overwrites (and, first pass, the qtab fill)
+    const int ring_base = (int)((line * LINE_WORDS) % RING_WORDS);
+#pragma unroll 4
+    for (int k = 0; k < LINE_WORDS; ++k) {
       const int idx = k * 64 + lane;
-      const int c = idx / TILE_WORDS, w = idx - c * TILE_WORDS;
+      const int c = idx >> 5, w = idx & 31;                 // 32 consecutive lanes = one 128-byte line
       const size_t cell = cell0 + c;
-      const size_t p0 = tile * TILE_BYTES + (size_t)w * 4;
+      const size_t p0 = line * 128 + (size_t)w * 4;
       uint32_t val = 0;
       if (cell < n_cells) {
         const uint8_t* base = cells + cell * cell_size;
         if (aligned4 && p0 + 4 <= cell_size) {
           val = *reinterpret_cast<const uint32_t*>(base + p0);
-        } else {
+        } else if (p0 <= cell_size) {
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
             size_t p = p0 + b;
@@ -189,48 +205,31 @@ __global__ void __launch_bounds__(TPB, CP2_HASH_WAVES) k_hash_cells(const uint8_
         }
         if (sponge_pad_pos >= p0 && sponge_pad_pos < p0 + 4) val |= 1u << (8 * (sponge_pad_pos - p0));
       }
-      my_stage[idx] = val;
+      int slot = ring_base + w;
+      if (slot >= RING_WORDS) slot -= RING_WORDS;
+      my_ring[c * RING_STRIDE + slot] = val;
     }
     __syncthreads();
-    const uint32_t* row = my_stage + lane * TILE_WORDS;
-    {
-      uint32_t r[16];
+    const size_t avail = (line + 1) * 128 < stream_len ? (line + 1) * 128 : stream_len;
+#pragma unroll 1
+    while (cons + 62 <= avail) {
+      const int off = (int)(cons % (RING_WORDS * 4));
+      int d = off >> 2;
+      uint32_t w[17];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) r[i] = row[i];
-      Fe a = fr::to_mont(chunk_limbs(r, 0));
-      Fe b = fr::to_mont(chunk_limbs(r, 1));
-      s.x = fr::norm(fr::add_lazy(s.x, a));
-      s.y = fr::norm(fr::add_lazy(s.y, b));
-      p2::permute(s, qtab);
-    }
-    if (4 * tile + 2 < total) {
-      uint32_t r[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) r[i] = row[15 + i];   // chunks 2,3 start at bit 496 = dword 15, bit 16
-      // re-base: chunk 2 begins 16 bits into r[0]; chunk_limbs wants bit 248*j from the row start,
-      // so shift the window: treat r as the row starting at dword 15 and use explicit bit offsets.
-      Fe a, b;
-#pragma unroll
-      for (int i = 0; i < fr::NL; ++i) {
-        const int width = (i == fr::NL - 1) ? 16 : 29;
-        {
-          const int bit = 16 + 29 * i, k = bit / 32, sh = bit % 32;
-          uint32_t v = r[k] >> sh;
-          if (sh + width > 32) v |= r[k + 1] << (32 - sh);
-          a.l[i] = v & ((1u << width) - 1);
-        }
-        {
-          const int bit = 16 + 248 + 29 * i, k = bit / 32, sh = bit % 32;
-          uint32_t v = r[k] >> sh;
-          if (sh + width > 32) v |= r[k + 1] << (32 - sh);
-          b.l[i] = v & ((1u << width) - 1);
-        }
+      for (int j = 0; j < 17; ++j) {
+        w[j] = my_row[d];
+        d = (d + 1 == RING_WORDS) ? 0 : d + 1;
       }
+      Fe a, b;
+      if (off & 2) chunk_pair<16>(w, a, b);
+      else chunk_pair<0>(w, a, b);
       a = fr::to_mont(a);
       b = fr::to_mont(b);
       s.x = fr::norm(fr::add_lazy(s.x, a));
       s.y = fr::norm(fr::add_lazy(s.y, b));
       p2::permute(s, qtab);
+      cons += 62;
     }
   }
   if (my_cell < n_cells) store_fe_canonical(out + 2 * my_cell, s.x);
