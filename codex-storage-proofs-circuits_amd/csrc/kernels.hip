@@ -243,35 +243,54 @@ __global__ void __launch_bounds__(TPB, CP2_HASH_WAVES) k_hash_cells(const uint8_
 __global__ void __launch_bounds__(TPB) k_gen_fake_cells(uint64_t seed0, uint64_t cells_per_slot, uint64_t first,
                                                           const uint64_t* __restrict__ list, size_t n_cells,
                                                           size_t cell_size, uint8_t* __restrict__ out) {
+  __shared__ uint4 gen_stage[TPB / 64][64 * 9];
   size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;
-  if (t >= n_cells) return;
-  const uint64_t g = list ? list[t] : first + t;
+  const bool active = t < n_cells;
+  if (!active && ((cell_size & 127) != 0 || (reinterpret_cast<uintptr_t>(out) & 15) != 0)) return;
+  const uint64_t g = active ? (list ? list[t] : first + t) : 0;   // idle tail lanes only take part in the write-out
   const uint64_t slot = cells_per_slot ? g / cells_per_slot : 0;
   const uint64_t idx = cells_per_slot ? g - slot * cells_per_slot : g;
   const uint64_t seed1 = (seed0 + 1001 * slot) + 0xdeadcafeULL;
   const uint64_t seed2 = idx + 0x98765432ULL;
   uint64_t state = 1;
   uint8_t* dst = out + t * cell_size;
-  const bool wide = ((cell_size & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  const bool wide = ((cell_size & 127) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
   if (wide) {
+    // Each lane makes 128 bytes of its cell, parks them in LDS, then the wave writes them out so that 8
+    // consecutive lanes store one cell's full 128-byte line (a lane storing 16 bytes at a 2 KiB stride made
+    // WRITE_SIZE 2.7x the data: partial-line writes).
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint4* my = gen_stage[wave];
+    const size_t wave_cell0 = (size_t)blockIdx.x * TPB + (size_t)wave * 64;
 #pragma unroll 1
-    for (size_t i = 0; i < cell_size; i += 16) {
-      uint32_t w[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < cell_size; i += 128) {
+#pragma unroll 1
+      for (int piece = 0; piece < 8; ++piece) {
+        uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
-      for (int b = 0; b < 16; ++b) {
-        state = state * (state + seed1) * (state + seed2) + state * (state ^ 0x5a5a5a5aULL) + seed1 * state + (seed2 + 17);
-        state = state % 1698428844001831ULL;
-        w[b >> 2] |= (uint32_t)(state & 0xff) << (8 * (b & 3));
+        for (int b = 0; b < 16; ++b) {
+          state = state * (state + seed1) * (state + seed2) + state * (state ^ 0x5a5a5a5aULL) + seed1 * state + (seed2 + 17);
+          state = state % 1698428844001831ULL;
+          w[b >> 2] |= (uint32_t)(state & 0xff) << (8 * (b & 3));
+        }
+        my[lane * 9 + piece] = make_uint4(w[0], w[1], w[2], w[3]);   // row stride 9 x 16 B: conflict-free both ways
       }
-      *reinterpret_cast<uint4*>(dst + i) = make_uint4(w[0], w[1], w[2], w[3]);
+      // wave-private region, in-order LDS pipeline: the reads below see the writes above
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = k * 8 + (lane >> 3), piece = lane & 7;
+        const size_t cell = wave_cell0 + c;
+        uint4 v = my[c * 9 + piece];
+        if (cell < n_cells) *reinterpret_cast<uint4*>(out + cell * cell_size + i + 16 * piece) = v;
+      }
     }
-  } else {
+    return;
+  }
 #pragma unroll 1
-    for (size_t i = 0; i < cell_size; ++i) {
-      state = state * (state + seed1) * (state + seed2) + state * (state ^ 0x5a5a5a5aULL) + seed1 * state + (seed2 + 17);
-      state = state % 1698428844001831ULL;
-      dst[i] = (uint8_t)state;
-    }
+  for (size_t i = 0; i < cell_size; ++i) {
+    state = state * (state + seed1) * (state + seed2) + state * (state ^ 0x5a5a5a5aULL) + seed1 * state + (seed2 + 17);
+    state = state % 1698428844001831ULL;
+    dst[i] = (uint8_t)state;
   }
 }
 
