@@ -90,3 +90,15 @@ def test_shard_ranges_cover_everything(entry):
                 f, c = d.shard_range(n, r, world)
                 got += list(range(f, f + c))
             assert got == list(range(n))
+
+
+def test_header_is_plain_c99_and_links(pkg, tmp_path):
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "check_header")
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-o", exe,
+                           os.path.join(root, "tests", "c_abi", "check_header.c"), "-L" + libdir, "-lcodex_p2",
+                           "-Wl,-rpath," + libdir])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "c abi ok" in r.stdout, (r.returncode, r.stdout, r.stderr)

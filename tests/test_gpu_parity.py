@@ -500,3 +500,25 @@ def test_streaming_ingestion_multi_chunk(pkg, ctx, oracle, tmp_path):
     assert np.array_equal(ds.local_roots(), want)
     fake = ctx.dataset(pkg.make_config(maxDepth=32, maxLog2NSlots=2, cellSize=cs, blockSize=bs, nSlots=ns, nCells=nc, nSamples=3, seed=4711))
     assert ds.proof_input(2, 5).json() == fake.proof_input(2, 5).json()
+
+
+def test_fuzz_sizes_against_oracle(pkg, ctx, oracle):
+    """Randomised shapes (seeded): ragged cell sizes / counts, Merkle sizes, sponge lengths, all bit-exact."""
+    C, P = oracle
+    rng = np.random.default_rng(20261003)
+    for _ in range(40):
+        cs = int(rng.choice([1, 2, 3, 29, 30, 31, 32, 33, 61, 62, 63, 64, 124, 127, 128, 129, 192, 250, 256, 1000, 2048, 3000]))
+        n = int(rng.integers(1, 200))
+        cells = rng.integers(0, 256, size=(n, cs), dtype=np.uint8)
+        assert np.array_equal(ctx.hash_cells(cells, cs), C.hash_cells(cells, cs, threads=8)), (cs, n)
+    for _ in range(25):
+        n = int(rng.integers(1, 600))
+        lv = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)       # non-canonical leaves allowed: taken mod r
+        a, b = ctx.merkle_tree(lv), C.merkle_tree(lv)
+        assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:])), n
+    for _ in range(15):
+        nf, items = int(rng.integers(1, 40)), int(rng.integers(1, 70))
+        f = rng.integers(0, 256, size=(nf * items, 32), dtype=np.uint8)
+        f[:, 31] &= 0x1F
+        want = np.stack([C.sponge2_felts(f[i * nf:(i + 1) * nf]) for i in range(items)])
+        assert np.array_equal(ctx.sponge2_felts_batch(f, nf), want), (nf, items)
