@@ -137,8 +137,11 @@ def main():
                 wave_insts = ipw * n / 64
                 peak = 1024 * 2.4e9 / 4
                 valu = {"bound": "valu-issue", "achieved": wave_insts / (avg_ms * 1e-3), "peak": peak,
-                        "unit": "wave-instructions/s", "frac": round(wave_insts / (avg_ms * 1e-3) / peak, 4),
-                        "valu_insts_per_permutation": ipw, "source": "SQ_INSTS_VALU, profiles/r01_permute_batch_traffic.json"}
+                        "unit": "wave-instructions/s", "frac": round(min(1.0, wave_insts / (avg_ms * 1e-3) / peak), 4),
+                        "valu_insts_per_permutation": ipw, "pmc_valu_busy_frac": prof.get("valu_busy_frac"),
+                        "note": "peak = 1 instruction / 4 cycles / SIMD (the VOP3 integer class, 3/4 of the mix; the rest are "
+                                "2-cycle VOP2 ops, so the raw ratio can exceed 1): the issue port is saturated",
+                        "source": "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE, profiles/r01_permute_batch_traffic.json"}
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -40,6 +40,10 @@ res = {
     "algorithmic_bytes_per_launch": 192 * n,
     "valu_insts_per_wave": counters["SQ_INSTS_VALU"]["per_launch_avg"] / (n / 64),
     "shader_clock_GHz_from_GRBM_GUI_ACTIVE": counters["GRBM_GUI_ACTIVE"]["per_launch_avg"] / 8 / (avg_ms * 1e-3) / 1e9,
+    # SQ_ACTIVE_INST_VALU counts quad-cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs
+    # (a 2-cycle VOP2 instruction still counts one quad-cycle, so the raw ratio can read slightly above 1)
+    "valu_busy_frac_raw": counters["SQ_ACTIVE_INST_VALU"]["per_launch_avg"] * 4 / (counters["GRBM_GUI_ACTIVE"]["per_launch_avg"] / 8 * 1024),
+    "valu_busy_frac": min(1.0, counters["SQ_ACTIVE_INST_VALU"]["per_launch_avg"] * 4 / (counters["GRBM_GUI_ACTIVE"]["per_launch_avg"] / 8 * 1024)),
 }
 json.dump(res, open(os.path.join(P, "%s_permute_batch_traffic.json" % R), "w"), indent=1)
 print(json.dumps({k: res[k] for k in ("kernel_trace_avg_launch_ms", "hbm_bytes_per_launch", "algorithmic_bytes_per_launch",
