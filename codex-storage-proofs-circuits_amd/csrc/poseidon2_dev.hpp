@@ -17,10 +17,12 @@ struct State {
   Fe x, y, z;
 };
 
-// the S-box keeps its output below 1.1 N (top limb < 1.1 * 0x30644f): asserted in the host check build
+// the S-box keeps its output below 1.3 N for inputs below 30 N (top limb < 1.3 * 0x30644f): asserted in the
+// host check build.  (Inputs reach ~24 N in the first external round of a sponge step: state < 4.3 N plus an
+// absorbed element < 2 N per lane, times 4 in the linear layer, plus the round constant.)
 __device__ __forceinline__ Fe sbox_checked(const Fe& x) {
   Fe r = fr::sbox(x);
-  CP2_BOUND(r.l[fr::NL - 1] < 3488548u, "sbox output >= 1.1N");
+  CP2_BOUND(r.l[fr::NL - 1] < 4122830u, "sbox output >= 1.3N");
   return r;
 }
 
