@@ -139,6 +139,10 @@ def main():
                 valu = {"bound": "valu-issue", "achieved": wave_insts / (avg_ms * 1e-3), "peak": peak,
                         "unit": "wave-instructions/s", "frac": round(min(1.0, wave_insts / (avg_ms * 1e-3) / peak), 4),
                         "valu_insts_per_permutation": ipw, "pmc_valu_busy_frac": prof.get("valu_busy_frac"),
+                        # integer multiplies/s over the microbenchmarked peak.  33 120 v_mad_u64_u32 per
+                        # permutation (80 S-boxes x 414); tools/ubench_valu.hip: 4.56 cycles per wave-instruction per SIMD
+                        "mad_u64_u32_per_s": 33120 * n / (avg_ms * 1e-3),
+                        "mad_u64_u32_frac_of_ubench_peak": round(33120 * (n / 64) / (avg_ms * 1e-3) / (1024 * 2.4e9 / 4.56), 4),
                         "note": "peak = 1 instruction / 4 cycles / SIMD (the VOP3 integer class, 3/4 of the mix; the rest are "
                                 "2-cycle VOP2 ops, so the raw ratio can exceed 1): the issue port is saturated",
                         "source": "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE, profiles/r01_permute_batch_traffic.json"}
