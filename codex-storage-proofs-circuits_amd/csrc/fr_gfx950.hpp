@@ -297,11 +297,12 @@ __device__ __forceinline__ void to_canonical_words(const Fe& a, uint32_t (&w)[8]
   Fe one = fe_zero();
   one.l[0] = 1;
   Fe c = mont_mul(a, one);            // (a + m N)/R <= N, limbs 0..7 < U
-  bool is_n = true;
+  uint32_t diff = 0;                  // c == N  <=>  every limb equal (limbs 0..7 < U, so the form is unique)
 #pragma unroll
-  for (int i = 0; i < NL; ++i) is_n = is_n && (c.l[i] == FR_N[i]);
+  for (int i = 0; i < NL; ++i) diff |= c.l[i] ^ FR_N[i];
+  const uint32_t keep = 0u - (uint32_t)(diff != 0);   // and-mask instead of 9 v_cndmask_b32 (~23 cycles each on gfx950)
 #pragma unroll
-  for (int i = 0; i < NL; ++i) c.l[i] = is_n ? 0u : c.l[i];
+  for (int i = 0; i < NL; ++i) c.l[i] &= keep;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int bit = 32 * j, i = bit / 29, s = bit % 29;   // word j starts inside limb i at bit s

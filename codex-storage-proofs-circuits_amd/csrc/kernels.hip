@@ -37,16 +37,15 @@ __device__ __forceinline__ void store_fe_canonical(uint4* p, const Fe& v) {
   p[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
-__device__ __forceinline__ Fe key_fe(uint32_t key) {   // nodeKey, Merkle.hs:162-165, Montgomery form
-  Fe k0 = fr::fe_const(fr::FR_KEY0_MONT), k1 = fr::fe_const(fr::FR_KEY1_MONT);
-  Fe k2 = fr::fe_const(fr::FR_KEY2_MONT), k3 = fr::fe_const(fr::FR_KEY3_MONT);
+// nodeKey (Merkle.hs:162-165) in Montgomery form, lane-varying key in {0,1,2,3}: mont(1)*bit0 + mont(2)*bit1
+// with and-masks (v_cndmask_b32 costs ~23 cycles on gfx950).  The sum for key 3 is a
+// lazy value < 2N with limbs < 2U, inside permute()'s input bounds.
+__device__ __forceinline__ Fe key_fe(uint32_t key) {
+  const Fe k1 = fr::fe_const(fr::FR_KEY1_MONT), k2 = fr::fe_const(fr::FR_KEY2_MONT);
+  const uint32_t m1 = 0u - (key & 1u), m2 = 0u - ((key >> 1) & 1u);
   Fe r;
 #pragma unroll
-  for (int i = 0; i < fr::NL; ++i) {
-    uint32_t lo = (key & 1) ? k1.l[i] : k0.l[i];
-    uint32_t hi = (key & 1) ? k3.l[i] : k2.l[i];
-    r.l[i] = (key & 2) ? hi : lo;
-  }
+  for (int i = 0; i < fr::NL; ++i) r.l[i] = (k1.l[i] & m1) + (k2.l[i] & m2);
   return r;
 }
 
