@@ -525,3 +525,54 @@ def test_fuzz_sizes_against_oracle(pkg, ctx, oracle):
         f[:, 31] &= 0x1F
         want = np.stack([C.sponge2_felts(f[i * nf:(i + 1) * nf]) for i in range(items)])
         assert np.array_equal(ctx.sponge2_felts_batch(f, nf), want), (nf, items)
+
+
+def test_two_contexts_on_two_host_threads(pkg, oracle):
+    """'One context per host thread; contexts are independent' (include/codex_p2.h): two threads, two contexts,
+    interleaved calls, each result equal to the oracle's."""
+    import threading
+    C, _ = oracle
+    rng = np.random.default_rng(77)
+    data = [rng.integers(0, 256, size=(3000, 256), dtype=np.uint8) for _ in range(2)]
+    want = [C.hash_cells(d, 256, threads=4) for d in data]
+    errs = []
+
+    def work(k):
+        try:
+            c = pkg.Context(0)
+            for _ in range(5):
+                if not np.array_equal(c.hash_cells(data[k], 256), want[k]):
+                    errs.append("mismatch in thread %d" % k)
+                lv = want[k][:257]
+                if not np.array_equal(c.merkle_root(lv), C.merkle_root(lv)):
+                    errs.append("merkle mismatch in thread %d" % k)
+            c.close()
+        except Exception as e:   # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+
+
+def test_caller_stream_ordering(pkg, ctx, oracle):
+    """_dev calls enqueue on the caller's stream: work queued by torch before and after is ordered with them."""
+    import torch
+    C, _ = oracle
+    st = torch.cuda.Stream()
+    n = 4096
+    with torch.cuda.stream(st):
+        x = torch.randint(0, 256, (n, 96), dtype=torch.uint8, device="cuda")
+        x[:, 31] &= 0x1F
+        x[:, 63] &= 0x1F
+        x[:, 95] &= 0x1F
+        y = torch.zeros_like(x)
+        ctx.set_stream(st.cuda_stream)
+        ctx.permute_batch_dev(x.data_ptr(), y.data_ptr(), n)
+        z = y.clone()                       # queued on the same stream after the kernel
+    st.synchronize()
+    ctx.reset_stream()
+    assert np.array_equal(z.cpu().numpy(), C.permute_batch(x.cpu().numpy(), threads=4))
