@@ -351,6 +351,37 @@ def test_dataset_errors(pkg, ctx):
         ctx.dataset(pkg.make_config(**dict(c, maxLog2NSlots=3, maxDepth=8))).proof_input(5, 1)   # slot index out of range
 
 
+def expected_proof_input_fast(C, P, c, slot, entropy, threads=16):
+    """The oracle's proof input for a fake-data configuration, with every hash done by the C oracle (fast) and the
+    indexing / merging / padding / JSON by the Python restatement.  Same result as P.generate_proof_input."""
+    cs, bs, nc, ns = c["cellSize"], c["blockSize"], c["nCells"], c["nSlots"]
+    cpb = bs // cs
+    to_int = lambda layers: [C.array_to_felts(l) for l in layers]   # noqa: E731
+    roots = np.stack([C.fake_slot_root(C.slot_seed(c["seed"], s), cs, bs, nc, threads) for s in range(ns)])
+    dset = to_int(C.merkle_tree(roots))
+    cells = C.gen_fake_cells(C.slot_seed(c["seed"], slot), 0, nc, cs)
+    leaves = C.hash_cells(cells, cs, threads=threads)
+    mini = [to_int(C.merkle_tree(leaves[b * cpb:(b + 1) * cpb])) for b in range(nc // cpb)]
+    big = to_int(C.merkle_tree(np.stack([C.felt_bytes(t[-1][0]) for t in mini])))
+    assert big[-1][0] == dset[0][slot]
+    e = C.felt_bytes(entropy)
+    idx = [C.cell_index(e, C.felt_bytes(big[-1][0]), nc, k) for k in range(1, c["nSamples"] + 1)]
+    inputs = []
+    for ci in idx:
+        prf = P.merge_merkle_proofs(P.merkle_proof(mini[ci // cpb], ci % cpb), P.merkle_proof(big, ci // cpb))
+        inputs.append({"cellData": cells[ci].tobytes(), "merkleProof": P.pad_merkle_proof(prf, c["maxDepth"])})
+    return {"dataSetRoot": dset[-1][0], "entropy": entropy, "nCells": nc, "nSlots": ns, "slotIndex": slot,
+            "slotRoot": big[-1][0], "slotProof": P.pad_merkle_proof(P.merkle_proof(dset, slot), c["maxLog2NSlots"]),
+            "proofInputs": inputs, "cellIndices": idx}
+
+
+def test_expected_fast_equals_python_oracle(oracle, golden):
+    """The helper above against the committed fixture (so that it can stand in for the slow Python path)."""
+    C, P = oracle
+    m = golden("proof_inputs.json")["inputs"]["testmain_small"]
+    assert P.export_json(expected_proof_input_fast(C, P, m["config"], m["slotIndex"], m["entropy"], 4)) == golden("input_testmain_small.json")
+
+
 def test_config4_shape_many_slots_batched(pkg, ctx, oracle):
     """Config 4 shape scaled to the test budget: 256 slots x 2^10 cells batched in one build, 100 samples,
     maxDepth 32; three proof inputs are checked against the circuit rules, three slot roots against the oracle."""
@@ -373,6 +404,9 @@ def test_config4_shape_many_slots_batched(pkg, ctx, oracle):
                          for i in range(3)]}
     c3 = dict(c, nSamples=3)
     assert P.circuit_check(p, c3)
+    # byte-exact JSON (100 samples x (67 + 32) field elements) against the oracle for one slot of the batch
+    want = expected_proof_input_fast(C, P, c, 100, 1234567)
+    assert text == P.export_json(want)
 
 
 # ---- host layer: the cli twin and the C++ mirror of the Nim interface ------------------------------------
