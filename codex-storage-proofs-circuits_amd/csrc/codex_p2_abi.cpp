@@ -195,10 +195,15 @@ extern "C" int cp2_hash_cells(cp2_ctx* ctx, const uint8_t* cells, size_t cell_si
   if (n_cells == 0) return CP2_OK;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   DevBuf d_in, d_out;
-  CP2_TRY(d_in.alloc(ctx, std::max<size_t>(cell_size * n_cells, 16)));
   CP2_TRY(d_out.alloc(ctx, n_cells * 32));
-  if (cell_size) CP2_HIP(ctx, hipMemcpyAsync(d_in.p, cells, cell_size * n_cells, hipMemcpyHostToDevice, ctx->stream));
-  CP2_TRY(cp2_hash_cells_dev(ctx, d_in.p, cell_size, n_cells, d_out.p));
+  if (cell_size * n_cells > ((size_t)32 << 20)) {
+    // large inputs stream through the pinned ring (upload and hashing overlapped)
+    CP2_TRY(hash_host_cells_pipelined(ctx, cells, cell_size, n_cells, d_out.u8()));
+  } else {
+    CP2_TRY(d_in.alloc(ctx, std::max<size_t>(cell_size * n_cells, 16)));
+    if (cell_size) CP2_HIP(ctx, hipMemcpyAsync(d_in.p, cells, cell_size * n_cells, hipMemcpyHostToDevice, ctx->stream));
+    CP2_TRY(cp2_hash_cells_dev(ctx, d_in.p, cell_size, n_cells, d_out.p));
+  }
   CP2_HIP(ctx, hipMemcpyAsync(out, d_out.p, n_cells * 32, hipMemcpyDeviceToHost, ctx->stream));
   CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return CP2_OK;

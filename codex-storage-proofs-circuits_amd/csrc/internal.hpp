@@ -78,5 +78,7 @@ inline std::vector<size_t> layer_sizes_of(size_t n) {
 }
 
 int merkle_trees_dev(cp2_ctx* ctx, const void* d_leaves, size_t n, size_t nseg, void* d_layers_out, bool leaves_in_place);
+// hash n host-resident cells into d_leaves (device, n x 32 bytes) through the pinned ingestion pipe
+int hash_host_cells_pipelined(cp2_ctx* ctx, const uint8_t* cells, size_t cell_size, size_t n, uint8_t* d_leaves);
 
 }  // namespace cp2i

@@ -224,6 +224,19 @@ struct IngestPipe {
   }
 };
 
+int cp2i::hash_host_cells_pipelined(cp2_ctx* ctx, const uint8_t* cells, size_t cell_size, size_t n, uint8_t* d_leaves) {
+  IngestPipe pipe;
+  CP2_TRY(pipe.init(ctx, cell_size, n));
+  for (size_t c0 = 0; c0 < n; c0 += pipe.chunk) {
+    size_t m = std::min(pipe.chunk, n - c0);
+    uint8_t* buf = nullptr;
+    CP2_TRY(pipe.acquire(&buf));
+    std::memcpy(buf, cells + c0 * cell_size, m * cell_size);
+    CP2_TRY(pipe.submit(m, cell_size, d_leaves + c0 * 32));
+  }
+  return CP2_OK;   // the pipe's destructor waits for the stream
+}
+
 extern "C" int cp2_slot_trees_build_host(cp2_ctx* ctx, const uint8_t* cells, size_t n_slots, size_t cell_size,
                                          size_t block_size, size_t n_cells, cp2_slot_trees** out) {
   if (!ctx || !out || !cells) return CP2_ERR_INVALID;
@@ -235,21 +248,9 @@ extern "C" int cp2_slot_trees_build_host(cp2_ctx* ctx, const uint8_t* cells, siz
   t->src = CellSrc::Host;
   t->h_cells = cells;
   int st = trees_layout(t);
-  {
-    IngestPipe pipe;
-    const size_t total = n_slots * n_cells;
-    if (st == CP2_OK) st = pipe.init(ctx, cell_size, total);
-    for (size_t c0 = 0; st == CP2_OK && c0 < total; c0 += pipe.chunk) {
-      size_t m = std::min(pipe.chunk, total - c0);
-      uint8_t* buf = nullptr;
-      st = pipe.acquire(&buf);
-      if (st != CP2_OK) break;
-      std::memcpy(buf, cells + c0 * cell_size, m * cell_size);
-      st = pipe.submit(m, cell_size, t->nodes.u8() + c0 * 32);
-    }
-    if (st == CP2_OK) st = trees_build_layers(t);
-    if (st == CP2_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = CP2_ERR_HIP;
-  }
+  if (st == CP2_OK) st = hash_host_cells_pipelined(ctx, cells, cell_size, n_slots * n_cells, t->nodes.u8());
+  if (st == CP2_OK) st = trees_build_layers(t);
+  if (st == CP2_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = CP2_ERR_HIP;
   if (st != CP2_OK) { delete t; return st; }
   *out = t;
   return CP2_OK;

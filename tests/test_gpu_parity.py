@@ -610,3 +610,13 @@ def test_caller_stream_ordering(pkg, ctx, oracle):
     st.synchronize()
     ctx.reset_stream()
     assert np.array_equal(z.cpu().numpy(), C.permute_batch(x.cpu().numpy(), threads=4))
+
+
+def test_hash_cells_large_host_input_is_pipelined(ctx, oracle):
+    """> 32 MiB of host cells goes through the pinned ingestion ring (several chunks); same digests."""
+    C, _ = oracle
+    rng = np.random.default_rng(9)
+    cells = rng.integers(0, 256, size=(70000, 2048), dtype=np.uint8)     # 137 MiB: three ring turns
+    got = ctx.hash_cells(cells, 2048)
+    idx = np.concatenate([np.arange(0, 70000, 997), [32767, 32768, 65535, 65536, 69999]])
+    assert np.array_equal(got[idx], C.hash_cells(cells[idx], 2048, threads=8))
