@@ -258,28 +258,36 @@ def witness_leg(torch, ctx, pkg):
 
 
 def dataset_leg(torch, dist, ctx, pkg, dev, rank, world):
-    """Config 5's exchange step at a small scale: slots sharded over ranks, RCCL all-gather of 32-byte slot
-    roots, dataset tree on every rank; every rank must get the same root."""
+    """Config 5's shape at a scale that finishes in a second: 8 GiB slots (cellSize 2048, nCells 2^22) sharded
+    over the ranks, two per GPU; each rank builds its slot trees with no communication, ONE all-gather of the
+    32-byte slot roots (RCCL over xGMI), the dataset tree on every rank; every rank must get the same root."""
     import importlib
     d = importlib.import_module("codex_storage_proofs_circuits_amd.distributed")
-    n_slots = 64 * world
+    per_rank, n_cells = 2, 1 << 22
+    n_slots = per_rank * world
     cfg = pkg.make_config(maxDepth=32, maxLog2NSlots=max(1, (n_slots - 1).bit_length()), cellSize=2048, blockSize=65536,
-                          nSlots=n_slots, nCells=1 << 12, nSamples=100, seed=12345)
+                          nSlots=n_slots, nCells=n_cells, nSamples=100, seed=12345)
+    ctx.reset_stream()
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
-    root, all_roots, (first, count) = d.dataset_root_sharded(d.HipBackend(pkg, ctx), cfg, rank, world, dist, dev)
+    backend = d.HipBackend(pkg, ctx)
+    root, all_roots, (first, count) = d.dataset_root_sharded(backend, cfg, rank, world, dist, dev)
+    pi = backend.dataset.proof_input(first, 1234567)          # a proof input for one of this rank's own slots
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
+    n_json = len(pi.json())
     r = torch.from_numpy(root.copy()).to(dev)
     rs = [torch.empty_like(r) for _ in range(world)]
     dist.all_gather(rs, r)
     same = all(torch.equal(rs[0], q) for q in rs)
-    perms = n_slots * (35 * (1 << 12) - 1) + n_slots - 1
-    return {"dataset": {"workload": "configs[4] shape scaled: %d slots x 2^12 cells sharded over %d GPUs, RCCL all-gather of slot roots -> dataset root" % (n_slots, world),
+    perms = n_slots * (35 * n_cells - 1) + n_slots - 1
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    return {"dataset": {"workload": "configs[4] shape: %d slots of 8 GiB (2 per GPU) sharded over %d GPUs, one all-gather of slot roots -> "
+                                    "dataset root, one proof input per rank" % (n_slots, world),
                         "seconds": round(dt, 4), "perms_per_s": perms / dt, "all_ranks_agree": bool(same),
-                        "dataset_root_hex": root.tobytes()[::-1].hex()}}
+                        "proof_input_json_bytes": n_json, "dataset_root_hex": root.tobytes()[::-1].hex()}}
 
 
 def cpu_baseline(C, np):
