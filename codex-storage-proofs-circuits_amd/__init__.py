@@ -22,6 +22,14 @@ CP2_OK = 0
 FELT = 32
 
 
+def _finalizing(_is_finalizing=sys.is_finalizing):
+    """True at interpreter shutdown (module globals may already be None there, hence the bound default)."""
+    try:
+        return _is_finalizing()
+    except Exception:
+        return True
+
+
 class CodexP2Error(RuntimeError):
     def __init__(self, status, where, detail=""):
         self.status = status
@@ -187,7 +195,7 @@ class Context:
 
     def __del__(self):
         # at interpreter shutdown the HIP runtime may already be gone: leak rather than call into it
-        if sys.is_finalizing():
+        if _finalizing():
             return
         try:
             self.close()
@@ -360,7 +368,7 @@ class SlotTrees:
             self.h = None
 
     def __del__(self):
-        if sys.is_finalizing():
+        if _finalizing():
             return
         try:
             self.free()
@@ -412,7 +420,7 @@ class Dataset:
             self.h = None
 
     def __del__(self):
-        if sys.is_finalizing():
+        if _finalizing():
             return
         try:
             self.free()
@@ -475,7 +483,7 @@ class ProofInput:
             self.h = None
 
     def __del__(self):
-        if sys.is_finalizing():
+        if _finalizing():
             return
         try:
             self.free()
