@@ -194,10 +194,10 @@ class Context:
             self.h = None
 
     def __del__(self):
-        # at interpreter shutdown the HIP runtime may already be gone: leak rather than call into it
-        if _finalizing():
-            return
+        # at interpreter shutdown the HIP runtime (and this module's globals) may already be gone: leak instead
         try:
+            if _finalizing():
+                return
             self.close()
         except Exception:
             pass
@@ -368,9 +368,9 @@ class SlotTrees:
             self.h = None
 
     def __del__(self):
-        if _finalizing():
-            return
         try:
+            if _finalizing():
+                return
             self.free()
         except Exception:
             pass
@@ -420,9 +420,9 @@ class Dataset:
             self.h = None
 
     def __del__(self):
-        if _finalizing():
-            return
         try:
+            if _finalizing():
+                return
             self.free()
         except Exception:
             pass
@@ -483,9 +483,9 @@ class ProofInput:
             self.h = None
 
     def __del__(self):
-        if _finalizing():
-            return
         try:
+            if _finalizing():
+                return
             self.free()
         except Exception:
             pass
