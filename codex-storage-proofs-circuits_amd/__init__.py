@@ -125,6 +125,7 @@ def load_library():
         "cp2_proof_input_generate": (i32, [vp, u64, vp, pvp]),
         "cp2_proof_inputs_generate_batch": (i32, [vp, vp, sz, vp, pvp]),
         "cp2_proof_inputs_write_json_batch": (i32, [pvp, sz, ctypes.POINTER(cp), i32, ctypes.POINTER(u64)]),
+        "cp2_dataset_export_proof_inputs": (i32, [vp, vp, sz, vp, cp, i32, sz, ctypes.POINTER(u64)]),
         "cp2_proof_input_free": (None, [vp]),
         "cp2_proof_input_roots": (i32, [vp, vp, vp, vp]),
         "cp2_proof_input_nsamples": (sz, [vp]),
@@ -451,6 +452,15 @@ class Dataset:
         self.ctx._ck(self.ctx.L.cp2_proof_input_generate(self.h, slot_idx, _p(e), ctypes.byref(h)), "cp2_proof_input_generate")
         return ProofInput(self.ctx, h, self.cfg)
 
+
+    def export_proof_inputs(self, slot_indices, entropy, directory=None, threads=1, batch=0):
+        """Pipelined generate + serialise (+ write "<directory>/input_<slot>.json"); returns the total text bytes."""
+        e = _u8(entropy if not isinstance(entropy, int) else felt_bytes(entropy))
+        idx = np.ascontiguousarray(np.asarray(slot_indices, dtype=np.uint64))
+        total = ctypes.c_uint64()
+        self.ctx._ck(self.ctx.L.cp2_dataset_export_proof_inputs(self.h, _p(idx), idx.size, _p(e), directory.encode() if directory else None,
+                                                                threads, batch, ctypes.byref(total)), "cp2_dataset_export_proof_inputs")
+        return total.value
 
     def proof_inputs(self, slot_indices, entropy):
         """Batched generateProofInput for many slots of this dataset (one sampling / gather / fetch)."""

@@ -899,6 +899,53 @@ extern "C" int cp2_proof_inputs_write_json_batch(const cp2_proof_input* const* p
   return CP2_OK;
 }
 
+// Proof inputs for many slots, generated and serialised as a two-stage pipeline: while the host threads turn
+// batch k into JSON text (and write it when dir != NULL: "<dir>/input_<slot>.json"), the GPU already samples and
+// gathers batch k+1.  Config 4's metric (witnesses/s) is this call after cp2_dataset_build.
+extern "C" int cp2_dataset_export_proof_inputs(cp2_dataset* ds, const uint64_t* slot_idx, size_t n, const uint8_t entropy[32],
+                                               const char* dir, int threads, size_t batch, uint64_t* total_bytes) {
+  if (!ds || !entropy || (n && !slot_idx)) return CP2_ERR_INVALID;
+  if (batch == 0) batch = 512;
+  if (threads < 1) threads = 1;
+  uint64_t bytes = 0;
+  int status = CP2_OK;
+  std::vector<cp2_proof_input*> cur, next;
+  auto generate = [&](size_t b0, std::vector<cp2_proof_input*>& out) -> int {
+    size_t m = std::min(batch, n - b0);
+    out.assign(m, nullptr);
+    return cp2_proof_inputs_generate_batch(ds, slot_idx + b0, m, entropy, out.data());
+  };
+  auto release = [](std::vector<cp2_proof_input*>& v) {
+    for (auto* p : v) delete p;
+    v.clear();
+  };
+  if (n) status = generate(0, cur);
+  for (size_t b0 = 0; status == CP2_OK && b0 < n; b0 += batch) {
+    const size_t b1 = b0 + batch;
+    int gen_status = CP2_OK;
+    std::thread producer;                                   // GPU stage of the NEXT batch
+    if (b1 < n) producer = std::thread([&] { gen_status = generate(b1, next); });
+    std::vector<std::string> names;                          // host stage of THIS batch
+    std::vector<const char*> paths;
+    if (dir) {
+      for (size_t i = 0; i < cur.size(); ++i) names.push_back(std::string(dir) + "/input_" + std::to_string(slot_idx[b0 + i]) + ".json");
+      for (auto& s2 : names) paths.push_back(s2.c_str());
+    }
+    uint64_t got = 0;
+    int st = cp2_proof_inputs_write_json_batch(cur.data(), cur.size(), dir ? paths.data() : nullptr, threads, &got);
+    bytes += got;
+    if (producer.joinable()) producer.join();
+    release(cur);
+    if (st != CP2_OK) status = st;
+    else if (gen_status != CP2_OK) status = gen_status;
+    cur.swap(next);
+  }
+  release(cur);
+  release(next);
+  if (total_bytes) *total_bytes = bytes;
+  return status;
+}
+
 extern "C" void cp2_free_buffer(void* p) { std::free(p); }
 
 extern "C" int cp2_proof_input_write_json(const cp2_proof_input* p, const char* path) {

@@ -209,6 +209,10 @@ void cp2_free_buffer(void* p);
  * serialise only).  total_bytes (may be NULL) receives the summed text length. */
 int cp2_proof_inputs_write_json_batch(const cp2_proof_input* const* ps, size_t n, const char* const* paths, int threads,
                                       uint64_t* total_bytes);
+/* All of it for many slots as a two-stage pipeline (GPU: sampling + gathers of batch k+1; host threads: JSON of
+ * batch k).  dir == NULL: serialise only; else "<dir>/input_<slot>.json" is written per slot.  batch == 0: 512. */
+int cp2_dataset_export_proof_inputs(cp2_dataset* ds, const uint64_t* slot_idx, size_t n, const uint8_t entropy[32],
+                                    const char* dir, int threads, size_t batch, uint64_t* total_bytes);
 /* replaces `writeCircomMainComponent`, reference/nim/proof_input/src/cli.nim:186-204 */
 int cp2_write_circom_main(const cp2_config* cfg, const char* path);
 

@@ -620,3 +620,17 @@ def test_hash_cells_large_host_input_is_pipelined(ctx, oracle):
     got = ctx.hash_cells(cells, 2048)
     idx = np.concatenate([np.arange(0, 70000, 997), [32767, 32768, 65535, 65536, 69999]])
     assert np.array_equal(got[idx], C.hash_cells(cells[idx], 2048, threads=8))
+
+
+def test_pipelined_export_writes_identical_files(pkg, ctx, golden, tmp_path):
+    m = golden("proof_inputs.json")["inputs"]["testmain_small"]
+    ds = ctx.dataset(pkg.make_config(**m["config"]))
+    slots = [0, 1, 2, 3, 4, 3, 1]
+    single = {s: ds.proof_input(s, m["entropy"]).json() for s in set(slots)}
+    total = ds.export_proof_inputs(slots, m["entropy"], str(tmp_path), threads=3, batch=2)      # 4 batches
+    assert total == sum(len(single[s]) for s in slots)
+    for s in set(slots):
+        assert open(tmp_path / ("input_%d.json" % s)).read() == single[s]
+    assert single[3] == golden("input_testmain_small.json")
+    assert ds.export_proof_inputs(slots, m["entropy"], None, threads=2, batch=0) == total
+    assert ds.export_proof_inputs([], m["entropy"]) == 0
