@@ -96,6 +96,48 @@ KERNEL64(k_mul_f64,      "v_mul_f64 %0, %3, %0")
 KERNEL64(k_add_f64,      "v_add_f64 %0, %3, %0")
 KERNEL64(k_pk_fma_f32,   "v_pk_fma_f32 %0, %3, %3, %0")
 
+// v_mad_u64_u32 operand-form variants: SGPR multiplicand, non-VCC carry-out pair, zero addend
+__global__ void __launch_bounds__(256) k_mad_sgpr(unsigned* out, unsigned long long* cyc, unsigned a, unsigned b) {
+  unsigned long long r[8]; unsigned x = a + threadIdx.x;
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) r[i] = (unsigned long long)x * (i + 1) + b;
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < ITER / 4; ++it) {
+    _Pragma("unroll") for (int u = 0; u < 4; ++u)
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)
+      asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r[i]) : "v"(x), "s"(b) : "vcc");
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  unsigned long long s = 0; _Pragma("unroll") for (int i = 0; i < 8; ++i) s ^= r[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)(s ^ (s >> 32));
+  if (threadIdx.x % 64 == 0) cyc[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
+}
+__global__ void __launch_bounds__(256) k_mad_sdst(unsigned* out, unsigned long long* cyc, unsigned a, unsigned b) {
+  unsigned long long r[8]; unsigned x = a + threadIdx.x, y = b ^ threadIdx.x;
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) r[i] = (unsigned long long)x * (i + 1) + y;
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < ITER / 4; ++it) {
+    _Pragma("unroll") for (int u = 0; u < 4; ++u)
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)
+      asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(r[i]) : "v"(x), "v"(y) : "s20", "s21");
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  unsigned long long s = 0; _Pragma("unroll") for (int i = 0; i < 8; ++i) s ^= r[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)(s ^ (s >> 32));
+  if (threadIdx.x % 64 == 0) cyc[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
+}
+__global__ void __launch_bounds__(256) k_mad_chain(unsigned* out, unsigned long long* cyc, unsigned a, unsigned b) {
+  // ONE dependent chain per wave (what the tie-ordered multiplier looks like): latency-bound unless enough waves
+  unsigned long long r = a; unsigned x = a + threadIdx.x, y = b ^ threadIdx.x;
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < ITER / 4; ++it) {
+    _Pragma("unroll") for (int u = 0; u < 32; ++u)
+      asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r) : "v"(x), "v"(y) : "vcc");
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)(r ^ (r >> 32));
+  if (threadIdx.x % 64 == 0) cyc[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
+}
+
 struct Entry { const char* name; void (*fn)(unsigned*, unsigned long long*, unsigned, unsigned); int instr_per_slot; };
 
 int main(int argc, char** argv) {
@@ -114,7 +156,7 @@ int main(int argc, char** argv) {
     {"v_alignbit_b32", k_alignbit, 1}, {"v_lshl_or_b32", k_lshl_or, 1}, {"v_and_or_b32", k_and_or, 1},
     {"v_xad_u32", k_xad, 1},
     {"v_mad_u64_u32", k_mad_u64_u32, 1}, {"v_mad_i64_i32", k_mad_i64_i32, 1},
-    {"v_lshl_add_u64", k_lshl_add_u64, 1}, {"v_fma_f64", k_fma_f64, 1}, {"v_mul_f64", k_mul_f64, 1},
+    {"v_mad_u64 sgpr src", k_mad_sgpr, 1}, {"v_mad_u64 s[20:21]", k_mad_sdst, 1}, {"v_mad_u64 1 chain", k_mad_chain, 1}, {"v_lshl_add_u64", k_lshl_add_u64, 1}, {"v_fma_f64", k_fma_f64, 1}, {"v_mul_f64", k_mul_f64, 1},
     {"v_add_f64", k_add_f64, 1}, {"v_pk_fma_f32", k_pk_fma_f32, 1},
   };
   unsigned* out; CK(hipMalloc(&out, (size_t)cus * 8 * 256 * sizeof(unsigned)));
