@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -19,7 +20,7 @@ using namespace cp2i;
 // ---------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------
-extern "C" int cp2_init(int device, cp2_ctx** out) {
+extern "C" int cp2_init(int device, cp2_ctx** out) try {
   if (!out) return CP2_ERR_INVALID;
   *out = nullptr;
   int count = 0;
@@ -42,6 +43,10 @@ extern "C" int cp2_init(int device, cp2_ctx** out) {
   c->stream = c->own_stream;
   *out = c;
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 extern "C" void cp2_free(cp2_ctx* ctx) {
@@ -52,22 +57,34 @@ extern "C" void cp2_free(cp2_ctx* ctx) {
   delete ctx;
 }
 
-extern "C" int cp2_set_stream(cp2_ctx* ctx, void* hip_stream) {
+extern "C" int cp2_set_stream(cp2_ctx* ctx, void* hip_stream) try {
   if (!ctx) return CP2_ERR_INVALID;
   ctx->stream = (hipStream_t)hip_stream;
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
-extern "C" int cp2_reset_stream(cp2_ctx* ctx) {
+extern "C" int cp2_reset_stream(cp2_ctx* ctx) try {
   if (!ctx) return CP2_ERR_INVALID;
   ctx->stream = ctx->own_stream;
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
-extern "C" int cp2_sync(cp2_ctx* ctx) {
+extern "C" int cp2_sync(cp2_ctx* ctx) try {
   if (!ctx) return CP2_ERR_INVALID;
   CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 extern "C" const char* cp2_strerror(int status) {
@@ -91,15 +108,19 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // ---------------------------------------------------------------------------------------------
 // a1 permutation
 // ---------------------------------------------------------------------------------------------
-extern "C" int cp2_permute_batch_dev(cp2_ctx* ctx, const void* d_in, void* d_out, size_t n) {
+extern "C" int cp2_permute_batch_dev(cp2_ctx* ctx, const void* d_in, void* d_out, size_t n) try {
   if (!ctx || (n && (!d_in || !d_out))) return CP2_ERR_INVALID;
   if (!aligned16(d_in) || !aligned16(d_out)) return CP2_ERR_ALIGN;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   CP2_HIP(ctx, cp2k::launch_permute_batch(d_in, d_out, n, ctx->stream));
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
-extern "C" int cp2_permute_batch(cp2_ctx* ctx, const uint8_t* in, uint8_t* out, size_t n) {
+extern "C" int cp2_permute_batch(cp2_ctx* ctx, const uint8_t* in, uint8_t* out, size_t n) try {
   if (!ctx || (n && (!in || !out))) return CP2_ERR_INVALID;
   if (n == 0) return CP2_OK;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
@@ -111,12 +132,16 @@ extern "C" int cp2_permute_batch(cp2_ctx* ctx, const uint8_t* in, uint8_t* out, 
   CP2_HIP(ctx, hipMemcpyAsync(out, d_out.p, n * 96, hipMemcpyDeviceToHost, ctx->stream));
   CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 // ---------------------------------------------------------------------------------------------
 // a6 keyed compression
 // ---------------------------------------------------------------------------------------------
-extern "C" int cp2_compress_batch(cp2_ctx* ctx, const uint8_t* xy, uint32_t key, uint8_t* out, size_t n) {
+extern "C" int cp2_compress_batch(cp2_ctx* ctx, const uint8_t* xy, uint32_t key, uint8_t* out, size_t n) try {
   if (!ctx || key > 3 || (n && (!xy || !out))) return CP2_ERR_INVALID;
   if (n == 0) return CP2_OK;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
@@ -129,20 +154,28 @@ extern "C" int cp2_compress_batch(cp2_ctx* ctx, const uint8_t* xy, uint32_t key,
   CP2_TRY(cp2_permute_batch(ctx, st.data(), res.data(), n));
   for (size_t i = 0; i < n; ++i) std::memcpy(out + 32 * i, &res[96 * i], 32);
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 // ---------------------------------------------------------------------------------------------
 // a3 sponge over field elements
 // ---------------------------------------------------------------------------------------------
-extern "C" int cp2_sponge2_felts_batch_dev(cp2_ctx* ctx, const void* d_felts, size_t nf, size_t nitems, void* d_out) {
+extern "C" int cp2_sponge2_felts_batch_dev(cp2_ctx* ctx, const void* d_felts, size_t nf, size_t nitems, void* d_out) try {
   if (!ctx || (nitems && (!d_out || (nf && !d_felts)))) return CP2_ERR_INVALID;
   if (!aligned16(d_felts) || !aligned16(d_out)) return CP2_ERR_ALIGN;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   CP2_HIP(ctx, cp2k::launch_sponge2_felts(d_felts, nf, nitems, d_out, ctx->stream));
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
-extern "C" int cp2_sponge2_felts_batch(cp2_ctx* ctx, const uint8_t* felts, size_t nf, size_t nitems, uint8_t* out) {
+extern "C" int cp2_sponge2_felts_batch(cp2_ctx* ctx, const uint8_t* felts, size_t nf, size_t nitems, uint8_t* out) try {
   if (!ctx || (nitems && (!out || (nf && !felts)))) return CP2_ERR_INVALID;
   if (nitems == 0) return CP2_OK;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
@@ -154,10 +187,18 @@ extern "C" int cp2_sponge2_felts_batch(cp2_ctx* ctx, const uint8_t* felts, size_
   CP2_HIP(ctx, hipMemcpyAsync(out, d_out.p, nitems * 32, hipMemcpyDeviceToHost, ctx->stream));
   CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
-extern "C" int cp2_sponge2_felts(cp2_ctx* ctx, const uint8_t* felts, size_t n, uint8_t out[32]) {
+extern "C" int cp2_sponge2_felts(cp2_ctx* ctx, const uint8_t* felts, size_t n, uint8_t out[32]) try {
   return cp2_sponge2_felts_batch(ctx, felts, n, 1, out);
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -165,7 +206,7 @@ extern "C" int cp2_sponge2_felts(cp2_ctx* ctx, const uint8_t* felts, size_t n, u
 // ---------------------------------------------------------------------------------------------
 extern "C" size_t cp2_felts_per_bytes(size_t len) { return (len + 1 + 30) / 31; }
 
-extern "C" int cp2_bytes_to_felts(const uint8_t* data, size_t len, uint8_t* out) {
+extern "C" int cp2_bytes_to_felts(const uint8_t* data, size_t len, uint8_t* out) try {
   if ((len && !data) || !out) return CP2_ERR_INVALID;
   size_t n = cp2_felts_per_bytes(len);
   std::memset(out, 0, n * 32);
@@ -177,20 +218,28 @@ extern "C" int cp2_bytes_to_felts(const uint8_t* data, size_t len, uint8_t* out)
     }
   }
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 // ---------------------------------------------------------------------------------------------
 // a5 hashCell
 // ---------------------------------------------------------------------------------------------
-extern "C" int cp2_hash_cells_dev(cp2_ctx* ctx, const void* d_cells, size_t cell_size, size_t n_cells, void* d_out) {
+extern "C" int cp2_hash_cells_dev(cp2_ctx* ctx, const void* d_cells, size_t cell_size, size_t n_cells, void* d_out) try {
   if (!ctx || (n_cells && (!d_out || (cell_size && !d_cells)))) return CP2_ERR_INVALID;
   if (!aligned16(d_out)) return CP2_ERR_ALIGN;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   CP2_HIP(ctx, cp2k::launch_hash_cells(d_cells, cell_size, n_cells, d_out, ctx->stream));
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
-extern "C" int cp2_hash_cells(cp2_ctx* ctx, const uint8_t* cells, size_t cell_size, size_t n_cells, uint8_t* out) {
+extern "C" int cp2_hash_cells(cp2_ctx* ctx, const uint8_t* cells, size_t cell_size, size_t n_cells, uint8_t* out) try {
   if (!ctx || (n_cells && (!out || (cell_size && !cells)))) return CP2_ERR_INVALID;
   if (n_cells == 0) return CP2_OK;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
@@ -207,10 +256,18 @@ extern "C" int cp2_hash_cells(cp2_ctx* ctx, const uint8_t* cells, size_t cell_si
   CP2_HIP(ctx, hipMemcpyAsync(out, d_out.p, n_cells * 32, hipMemcpyDeviceToHost, ctx->stream));
   CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
-extern "C" int cp2_hash_bytes(cp2_ctx* ctx, const uint8_t* data, size_t len, uint8_t out[32]) {
+extern "C" int cp2_hash_bytes(cp2_ctx* ctx, const uint8_t* data, size_t len, uint8_t out[32]) try {
   return cp2_hash_cells(ctx, data, len, 1, out);
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -242,16 +299,20 @@ int cp2i::merkle_trees_dev(cp2_ctx* ctx, const void* d_leaves, size_t n, size_t 
   return CP2_OK;
 }
 
-extern "C" int cp2_merkle_trees_dev(cp2_ctx* ctx, const void* d_leaves, size_t n, size_t nseg, void* d_layers_out) {
+extern "C" int cp2_merkle_trees_dev(cp2_ctx* ctx, const void* d_leaves, size_t n, size_t nseg, void* d_layers_out) try {
   if (!ctx || !d_leaves || !d_layers_out) return CP2_ERR_INVALID;
   if (!aligned16(d_leaves) || !aligned16(d_layers_out)) return CP2_ERR_ALIGN;
   if (n == 0) return CP2_ERR_INVALID;   // Merkle.hs:72 "input is empty"
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   return merkle_trees_dev(ctx, d_leaves, n, nseg, d_layers_out, d_leaves == d_layers_out);
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 extern "C" int cp2_merkle_tree(cp2_ctx* ctx, const uint8_t* leaves, size_t n, uint8_t* layers_out, size_t* layer_sizes,
-                               size_t* n_layers) {
+                               size_t* n_layers) try {
   if (!ctx || !leaves || !layers_out || n == 0) return CP2_ERR_INVALID;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   std::vector<size_t> sizes = layer_sizes_of(n);
@@ -265,15 +326,23 @@ extern "C" int cp2_merkle_tree(cp2_ctx* ctx, const uint8_t* leaves, size_t n, ui
   if (layer_sizes) std::copy(sizes.begin(), sizes.end(), layer_sizes);
   if (n_layers) *n_layers = sizes.size();
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
-extern "C" int cp2_merkle_root(cp2_ctx* ctx, const uint8_t* leaves, size_t n, uint8_t out[32]) {
+extern "C" int cp2_merkle_root(cp2_ctx* ctx, const uint8_t* leaves, size_t n, uint8_t out[32]) try {
   if (!ctx || !leaves || !out || n == 0) return CP2_ERR_INVALID;
   size_t total = cp2_merkle_total(n);
   std::vector<uint8_t> layers(total * 32);
   CP2_TRY(cp2_merkle_tree(ctx, leaves, n, layers.data(), nullptr, nullptr));
   std::memcpy(out, &layers[(total - 1) * 32], 32);
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -281,14 +350,18 @@ extern "C" int cp2_merkle_root(cp2_ctx* ctx, const uint8_t* leaves, size_t n, ui
 // ---------------------------------------------------------------------------------------------
 extern "C" uint64_t cp2_slot_seed(uint64_t dataset_seed, uint64_t slot_idx) { return dataset_seed + 72 + 1001 * slot_idx; }
 
-extern "C" int cp2_gen_fake_cells_dev(cp2_ctx* ctx, uint64_t seed, uint64_t first, size_t n, size_t cell_size, void* d_out) {
+extern "C" int cp2_gen_fake_cells_dev(cp2_ctx* ctx, uint64_t seed, uint64_t first, size_t n, size_t cell_size, void* d_out) try {
   if (!ctx || (n && cell_size && !d_out)) return CP2_ERR_INVALID;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   CP2_HIP(ctx, cp2k::launch_gen_fake_cells(seed, 0, first, nullptr, n, cell_size, d_out, ctx->stream));
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
-extern "C" int cp2_gen_fake_cells(cp2_ctx* ctx, uint64_t seed, uint64_t first, size_t n, size_t cell_size, uint8_t* out) {
+extern "C" int cp2_gen_fake_cells(cp2_ctx* ctx, uint64_t seed, uint64_t first, size_t n, size_t cell_size, uint8_t* out) try {
   if (!ctx || (n && cell_size && !out)) return CP2_ERR_INVALID;
   if (n == 0 || cell_size == 0) return CP2_OK;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
@@ -298,13 +371,17 @@ extern "C" int cp2_gen_fake_cells(cp2_ctx* ctx, uint64_t seed, uint64_t first, s
   CP2_HIP(ctx, hipMemcpyAsync(out, d.p, n * cell_size, hipMemcpyDeviceToHost, ctx->stream));
   CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 // ---------------------------------------------------------------------------------------------
 // a12 sampling
 // ---------------------------------------------------------------------------------------------
 extern "C" int cp2_cell_indices(cp2_ctx* ctx, const uint8_t entropy[32], const uint8_t slot_root[32], uint64_t n_cells,
-                                size_t n_samples, uint64_t* out) {
+                                size_t n_samples, uint64_t* out) try {
   if (!ctx || !entropy || !slot_root || (n_samples && !out)) return CP2_ERR_INVALID;
   if (n_cells == 0 || (n_cells & (n_cells - 1)) != 0) return CP2_ERR_INVALID;   // sample/bn254.nim:19-20
   if (n_samples == 0) return CP2_OK;
@@ -322,4 +399,8 @@ extern "C" int cp2_cell_indices(cp2_ctx* ctx, const uint8_t entropy[32], const u
     out[i] = lo & (n_cells - 1);
   }
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -115,7 +116,7 @@ static int trees_build_layers(cp2_slot_trees* t) {
 }
 
 extern "C" int cp2_slot_trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_slot, size_t n_slots,
-                                         size_t cell_size, size_t block_size, size_t n_cells, cp2_slot_trees** out) {
+                                         size_t cell_size, size_t block_size, size_t n_cells, cp2_slot_trees** out) try {
   if (!ctx || !out) return CP2_ERR_INVALID;
   *out = nullptr;
   CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
@@ -144,10 +145,14 @@ extern "C" int cp2_slot_trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, ui
   if (st != CP2_OK) { delete t; return st; }
   *out = t;
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 extern "C" int cp2_slot_trees_build_dev(cp2_ctx* ctx, const void* d_cells, size_t n_slots, size_t cell_size,
-                                        size_t block_size, size_t n_cells, cp2_slot_trees** out) {
+                                        size_t block_size, size_t n_cells, cp2_slot_trees** out) try {
   if (!ctx || !out || !d_cells) return CP2_ERR_INVALID;
   *out = nullptr;
   CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
@@ -165,6 +170,10 @@ extern "C" int cp2_slot_trees_build_dev(cp2_ctx* ctx, const void* d_cells, size_
   if (st != CP2_OK) { delete t; return st; }
   *out = t;   // asynchronous: the caller syncs (cp2_sync) or reads roots (which syncs)
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 // ---- streaming ingestion ----------------------------------------------------
@@ -238,7 +247,7 @@ int cp2i::hash_host_cells_pipelined(cp2_ctx* ctx, const uint8_t* cells, size_t c
 }
 
 extern "C" int cp2_slot_trees_build_host(cp2_ctx* ctx, const uint8_t* cells, size_t n_slots, size_t cell_size,
-                                         size_t block_size, size_t n_cells, cp2_slot_trees** out) {
+                                         size_t block_size, size_t n_cells, cp2_slot_trees** out) try {
   if (!ctx || !out || !cells) return CP2_ERR_INVALID;
   *out = nullptr;
   CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
@@ -254,6 +263,10 @@ extern "C" int cp2_slot_trees_build_host(cp2_ctx* ctx, const uint8_t* cells, siz
   if (st != CP2_OK) { delete t; return st; }
   *out = t;
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 // slot files "<base><k>.dat" (dataset.nim:34) streamed through the ingestion pipe; short files read as zeros
@@ -309,7 +322,7 @@ struct TreeFileHeader {
 };
 }  // namespace
 
-extern "C" int cp2_slot_trees_save(cp2_slot_trees* t, const char* path) {
+extern "C" int cp2_slot_trees_save(cp2_slot_trees* t, const char* path) try {
   if (!t || !path) return CP2_ERR_INVALID;
   cp2_ctx* ctx = t->ctx;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
@@ -329,9 +342,13 @@ extern "C" int cp2_slot_trees_save(cp2_slot_trees* t, const char* path) {
             std::fwrite(host.data(), 1, host.size(), f) == host.size();
   ok = (std::fclose(f) == 0) && ok;
   return ok ? CP2_OK : CP2_ERR_IO;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
-extern "C" int cp2_slot_trees_load(cp2_ctx* ctx, const char* path, cp2_slot_trees** out) {
+extern "C" int cp2_slot_trees_load(cp2_ctx* ctx, const char* path, cp2_slot_trees** out) try {
   if (!ctx || !path || !out) return CP2_ERR_INVALID;
   *out = nullptr;
   FILE* f = std::fopen(path, "rb");
@@ -367,15 +384,23 @@ extern "C" int cp2_slot_trees_load(cp2_ctx* ctx, const char* path, cp2_slot_tree
   if (st != CP2_OK) { delete t; return st; }
   *out = t;
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 // trees loaded from a cache that were built from caller memory have no cell source until one is attached
-extern "C" int cp2_slot_trees_attach_cells(cp2_slot_trees* t, const uint8_t* host_cells, const void* dev_cells) {
+extern "C" int cp2_slot_trees_attach_cells(cp2_slot_trees* t, const uint8_t* host_cells, const void* dev_cells) try {
   if (!t || (host_cells && dev_cells)) return CP2_ERR_INVALID;
   if (host_cells) { t->src = CellSrc::Host; t->h_cells = host_cells; t->d_cells = nullptr; }
   else if (dev_cells) { t->src = CellSrc::Dev; t->d_cells = static_cast<const uint8_t*>(dev_cells); t->h_cells = nullptr; }
   else return CP2_ERR_INVALID;
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 extern "C" void cp2_slot_trees_free(cp2_slot_trees* t) {
@@ -394,13 +419,17 @@ extern "C" const void* cp2_slot_trees_roots_dev(const cp2_slot_trees* t) {
   return t ? t->nodes.u8() + t->toff.back() * 32 : nullptr;
 }
 
-extern "C" int cp2_slot_trees_roots(cp2_slot_trees* t, uint8_t* out) {
+extern "C" int cp2_slot_trees_roots(cp2_slot_trees* t, uint8_t* out) try {
   if (!t || !out) return CP2_ERR_INVALID;
   cp2_ctx* ctx = t->ctx;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   CP2_HIP(ctx, hipMemcpyAsync(out, cp2_slot_trees_roots_dev(t), t->n_slots * 32, hipMemcpyDeviceToHost, ctx->stream));
   CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 // node-row indices of the merged path of `cell` in slot `slot` (merkle.nim:21-42 twice, then :86-100)
@@ -425,7 +454,7 @@ static void path_rows(const cp2_slot_trees* t, size_t slot, uint64_t cell, size_
 }
 
 extern "C" int cp2_slot_trees_paths(cp2_slot_trees* t, size_t slot, const uint64_t* cell_idx, size_t n, size_t max_depth,
-                                    uint8_t* out, uint8_t* leaf_hashes) {
+                                    uint8_t* out, uint8_t* leaf_hashes) try {
   if (!t || (n && (!cell_idx || !out)) || slot >= t->n_slots) return CP2_ERR_INVALID;
   if (cp2_slot_trees_depth(t) > max_depth) return CP2_ERR_INVALID;     // types.nim:29 assert(pad >= 0)
   if (n == 0) return CP2_OK;
@@ -451,6 +480,10 @@ extern "C" int cp2_slot_trees_paths(cp2_slot_trees* t, size_t slot, const uint64
     if (leaf_hashes) std::memcpy(leaf_hashes + i * 32, &tmp[(i * per + max_depth) * 32], 32);
   }
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 // the bytes of n cells given by global index g = local_slot * n_cells + cell (slotLoadCellData, slot.nim:57-68)
@@ -521,7 +554,7 @@ struct cp2_dataset {
 };
 
 extern "C" int cp2_dataset_build(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local,
-                                 cp2_dataset** out) {
+                                 cp2_dataset** out) try {
   if (!ctx || !cfg || !out) return CP2_ERR_INVALID;
   *out = nullptr;
   if (n_local == 0 || first_slot + n_local > cfg->n_slots) return CP2_ERR_INVALID;
@@ -543,12 +576,16 @@ extern "C" int cp2_dataset_build(cp2_ctx* ctx, const cp2_config* cfg, uint64_t f
   if (st != CP2_OK) { delete ds; return st; }
   *out = ds;
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 // Same as cp2_dataset_build, but the slot trees are read from `cache_path` when that file exists and matches
 // the configuration, and written there after a build otherwise.
 extern "C" int cp2_dataset_build_cached(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local,
-                                        const char* cache_path, cp2_dataset** out) {
+                                        const char* cache_path, cp2_dataset** out) try {
   if (!ctx || !cfg || !out || !cache_path) return CP2_ERR_INVALID;
   *out = nullptr;
   if (n_local == 0 || first_slot + n_local > cfg->n_slots) return CP2_ERR_INVALID;
@@ -579,6 +616,10 @@ extern "C" int cp2_dataset_build_cached(cp2_ctx* ctx, const cp2_config* cfg, uin
   int st = cp2_slot_trees_save((*out)->trees, cache_path);
   if (st != CP2_OK) { cp2_dataset_free(*out); *out = nullptr; }
   return st;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 extern "C" void cp2_dataset_free(cp2_dataset* ds) {
@@ -587,12 +628,16 @@ extern "C" void cp2_dataset_free(cp2_dataset* ds) {
   delete ds;
 }
 
-extern "C" int cp2_dataset_local_roots(cp2_dataset* ds, uint8_t* out) {
+extern "C" int cp2_dataset_local_roots(cp2_dataset* ds, uint8_t* out) try {
   if (!ds || !out) return CP2_ERR_INVALID;
   return cp2_slot_trees_roots(ds->trees, out);
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
-extern "C" int cp2_dataset_set_roots(cp2_dataset* ds, const uint8_t* all_roots) {
+extern "C" int cp2_dataset_set_roots(cp2_dataset* ds, const uint8_t* all_roots) try {
   if (!ds) return CP2_ERR_INVALID;
   cp2_ctx* ctx = ds->ctx;
   const size_t n = ds->cfg.n_slots;
@@ -610,13 +655,21 @@ extern "C" int cp2_dataset_set_roots(cp2_dataset* ds, const uint8_t* all_roots) 
   CP2_TRY(cp2_merkle_tree(ctx, roots.data(), n, ds->dlayers.data(), nullptr, nullptr));
   ds->have_roots = true;
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
-extern "C" int cp2_dataset_root(cp2_dataset* ds, uint8_t out[32]) {
+extern "C" int cp2_dataset_root(cp2_dataset* ds, uint8_t out[32]) try {
   if (!ds || !out) return CP2_ERR_INVALID;
   if (!ds->have_roots) CP2_TRY(cp2_dataset_set_roots(ds, nullptr));
   std::memcpy(out, &ds->dlayers[ds->dlayers.size() - 32], 32);
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -655,7 +708,7 @@ static void fill_slot_proof(const cp2_dataset* ds, uint64_t slot_idx, std::vecto
 // generateProofInput (gen_input/bn254.nim:35-79) for `n` slots of the dataset at once: one sampling launch,
 // one path gather, one cell fetch for all of them.
 extern "C" int cp2_proof_inputs_generate_batch(cp2_dataset* ds, const uint64_t* slot_idx, size_t n, const uint8_t entropy[32],
-                                               cp2_proof_input** out) {
+                                               cp2_proof_input** out) try {
   if (!ds || !entropy || (n && (!slot_idx || !out))) return CP2_ERR_INVALID;
   for (size_t i = 0; i < n; ++i) out[i] = nullptr;
   if (n == 0) return CP2_OK;
@@ -744,21 +797,33 @@ extern "C" int cp2_proof_inputs_generate_batch(cp2_dataset* ds, const uint64_t* 
   }
   trace.lap("split into proof inputs");
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
-extern "C" int cp2_proof_input_generate(cp2_dataset* ds, uint64_t slot_idx, const uint8_t entropy[32], cp2_proof_input** out) {
+extern "C" int cp2_proof_input_generate(cp2_dataset* ds, uint64_t slot_idx, const uint8_t entropy[32], cp2_proof_input** out) try {
   if (!out) return CP2_ERR_INVALID;
   return cp2_proof_inputs_generate_batch(ds, &slot_idx, 1, entropy, out);
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 extern "C" void cp2_proof_input_free(cp2_proof_input* p) { delete p; }
 
-extern "C" int cp2_proof_input_roots(const cp2_proof_input* p, uint8_t dataset_root[32], uint8_t slot_root[32], uint8_t entropy[32]) {
+extern "C" int cp2_proof_input_roots(const cp2_proof_input* p, uint8_t dataset_root[32], uint8_t slot_root[32], uint8_t entropy[32]) try {
   if (!p) return CP2_ERR_INVALID;
   if (dataset_root) std::memcpy(dataset_root, p->dataset_root, 32);
   if (slot_root) std::memcpy(slot_root, p->slot_root, 32);
   if (entropy) std::memcpy(entropy, p->entropy, 32);
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 extern "C" size_t cp2_proof_input_nsamples(const cp2_proof_input* p) { return p ? p->indices.size() : 0; }
 extern "C" const uint64_t* cp2_proof_input_cell_indices(const cp2_proof_input* p) { return p ? p->indices.data() : nullptr; }
@@ -843,7 +908,7 @@ static void proof_input_text(const cp2_proof_input* p, std::string& s) {
   s += "}\n";
 }
 
-extern "C" int cp2_proof_input_json(const cp2_proof_input* p, char** text, size_t* len) {
+extern "C" int cp2_proof_input_json(const cp2_proof_input* p, char** text, size_t* len) try {
   if (!p || !text) return CP2_ERR_INVALID;
   std::string s;
   proof_input_text(p, s);
@@ -854,6 +919,10 @@ extern "C" int cp2_proof_input_json(const cp2_proof_input* p, char** text, size_
   *text = buf;
   if (len) *len = s.size();
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 static int write_text_file(const std::string& s, const char* path) {
@@ -867,7 +936,7 @@ static int write_text_file(const std::string& s, const char* path) {
 // Serialise (and optionally write) many proof inputs on `threads` host threads.  paths == NULL or
 // paths[i] == NULL: serialise only.  total_bytes (may be NULL) receives the summed text length.
 extern "C" int cp2_proof_inputs_write_json_batch(const cp2_proof_input* const* ps, size_t n, const char* const* paths,
-                                                 int threads, uint64_t* total_bytes) {
+                                                 int threads, uint64_t* total_bytes) try {
   if (n && !ps) return CP2_ERR_INVALID;
   for (size_t i = 0; i < n; ++i)
     if (!ps[i]) return CP2_ERR_INVALID;
@@ -897,13 +966,17 @@ extern "C" int cp2_proof_inputs_write_json_batch(const cp2_proof_input* const* p
   }
   if (total_bytes) *total_bytes = tot;
   return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 // Proof inputs for many slots, generated and serialised as a two-stage pipeline: while the host threads turn
 // batch k into JSON text (and write it when dir != NULL: "<dir>/input_<slot>.json"), the GPU already samples and
 // gathers batch k+1.  Config 4's metric (witnesses/s) is this call after cp2_dataset_build.
 extern "C" int cp2_dataset_export_proof_inputs(cp2_dataset* ds, const uint64_t* slot_idx, size_t n, const uint8_t entropy[32],
-                                               const char* dir, int threads, size_t batch, uint64_t* total_bytes) {
+                                               const char* dir, int threads, size_t batch, uint64_t* total_bytes) try {
   if (!ds || !entropy || (n && !slot_idx)) return CP2_ERR_INVALID;
   if (batch == 0) batch = 512;
   if (threads < 1) threads = 1;
@@ -944,18 +1017,26 @@ extern "C" int cp2_dataset_export_proof_inputs(cp2_dataset* ds, const uint64_t* 
   release(next);
   if (total_bytes) *total_bytes = bytes;
   return status;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 extern "C" void cp2_free_buffer(void* p) { std::free(p); }
 
-extern "C" int cp2_proof_input_write_json(const cp2_proof_input* p, const char* path) {
+extern "C" int cp2_proof_input_write_json(const cp2_proof_input* p, const char* path) try {
   if (!p || !path) return CP2_ERR_INVALID;
   std::string s;
   proof_input_text(p, s);
   return write_text_file(s, path);
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
-extern "C" int cp2_write_circom_main(const cp2_config* cfg, const char* path) {
+extern "C" int cp2_write_circom_main(const cp2_config* cfg, const char* path) try {
   if (!cfg || !path || cfg->cell_size == 0) return CP2_ERR_INVALID;
   if (cfg->block_size % cfg->cell_size) return CP2_ERR_INVALID;
   uint64_t cpb = cfg->block_size / cfg->cell_size;
@@ -971,4 +1052,8 @@ extern "C" int cp2_write_circom_main(const cp2_config* cfg, const char* path) {
                cfg->max_depth, cfg->max_log2_nslots, depth, (unsigned long long)((cfg->cell_size + 30) / 31),
                (unsigned long long)cfg->n_samples);
   return std::fclose(f) == 0 ? CP2_OK : CP2_ERR_IO;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
