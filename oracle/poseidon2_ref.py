@@ -396,8 +396,14 @@ def circom_main(cfg):
 #   circuit/codex/sample_cells.circom:58-148, single_cell.circom:30-73, merkle.circom:44-114
 # --------------------------------------------------------------------------------------
 
+def _circom():
+    from . import circom_ref
+    return circom_ref
+
+
 def circuit_root_from_path(leaf, path_bits, last_bits, mask_bits, path):
-    """circuit/codex/merkle.circom:44-114 RootFromMerklePath, signal for signal.
+    """circuit/codex/merkle.circom:44-114 RootFromMerklePath, signal for signal (hashing through the circom-side
+    restatement oracle/circom_ref.py, not through this module's producer-side functions).
 
     path_bits / last_bits: bits of the leaf index / of the last index, LSB first (length depth);
     mask_bits: depth+1 bits [1,..,1,0,..,0]; path: depth siblings.  Returns recRoot."""
@@ -415,7 +421,7 @@ def circuit_root_from_path(leaf, path_bits, last_bits, mask_bits, path):
         odd = is_last[i] * (1 - path_bits[i])
         L, Rr = aux[i], path[i]
         sw = ((Rr - L) * path_bits[i]) % R_MOD
-        aux[i + 1] = compress((L + sw) % R_MOD, (Rr - sw) % R_MOD, bottom + 2 * odd)
+        aux[i + 1] = _circom().KeyedCompression(bottom + 2 * odd, [(L + sw) % R_MOD, (Rr - sw) % R_MOD])
     return sum((mc[i] - mc[i + 1]) * aux[i + 1] for i in range(depth)) % R_MOD   # merkle.circom:106-112
 
 
@@ -441,11 +447,11 @@ def circuit_check(p, cfg):
     last_bits = lgmask[:max_depth]
     assert len(p["proofInputs"]) == cfg["nSamples"]
     for cnt, q in enumerate(p["proofInputs"]):
-        h = sponge2([p["entropy"], p["slotRoot"], cnt + 1])                                # :23-48
+        h = _circom().Poseidon2_hash_rate2([p["entropy"], p["slotRoot"], cnt + 1])         # :23-48
         index_bits = [lgmask[i] * ((h >> i) & 1) for i in range(max_depth)]
         felts = bytes_to_felts(q["cellData"])
         assert len(felts) == (cfg["cellSize"] + 30) // 31
-        leaf = sponge2(felts)                                                               # single_cell.circom:63-65
+        leaf = _circom().Poseidon2_hash_rate2(felts)                                        # single_cell.circom:63-65
         path = q["merkleProof"]["merklePath"]
         assert len(path) == max_depth
         bot = circuit_root_from_path(leaf, index_bits[:bot_depth], last_bits[:bot_depth],

@@ -170,3 +170,29 @@ def test_c_slot_root_matches_python(oracle):
     cfg = dict(cellSize=64, blockSize=512, nCells=32, seed=9)
     _, big = P.build_slot_tree_full(cfg, 2)
     assert C.array_to_felts(C.fake_slot_root(C.slot_seed(9, 2), 64, 512, 32, threads=3))[0] == big[-1][0]
+
+
+def test_circom_side_specification_agrees_with_haskell_side(oracle, golden):
+    """The consumer-side templates (circuit/poseidon2/*.circom, restated literally in oracle/circom_ref.py) and the
+    producer-side restatement (Haskell twin) give the same permutation, sponges and keyed compression."""
+    import random
+    from oracle import circom_ref as Cm
+    _, P = oracle
+    kat = golden("kat_permutation.json")
+    assert [hex(v) for v in Cm.Permutation([int(v) for v in kat["input"]])] == kat["output_hex"]
+    rnd = random.Random(11)
+    for _ in range(10):
+        st = [rnd.randrange(P.R_MOD) for _ in range(3)]
+        assert tuple(Cm.Permutation(st)) == P.permutation(tuple(st))
+        assert Cm.KeyedCompression(st[2] % 4, st[:2]) == P.compress(st[0], st[1], st[2] % 4)
+    for n in list(range(9)) + [67, 68]:
+        xs = [rnd.randrange(P.R_MOD) for _ in range(n)]
+        assert Cm.Poseidon2_hash_rate2(xs) == P.sponge2(xs)
+        assert Cm.Poseidon2_hash_rate1(xs[:8]) == P.sponge1(xs[:8])
+    g = golden("sponge_felts.json")
+    for n in range(9):
+        assert str(Cm.Poseidon2_hash_rate2(list(range(1, n + 1)))) == g["rate2"][n]
+        assert str(Cm.Poseidon2_hash_rate1(list(range(1, n + 1)))) == g["rate1"][n]
+    # the cell hash the circuit computes (single_cell.circom:63-65) on the felts the JSON carries
+    cell = P.gen_fake_cell(P.slot_seed(12345, 3), 17, 2048)
+    assert Cm.Poseidon2_hash_rate2(P.bytes_to_felts(cell)) == P.hash_cell(cell, 2048)
