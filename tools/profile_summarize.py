@@ -6,7 +6,8 @@ R = sys.argv[1] if len(sys.argv) > 1 else "r01"
 O = os.path.join(ROOT, "gpurun_out", "prof_" + R)
 P = os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
-stats = glob.glob(os.path.join(O, "kt", "*", "*_kernel_stats.csv"))[0]
+newest = lambda pattern: sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]   # gpurun_out/ accumulates runs
+stats = newest(os.path.join(O, "kt", "*", "*_kernel_stats.csv"))[0]
 rows = [r for r in csv.DictReader(open(stats)) if r["Name"].startswith("cp2k::")]
 with open(os.path.join(P, "%s_bench_kernel_stats.csv" % R), "w") as f:
     w = csv.writer(f)
@@ -15,7 +16,7 @@ with open(os.path.join(P, "%s_bench_kernel_stats.csv" % R), "w") as f:
         w.writerow([r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")])
 counters = {}
 for d in ("fetch", "write", "sq", "sq2"):
-    fs = glob.glob(os.path.join(O, d, "*", "*_counter_collection.csv"))
+    fs = newest(os.path.join(O, d, "*", "*_counter_collection.csv"))
     if not fs:
         continue
     agg = collections.defaultdict(list)
