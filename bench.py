@@ -65,7 +65,10 @@ def main():
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+            try:
+                dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+            except TypeError:                                    # older torch: no device_id argument
+                dist.init_process_group("nccl")
         else:
             dist.init_process_group(backend)
 
