@@ -34,6 +34,23 @@ BYTES_PER_PERM = 192               # 96 B in + 96 B out per perm
 N_STATES = 1 << 24                 # BASELINE.json configs[1]
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """Point the process-level stdout (fd 1, what C libraries printf to) at stderr for the duration."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,13 +81,21 @@ def main():
     dev = torch.device("cuda", local_rank)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        if backend == "nccl":
-            try:
-                dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
-            except TypeError:                                    # older torch: no device_id argument
-                dist.init_process_group("nccl")
-        else:
-            dist.init_process_group(backend)
+        # RCCL printf()s a version banner on STDOUT when NCCL_DEBUG is set (the GPU boxes export NCCL_DEBUG=VERSION,
+        # and NCCL_DEBUG_FILE does not catch it); stdout must carry exactly one JSON line, so file descriptor 1 points
+        # at stderr while the communicator is created.
+        with _stdout_to_stderr():
+            if backend == "nccl":
+                try:
+                    dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+                except TypeError:                                    # older torch: no device_id argument
+                    dist.init_process_group("nccl")
+            else:
+                dist.init_process_group(backend)
+            warm = torch.zeros(1, device=coll_dev)
+            dist.all_reduce(warm)                                    # forces communicator creation inside the redirect
+            if coll_dev.type == "cuda":
+                torch.cuda.synchronize()
 
     pkg = g.load_package()
     ctx = pkg.Context(local_rank)                        # raises without a gfx950 GPU: no fallback
