@@ -634,3 +634,16 @@ def test_pipelined_export_writes_identical_files(pkg, ctx, golden, tmp_path):
     assert single[3] == golden("input_testmain_small.json")
     assert ds.export_proof_inputs(slots, m["entropy"], None, threads=2, batch=0) == total
     assert ds.export_proof_inputs([], m["entropy"]) == 0
+
+
+def test_rccl_backend_available_world1():
+    """The N>1 bench path uses backend "nccl" (= RCCL): create a communicator with world_size 1 in a child process,
+    all-gather uint8 rows and MAX-reduce a float64, and check that RCCL's banner stays off stdout."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_probe.py")], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip() == "rccl world=1 ok True 1.5", r.stdout
