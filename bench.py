@@ -5,24 +5,32 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no launcher spawns the N rank processes itself (before anything touches the
+GPU) and relays rank 0's JSON line.
+
 A "step" is one pass of the hot path over one batch: the batched permutation kernel over 2^24 states
-(BASELINE.json configs[1], 1.5 GiB in + 1.5 GiB out, already resident in HBM when the clock starts).
-With N ranks every rank runs the same batch on its own GPU (weak scaling, no data-path collective: the
-permutation has no exchange step); value = all states of all ranks / max-over-ranks time.
+(BASELINE.json configs[1], 1.5 GiB in + 1.5 GiB out, already resident in HBM when the clock starts; every element
+uniform in [0, r) by rejection).  With N ranks every rank runs the same-sized batch on its own GPU (weak scaling, no
+data-path collective: the permutation has no exchange step); value = all states of all ranks / max-over-ranks time.
 
 The JSON line also carries
   roofline      the dominant kernel (k_permute_batch) against the HBM roof BASELINE.json prescribes:
-                achieved = 192 algorithmic B/permutation x 2^24 / average launch time (HIP events on the
-                launch stream).  The kernel is VALU-integer bound (see DESIGN.md), so `frac` is small by nature;
-                `valu` reports the instruction-issue view next to it.
+                achieved = 192 algorithmic B/permutation x 2^24 / average launch time (HIP events on the launch
+                stream, measured in this run).  `traffic` is NOT measured in this run: it is the per-launch HBM byte
+                count of the committed rocprofv3 --pmc summary named in `traffic_source`.
+  valu_roofline the instruction-issue view (the binding resource); model-derived, unclamped.
   cpu_baseline  the C oracle (a port of the same algorithm, NOT the Nim binary: no Nim toolchain exists)
                 timed on this box's host cores on a bounded sample, rank 0 at N=1 only.
-  extra         config 3 (8 GiB slot -> slot root: sponge + trees) and, for N>1, the config-5 exchange
-                (RCCL all-gather of slot roots -> dataset root) on a small dataset.
+  extra         config 3 (8 GiB slot -> slot root), config 4 (4096 slots -> 4096 input.json texts: witnesses/s, classic
+                and streamed), ingestion rates against the measured pinned H2D peak, and for N>1 the config-5 exchange.
 """
 import argparse
+import contextlib
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,9 +40,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0             # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_PERM = 192               # 96 B in + 96 B out per permutation (config 2)
 N_STATES = 1 << 24                 # BASELINE.json configs[1]
-
-
-import contextlib
+R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 
 
 @contextlib.contextmanager
@@ -51,15 +57,74 @@ def _stdout_to_stderr():
         os.close(saved)
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (nothing in THIS process has touched
+    the GPU), relay rank 0's stdout, fail if any rank fails.  No exec: children are ordinary subprocesses."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    sys.exit(1 if rc else 0)
+
+
+def uniform_felts_device(torch, dev, m, gen):
+    """(m, 32) uint8 on `dev`: canonical little-endian field elements, uniform in [0, r) by rejection from 254-bit
+    candidates.  Acceptance probability r / 2^254 = 0.756."""
+    r_bytes = torch.tensor(list(R_MOD.to_bytes(32, "little")), dtype=torch.uint8, device=dev)
+
+    def candidates(k):
+        c = torch.randint(0, 256, (k, 32), dtype=torch.uint8, device=dev, generator=gen)
+        c[:, 31] &= 0x3F
+        return c
+
+    def below_r(c):
+        lt = torch.zeros(c.shape[0], dtype=torch.bool, device=dev)
+        eq = torch.ones(c.shape[0], dtype=torch.bool, device=dev)
+        for b in range(31, -1, -1):
+            col = c[:, b]
+            lt |= eq & (col < r_bytes[b])
+            eq &= col == r_bytes[b]
+        return lt
+
+    out = candidates(m)
+    bad = (~below_r(out)).nonzero().flatten()
+    while bad.numel():
+        c = candidates(bad.numel())
+        out[bad] = c
+        bad = bad[~below_r(c)]
+    return out
+
+
+def newest_profile(pattern):
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return fs[-1] if fs else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--states", type=int, default=N_STATES, help="states per step per GPU (default 2^24)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the config-3 / config-5 extra legs")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config-3 / config-4 / ingest / config-5 extra legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)
 
     import torch
     import torch.distributed as dist
@@ -69,8 +134,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (see the docstring)" % args.gpus)
         raise SystemExit("WORLD_SIZE=%d but --gpus=%d" % (world, args.gpus))
     # Rehearsal knobs (not used by the driver): BENCH_BACKEND=gloo + BENCH_SHARE_GPU=1 run N ranks on ONE GPU with
     # CPU-side collectives, to exercise the multi-rank logic on a one-GPU box (RCCL refuses two ranks per GPU).
@@ -104,9 +167,7 @@ def main():
 
     n = args.states
     gen = torch.Generator(device=dev).manual_seed(0xC0DE + rank)
-    x = torch.randint(0, 256, (n, 96), dtype=torch.uint8, device=dev, generator=gen)
-    for off in (31, 63, 95):
-        x[:, off] &= 0x1F                                # < 2^253 < r: canonical, effectively uniform
+    x = uniform_felts_device(torch, dev, 3 * n, gen).reshape(n, 96)
     y = torch.empty_like(x)
 
     def step():
@@ -137,48 +198,54 @@ def main():
     total_perms = n * args.steps * world
     value = total_perms / elapsed
 
-    # ---- sanity: the result of the timed kernel is the reference permutation (a few states, vs the oracle).
+    # ---- sanity: the result of the timed kernel is the reference permutation (a strided sample, vs the oracle).
     # Rank 0 only: the oracle is a checker built on demand, N ranks must not race its build.
     import numpy as np
     C = None
     if rank == 0:
         C, P = g.load_oracle()
-        idx = torch.tensor([0, 1, n // 2, n - 1], device=dev)
-        assert np.array_equal(y[idx].cpu().numpy(), C.permute_batch(x[idx].cpu().numpy())), "bench output != oracle"
+        idx = torch.cat([torch.tensor([0, 1, n // 2, n - 1], device=dev), torch.arange(0, n, max(1, n // 2048), device=dev)])
+        assert np.array_equal(y[idx].cpu().numpy(), C.permute_batch(x[idx].cpu().numpy(), threads=4)), "bench output != oracle"
     if world > 1:
         dist.barrier()
 
     avg_ms = sum(kernel_ms) / len(kernel_ms)
     achieved = BYTES_PER_PERM * n / (avg_ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 correction + WRITE_SIZE, separate rocprofv3
-    # passes; summary committed under profiles/).  It is a property of the 2^24-state launch only.
-    traffic, valu = None, None
-    tpath = os.path.join(ROOT, "profiles", "r01_permute_batch_traffic.json")
-    if os.path.exists(tpath) and n == N_STATES:
+    # passes; summary committed under profiles/).  A property of the 2^24-state launch only; not measured in this run.
+    traffic, traffic_source, valu = None, None, None
+    tpath = newest_profile("r*_permute_batch_traffic.json")
+    if tpath and n == N_STATES:
         try:
             prof = json.load(open(tpath))
             traffic = prof.get("hbm_bytes_per_launch")
+            traffic_source = "%s (rocprofv3 --pmc, separate passes of this command; not measured in this run)" % os.path.relpath(tpath, ROOT)
             ipw = prof.get("valu_insts_per_wave")
             if ipw:
-                # the real ceiling: VALU issue.  Measured (tools/ubench_valu.hip): the VOP3 integer ops this kernel
-                # is made of (v_mad_u64_u32 and friends) issue once per 4 cycles per SIMD; 1024 SIMDs at 2.4 GHz.
+                ghz = prof.get("shader_clock_GHz_from_GRBM_GUI_ACTIVE") or 2.4
                 wave_insts = ipw * n / 64
-                peak = 1024 * 2.4e9 / 4
-                valu = {"bound": "valu-issue", "achieved": wave_insts / (avg_ms * 1e-3), "peak": peak,
-                        "unit": "wave-instructions/s", "frac": round(min(1.0, wave_insts / (avg_ms * 1e-3) / peak), 4),
-                        "valu_insts_per_permutation": ipw, "pmc_valu_busy_frac": prof.get("valu_busy_frac"),
-                        # integer multiplies/s over the microbenchmarked peak.  33 120 v_mad_u64_u32 per
-                        # permutation (80 S-boxes x 414); tools/ubench_valu.hip: 4.56 cycles per wave-instruction per SIMD
-                        "mad_u64_u32_per_s": 33120 * n / (avg_ms * 1e-3),
-                        "mad_u64_u32_frac_of_ubench_peak": round(33120 * (n / 64) / (avg_ms * 1e-3) / (1024 * 2.4e9 / 4.56), 4),
-                        "note": "peak = 1 instruction / 4 cycles / SIMD (the VOP3 integer class, 3/4 of the mix; the rest are "
-                                "2-cycle VOP2 ops, so the raw ratio can exceed 1): the issue port is saturated",
-                        "source": "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE, profiles/r01_permute_batch_traffic.json"}
+                peak4 = 1024 * ghz * 1e9 / 4
+                mads = prof.get("mad_u64_u32_per_permutation", 33120)
+                valu = {"bound": "valu-issue", "model_derived": True,
+                        "achieved": wave_insts / (avg_ms * 1e-3), "unit": "wave-instructions/s",
+                        "peak_if_every_instruction_took_4_cycles": peak4,
+                        "frac_raw_vs_4_cycle_peak": round(wave_insts / (avg_ms * 1e-3) / peak4, 4),
+                        "shader_clock_GHz_measured_in_profile": ghz,
+                        "valu_insts_per_permutation": ipw, "pmc_valu_busy_frac_raw": prof.get("valu_busy_frac_raw"),
+                        "issue_cycles_per_permutation_wave_model": prof.get("issue_cycles_per_wave_model"),
+                        # integer multiplies/s over the microbenchmarked peak (tools/ubench_valu.hip:
+                        # 4.56 cycles per v_mad_u64_u32 wave-instruction per SIMD)
+                        "mad_u64_u32_per_s": mads * n / (avg_ms * 1e-3),
+                        "mad_u64_u32_frac_of_ubench_peak": round(mads * (n / 64) / (avg_ms * 1e-3) / (1024 * ghz * 1e9 / 4.56), 4),
+                        "note": "the mix is ~3/4 four-cycle VOP3 integer ops and ~1/4 two-cycle VOP2 ops, so the raw ratio against a "
+                                "4-cycle peak can exceed 1; tools/cycle_model.py prices each class at its measured cost",
+                        "source": os.path.relpath(tpath, ROOT)}
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "k_permute_batch", "avg_launch_ms": round(avg_ms, 4),
+                "launch_ms_min_max": [round(min(kernel_ms), 4), round(max(kernel_ms), 4)],
                 "algorithmic_bytes_per_launch": BYTES_PER_PERM * n,
                 "note": "VALU-integer bound by construction (about 5.5e4 VALU instructions per permutation against 192 B); see DESIGN.md"}
 
@@ -187,8 +254,9 @@ def main():
         "value": value, "unit": "permutations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32x9 (29-bit limbs, Montgomery mod BN254 r)", "data": "synthetic",
-        "config": {"workload": "configs[1]: batched Poseidon2 t=3 permutation, 2^%d random canonical Fr states per GPU per step, bit-exact vs oracle"
-                               % (n.bit_length() - 1), "states_per_gpu": n, "parallelism": "independent shards, %d rank(s)" % world},
+        "config": {"workload": "configs[1]: batched Poseidon2 t=3 permutation, 2^%d Fr states per GPU per step, every element uniform in "
+                               "[0, r) by rejection, bit-exact vs oracle" % (n.bit_length() - 1),
+                   "states_per_gpu": n, "parallelism": "independent shards, %d rank(s)" % world},
         "per_gpu_value": value / world, "collective_backend": (backend if world > 1 else None),
         "roofline": roofline,
     }
@@ -197,16 +265,23 @@ def main():
 
     # ---- extra legs (outside the timed region) -------------------------------------------------------
     extra = {}
+    del x, y
+    torch.cuda.empty_cache()
     if not args.no_extra:
         try:
             extra.update(slot_root_leg(torch, ctx, pkg, dev, stream))
         except Exception as e:   # never lose the headline line to an extra leg
             extra["slot_root_error"] = repr(e)
+        torch.cuda.empty_cache()
         if world == 1:
             try:
                 extra.update(witness_leg(torch, ctx, pkg))
             except Exception as e:
                 extra["witness_error"] = repr(e)
+            try:
+                extra.update(ingest_leg(torch, ctx, pkg, dev))
+            except Exception as e:
+                extra["ingest_error"] = repr(e)
         if world > 1:
             try:
                 extra.update(dataset_leg(torch, dist, ctx, pkg, coll_dev, rank, world))
@@ -221,6 +296,13 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def host_threads():
+    try:
+        return max(1, min(16, len(os.sched_getaffinity(0))))   # a one-GPU box's CPU share is 16 cores
+    except AttributeError:
+        return max(1, min(16, os.cpu_count() or 1))
 
 
 def slot_root_leg(torch, ctx, pkg, dev, stream):
@@ -239,58 +321,144 @@ def slot_root_leg(torch, ctx, pkg, dev, stream):
     e[3].record(stream)
     torch.cuda.synchronize()
     root = trees.roots()[0]
+    trees.free()
     gen_ms, build_ms = e[0].elapsed_time(e[1]), e[2].elapsed_time(e[3])
     perms = 35 * n_cells - 1
     alg_bytes = n_cells * cs + 2 * 32 * n_cells      # cells read once, leaf layer written and read back
     del buf
+    gold = None
+    try:
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize.json")))["config3"]["slot_root_hex"]
+    except Exception:
+        pass
+    root_hex = root.tobytes()[::-1].hex()
     return {"slot_root": {"workload": "configs[2]: cellSize=2048, nCells=2^22 (8 GiB) sponge+tree, 1 GPU",
                           "build_ms": round(build_ms, 2), "perms": perms, "perms_per_s": perms / (build_ms * 1e-3),
                           "algorithmic_GBps": round(alg_bytes / (build_ms * 1e-3) / 1e9, 2),
-                          "fake_data_gen_ms": round(gen_ms, 2), "slot_root_hex": root.tobytes()[::-1].hex()}}
+                          "fake_data_gen_ms": round(gen_ms, 2), "slot_root_hex": root_hex,
+                          "equals_oracle_fixture": (root_hex == gold) if gold else None}}
 
 
 def witness_leg(torch, ctx, pkg):
     """Config 4 (the metric's second half): nSamples=100, maxDepth=32, 4096 slots batched on one GPU.
     4096 x 8 GiB does not fit HBM, so nCells = 2^12 per slot (8 MiB), 32 GiB of fake data
-    generated and hashed on the device; one witness = one SlotProofInput serialised as input.json."""
+    generated and hashed on the device; one witness = one SlotProofInput serialised as input.json.
+    Classic: build every tree, then generate + serialise (pipelined in batches).  Streamed: the same work as one
+    pipeline in which the proof inputs of finished slots are produced while later slots are still hashing."""
     n_slots, n_cells = 4096, 1 << 12
     cfg = pkg.make_config(maxDepth=32, maxLog2NSlots=12, cellSize=2048, blockSize=65536, nSlots=n_slots, nCells=n_cells,
                           nSamples=100, seed=12345)
+    threads = host_threads()
     ctx.reset_stream()
     torch.cuda.synchronize()
+    res = {}
+    # ---- classic
     t0 = time.perf_counter()
     ds = ctx.dataset(cfg)                 # every slot tree, built once (sync on return)
     ds.set_roots(None)                    # dataset tree over the 4096 slot roots
     t1 = time.perf_counter()
-    pis = ds.proof_inputs(list(range(n_slots)), 1234567)
+    nbytes = ds.export_proof_inputs(list(range(n_slots)), 1234567, None, threads=threads, batch=512)
     t2 = time.perf_counter()
-    threads = 16
-    try:
-        threads = max(1, min(16, len(os.sched_getaffinity(0))))
-    except AttributeError:
-        pass
-    nbytes = pkg.write_json_batch(ctx, pis, None, threads=threads)
-    t3 = time.perf_counter()
-    for p in pis:
-        p.free()
-    # the same two stages overlapped (GPU batch k+1 while the host serialises batch k)
-    t4 = time.perf_counter()
-    nbytes2 = ds.export_proof_inputs(list(range(n_slots)), 1234567, None, threads=threads, batch=512)
-    t5 = time.perf_counter()
-    assert nbytes2 == nbytes
-    perms = n_slots * (35 * n_cells - 1) + (n_slots - 1) + 200 * n_slots
     root_hex = ds.root().tobytes()[::-1].hex()
     ds.free()
+    # ---- streamed, twice: the first pass also pays for the pinned staging (hipHostMalloc), which the context keeps
+    runs = []
+    for _ in range(2):
+        torch.cuda.synchronize()
+        s0 = time.perf_counter()
+        sd = ctx.dataset_streamed(cfg, 1234567, threads=threads)
+        s1 = time.perf_counter()
+        sd.set_roots(None)
+        nb2 = sd.export_streamed(None, threads=threads)
+        s2 = time.perf_counter()
+        assert nb2 == nbytes and sd.root().tobytes()[::-1].hex() == root_hex
+        sd.free()
+        runs.append({"build_with_bodies_s": round(s1 - s0, 4), "dataset_tree_and_heads_s": round(s2 - s1, 4), "total_s": round(s2 - s0, 4)})
+    perms = n_slots * (35 * n_cells - 1) + (n_slots - 1) + 200 * n_slots
+    gold = None
+    try:
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize.json")))["config4"]["dataset_root_hex"]
+    except Exception:
+        pass
+    best = min(r["total_s"] for r in runs)
+    res["witnesses"] = {"workload": "configs[3]: nSamples=100, maxDepth=32, 4096 slots x 2^12 cells (32 GiB fake data) batched, 1 GPU",
+                        "json_threads": threads, "json_bytes": nbytes,
+                        "classic": {"build_trees_s": round(t1 - t0, 4), "pipelined_generate_and_json_s": round(t2 - t1, 4),
+                                    "witnesses_per_s_with_json": n_slots / (t2 - t0)},
+                        "streamed_runs": runs,
+                        "witnesses_per_s_with_json": n_slots / best,
+                        "witnesses_per_s_with_json_first_run": n_slots / runs[0]["total_s"],
+                        "perms": perms, "perms_per_s_build": (perms - 200 * n_slots) / (t1 - t0),
+                        "dataset_root_hex": root_hex, "equals_oracle_fixture": (root_hex == gold) if gold else None}
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    return {"witnesses": {"workload": "configs[3]: nSamples=100, maxDepth=32, 4096 slots x 2^12 cells (32 GiB fake data) batched, 1 GPU",
-                          "build_trees_s": round(t1 - t0, 3), "generate_4096_proof_inputs_s": round(t2 - t1, 3),
-                          "json_serialise_s": round(t3 - t2, 3), "json_threads": threads, "json_bytes": nbytes,
-                          "pipelined_generate_and_json_s": round(t5 - t4, 3),
-                          "witnesses_per_s_without_json": n_slots / (t2 - t0),
-                          "witnesses_per_s_with_json": n_slots / ((t1 - t0) + (t5 - t4)),
-                          "witnesses_per_s_with_json_unpipelined": n_slots / (t3 - t0),
-                          "perms": perms, "perms_per_s_build": (perms - 200 * n_slots) / (t1 - t0),
-                          "dataset_root_hex": root_hex}}
+    return res
+
+
+def ingest_leg(torch, ctx, pkg, dev):
+    """Real (non-fake) slots: host memory and page-cache files -> pinned ring -> HBM -> hash.  Rates against the pinned
+    hipMemcpyAsync H2D peak measured here and against the rate the hash kernel sustains from HBM."""
+    import numpy as np
+    ctx.reset_stream()
+    cs, bs, nc = 2048, 65536, 1 << 20                     # one 2 GiB slot
+    nbytes = nc * cs
+    # pinned H2D peak (torch pinned tensor -> device, 1 GiB, best of 4)
+    src = torch.empty(1 << 30, dtype=torch.uint8).pin_memory()
+    dst = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    best = 0.0
+    for _ in range(4):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        dst.copy_(src, non_blocking=True)
+        b.record()
+        torch.cuda.synchronize()
+        best = max(best, (1 << 30) / (a.elapsed_time(b) * 1e-3) / 1e9)
+    del src, dst
+    # kernel rate from HBM for the same slot
+    d = torch.empty((nc, cs), dtype=torch.uint8, device=dev)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.gen_fake_cells_dev(ctx.slot_seed(1, 0), 0, nc, cs, d.data_ptr())
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    tr = ctx.slot_trees_dev(d.data_ptr(), 1, cs, bs, nc)
+    b.record()
+    torch.cuda.synchronize()
+    kernel_gbps = nbytes / (a.elapsed_time(b) * 1e-3) / 1e9
+    want = tr.roots()[0].copy()
+    tr.free()
+    cells = d.cpu().numpy()
+    del d
+    ctx.reset_stream()
+    path_base = "/tmp/cp2_bench_slot"
+    cells.tofile(path_base + "0.dat")
+    cfg = pkg.make_config(maxDepth=32, maxLog2NSlots=1, cellSize=cs, blockSize=bs, nSlots=1, nCells=nc, nSamples=5, file=path_base)
+    table = []
+    for threads, chunk_mb in ((8, 64), (4, 384), (8, 384), (16, 384), (8, 768)):
+        ctx.set_ingest(threads, 3, chunk_mb << 20)
+        warm = min(nc, (chunk_mb << 20) // cs)
+        ctx.slot_trees_host(cells[:warm], 1, cs, bs, warm).free()               # pinned ring of this size allocated outside the timing
+        t = time.perf_counter()
+        trh = ctx.slot_trees_host(cells, 1, cs, bs, nc)
+        dt_h = time.perf_counter() - t
+        ok_h = bool(np.array_equal(trh.roots()[0], want))
+        trh.free()
+        t = time.perf_counter()
+        ds = ctx.dataset(cfg)
+        dt_f = time.perf_counter() - t
+        ok_f = bool(np.array_equal(ds.local_roots()[0], want))
+        ds.free()
+        table.append({"fill_threads": threads, "chunk_MiB": chunk_mb, "host_pointer_GBps": round(nbytes / dt_h / 1e9, 2), "page_cache_file_GBps": round(nbytes / dt_f / 1e9, 2),
+                      "roots_match_device_build": ok_h and ok_f})
+    ctx.set_ingest(0, 0, 0)
+    os.remove(path_base + "0.dat")
+    bh = max(r["host_pointer_GBps"] for r in table)
+    bf = max(r["page_cache_file_GBps"] for r in table)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    return {"ingest": {"workload": "one 2 GiB slot (cellSize 2048) from host memory / from a page-cache-warm slot file through the pinned ring",
+                       "pinned_h2d_peak_GBps": round(best, 2), "hash_from_hbm_GBps": round(kernel_gbps, 2), "by_fill_threads": table,
+                       "best_host_pointer_GBps": bh, "best_page_cache_file_GBps": bf,
+                       "host_pointer_frac_of_h2d_peak": round(bh / best, 3), "file_frac_of_h2d_peak": round(bf / best, 3),
+                       "host_pointer_frac_of_kernel_rate": round(bh / kernel_gbps, 3)}}
 
 
 def dataset_leg(torch, dist, ctx, pkg, dev, rank, world):
@@ -328,12 +496,7 @@ def dataset_leg(torch, dist, ctx, pkg, dev, rank, world):
 
 def cpu_baseline(C, np):
     """The oracle timed on this box's host cores on a bounded sample of the same workload (config 2 shape)."""
-    # a one-GPU box's CPU share is 16 cores even though more are visible; never oversubscribe it
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))
+    cores = host_threads()
     rng = np.random.default_rng(0xC0DE)
     n1 = 1 << 17
     x = rng.integers(0, 256, size=(n1, 96), dtype=np.uint8)

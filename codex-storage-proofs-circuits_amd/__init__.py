@@ -84,6 +84,7 @@ def load_library():
         "cp2_strerror": (cp, [i32]),
         "cp2_last_error": (cp, [vp]),
         "cp2_device_is_native": (i32, [vp]),
+        "cp2_set_ingest": (i32, [vp, i32, i32, sz]),
         "cp2_permute_batch": (i32, [vp, vp, vp, sz]),
         "cp2_permute_batch_dev": (i32, [vp, vp, vp, sz]),
         "cp2_compress_batch": (i32, [vp, vp, u32, vp, sz]),
@@ -126,6 +127,9 @@ def load_library():
         "cp2_proof_inputs_generate_batch": (i32, [vp, vp, sz, vp, pvp]),
         "cp2_proof_inputs_write_json_batch": (i32, [pvp, sz, ctypes.POINTER(cp), i32, ctypes.POINTER(u64)]),
         "cp2_dataset_export_proof_inputs": (i32, [vp, vp, sz, vp, cp, i32, sz, ctypes.POINTER(u64)]),
+        "cp2_dataset_build_streamed": (i32, [vp, ctypes.POINTER(Config), u64, u64, vp, i32, sz, pvp]),
+        "cp2_dataset_export_streamed": (i32, [vp, cp, i32, ctypes.POINTER(u64)]),
+        "cp2_dataset_streamed_json": (i32, [vp, u64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz)]),
         "cp2_proof_input_free": (None, [vp]),
         "cp2_proof_input_roots": (i32, [vp, vp, vp, vp]),
         "cp2_proof_input_nsamples": (sz, [vp]),
@@ -216,6 +220,9 @@ class Context:
 
     def sync(self):
         self._ck(self.L.cp2_sync(self.h), "cp2_sync")
+
+    def set_ingest(self, fill_threads=0, ring_depth=0, chunk_bytes=0):
+        self._ck(self.L.cp2_set_ingest(self.h, fill_threads, ring_depth, chunk_bytes), "cp2_set_ingest")
 
     # -- a1
     def permute_batch(self, states):
@@ -347,6 +354,11 @@ class Context:
     def dataset(self, cfg, first_slot=0, n_local=None, cache=None):
         return Dataset(self, cfg, first_slot, cfg.n_slots if n_local is None else n_local, cache)
 
+    def dataset_streamed(self, cfg, entropy, first_slot=0, n_local=None, threads=1, group_slots=0):
+        """cp2_dataset_build_streamed: trees + (overlapped) the proof-input bodies of every local slot for `entropy`."""
+        return Dataset(self, cfg, first_slot, cfg.n_slots if n_local is None else n_local, None,
+                       streamed=(entropy, threads, group_slots))
+
 
 def make_config(maxDepth=32, maxLog2NSlots=8, cellSize=2048, blockSize=65536, nSlots=11, nCells=256, nSamples=5,
                 seed=12345, file=None):
@@ -405,10 +417,15 @@ class SlotTrees:
 
 
 class Dataset:
-    def __init__(self, ctx, cfg, first_slot, n_local, cache=None):
+    def __init__(self, ctx, cfg, first_slot, n_local, cache=None, streamed=None):
         self.ctx, self.cfg = ctx, cfg
         h = ctypes.c_void_p()
-        if cache:
+        if streamed is not None:
+            entropy, threads, group = streamed
+            e = _u8(entropy if not isinstance(entropy, int) else felt_bytes(entropy))
+            ctx._ck(ctx.L.cp2_dataset_build_streamed(ctx.h, ctypes.byref(cfg), first_slot, n_local, _p(e), threads, group,
+                                                     ctypes.byref(h)), "cp2_dataset_build_streamed")
+        elif cache:
             ctx._ck(ctx.L.cp2_dataset_build_cached(ctx.h, ctypes.byref(cfg), first_slot, n_local, cache.encode(), ctypes.byref(h)),
                     "cp2_dataset_build_cached")
         else:
@@ -461,6 +478,20 @@ class Dataset:
         self.ctx._ck(self.ctx.L.cp2_dataset_export_proof_inputs(self.h, _p(idx), idx.size, _p(e), directory.encode() if directory else None,
                                                                 threads, batch, ctypes.byref(total)), "cp2_dataset_export_proof_inputs")
         return total.value
+
+    def export_streamed(self, directory=None, threads=1):
+        """Finish the proof inputs prepared by Context.dataset_streamed; returns the total text bytes."""
+        total = ctypes.c_uint64()
+        self.ctx._ck(self.ctx.L.cp2_dataset_export_streamed(self.h, directory.encode() if directory else None, threads,
+                                                            ctypes.byref(total)), "cp2_dataset_export_streamed")
+        return total.value
+
+    def streamed_json(self, slot_idx):
+        text, ln = ctypes.c_void_p(), ctypes.c_size_t()
+        self.ctx._ck(self.ctx.L.cp2_dataset_streamed_json(self.h, slot_idx, ctypes.byref(text), ctypes.byref(ln)), "cp2_dataset_streamed_json")
+        s = ctypes.string_at(text, ln.value).decode()
+        self.ctx.L.cp2_free_buffer(text)
+        return s
 
     def proof_inputs(self, slot_indices, entropy):
         """Batched generateProofInput for many slots of this dataset (one sampling / gather / fetch)."""

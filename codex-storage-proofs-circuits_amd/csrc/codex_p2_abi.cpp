@@ -53,7 +53,12 @@ extern "C" void cp2_free(cp2_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->aux_stream) {
+    (void)hipStreamSynchronize(ctx->aux_stream);
+    (void)hipStreamDestroy(ctx->aux_stream);
+  }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  ctx->pool->trim();   // cached scratch goes now; pinned blocks still held by live proof inputs return to the pool later
   delete ctx;
 }
 
@@ -125,8 +130,8 @@ extern "C" int cp2_permute_batch(cp2_ctx* ctx, const uint8_t* in, uint8_t* out, 
   if (n == 0) return CP2_OK;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   DevBuf d_in, d_out;
-  CP2_TRY(d_in.alloc(ctx, n * 96));
-  CP2_TRY(d_out.alloc(ctx, n * 96));
+  CP2_TRY(d_in.scratch(ctx, n * 96));
+  CP2_TRY(d_out.scratch(ctx, n * 96));
   CP2_HIP(ctx, hipMemcpyAsync(d_in.p, in, n * 96, hipMemcpyHostToDevice, ctx->stream));
   CP2_TRY(cp2_permute_batch_dev(ctx, d_in.p, d_out.p, n));
   CP2_HIP(ctx, hipMemcpyAsync(out, d_out.p, n * 96, hipMemcpyDeviceToHost, ctx->stream));
@@ -180,8 +185,8 @@ extern "C" int cp2_sponge2_felts_batch(cp2_ctx* ctx, const uint8_t* felts, size_
   if (nitems == 0) return CP2_OK;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   DevBuf d_in, d_out;
-  CP2_TRY(d_in.alloc(ctx, std::max<size_t>(nf * nitems * 32, 32)));
-  CP2_TRY(d_out.alloc(ctx, nitems * 32));
+  CP2_TRY(d_in.scratch(ctx, std::max<size_t>(nf * nitems * 32, 32)));
+  CP2_TRY(d_out.scratch(ctx, nitems * 32));
   if (nf) CP2_HIP(ctx, hipMemcpyAsync(d_in.p, felts, nf * nitems * 32, hipMemcpyHostToDevice, ctx->stream));
   CP2_TRY(cp2_sponge2_felts_batch_dev(ctx, d_in.p, nf, nitems, d_out.p));
   CP2_HIP(ctx, hipMemcpyAsync(out, d_out.p, nitems * 32, hipMemcpyDeviceToHost, ctx->stream));
@@ -244,12 +249,12 @@ extern "C" int cp2_hash_cells(cp2_ctx* ctx, const uint8_t* cells, size_t cell_si
   if (n_cells == 0) return CP2_OK;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   DevBuf d_in, d_out;
-  CP2_TRY(d_out.alloc(ctx, n_cells * 32));
+  CP2_TRY(d_out.scratch(ctx, n_cells * 32));
   if (cell_size * n_cells > ((size_t)32 << 20)) {
     // large inputs stream through the pinned ring (upload and hashing overlapped)
     CP2_TRY(hash_host_cells_pipelined(ctx, cells, cell_size, n_cells, d_out.u8()));
   } else {
-    CP2_TRY(d_in.alloc(ctx, std::max<size_t>(cell_size * n_cells, 16)));
+    CP2_TRY(d_in.scratch(ctx, std::max<size_t>(cell_size * n_cells, 16)));
     if (cell_size) CP2_HIP(ctx, hipMemcpyAsync(d_in.p, cells, cell_size * n_cells, hipMemcpyHostToDevice, ctx->stream));
     CP2_TRY(cp2_hash_cells_dev(ctx, d_in.p, cell_size, n_cells, d_out.p));
   }
@@ -318,7 +323,7 @@ extern "C" int cp2_merkle_tree(cp2_ctx* ctx, const uint8_t* leaves, size_t n, ui
   std::vector<size_t> sizes = layer_sizes_of(n);
   size_t total = cp2_merkle_total(n);
   DevBuf d;
-  CP2_TRY(d.alloc(ctx, total * 32));
+  CP2_TRY(d.scratch(ctx, total * 32));
   CP2_HIP(ctx, hipMemcpyAsync(d.p, leaves, n * 32, hipMemcpyHostToDevice, ctx->stream));
   CP2_TRY(merkle_trees_dev(ctx, d.p, n, 1, d.p, true));
   CP2_HIP(ctx, hipMemcpyAsync(layers_out, d.p, total * 32, hipMemcpyDeviceToHost, ctx->stream));
@@ -366,7 +371,7 @@ extern "C" int cp2_gen_fake_cells(cp2_ctx* ctx, uint64_t seed, uint64_t first, s
   if (n == 0 || cell_size == 0) return CP2_OK;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   DevBuf d;
-  CP2_TRY(d.alloc(ctx, n * cell_size));
+  CP2_TRY(d.scratch(ctx, n * cell_size));
   CP2_TRY(cp2_gen_fake_cells_dev(ctx, seed, first, n, cell_size, d.p));
   CP2_HIP(ctx, hipMemcpyAsync(out, d.p, n * cell_size, hipMemcpyDeviceToHost, ctx->stream));
   CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));

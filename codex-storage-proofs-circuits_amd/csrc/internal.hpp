@@ -2,17 +2,107 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstdint>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/codex_p2.h"
+
+namespace cp2i {
+
+// Per-context cache of device and pinned-host scratch blocks.  The host-pointer entry points (one hipMalloc +
+// hipFree pair per call before) and the staging buffers of the builders draw from it, so a context that is
+// called repeatedly stops allocating after its first calls.  Blocks are handed back only when no work that
+// touches them is in flight (DevBuf / PinBuf synchronise the context's stream first).  Thread-safe.
+class BlockPool {
+ public:
+  static constexpr size_t MAX_CACHED_DEV = (size_t)6 << 30, MAX_CACHED_PIN = (size_t)3 << 30;
+  ~BlockPool() { trim(); }
+  // returns nullptr on failure; *got = usable size (>= n)
+  void* get(bool pinned, size_t n, size_t* got) {
+    if (n == 0) n = 16;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      auto& fl = pinned ? pin_ : dev_;
+      size_t best = fl.size();
+      for (size_t i = 0; i < fl.size(); ++i)
+        if (fl[i].bytes >= n && fl[i].bytes / 4 <= n && (best == fl.size() || fl[i].bytes < fl[best].bytes)) best = i;
+      if (best != fl.size()) {
+        Blk b = fl[best];
+        fl.erase(fl.begin() + (long)best);
+        (pinned ? cached_pin_ : cached_dev_) -= b.bytes;
+        *got = b.bytes;
+        return b.p;
+      }
+    }
+    size_t want = round_up(n);
+    void* p = nullptr;
+    hipError_t e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+    if (e != hipSuccess) {   // make room and try the exact size once
+      (void)hipGetLastError();
+      trim();
+      want = n;
+      e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+      if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    *got = want;
+    return p;
+  }
+  void put(bool pinned, void* p, size_t bytes) {
+    if (!p) return;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      size_t& cached = pinned ? cached_pin_ : cached_dev_;
+      if (cached + bytes <= (pinned ? MAX_CACHED_PIN : MAX_CACHED_DEV)) {
+        (pinned ? pin_ : dev_).push_back({p, bytes});
+        cached += bytes;
+        return;
+      }
+    }
+    if (pinned) (void)hipHostFree(p); else (void)hipFree(p);
+  }
+  void trim() {
+    std::vector<Blk> d, h;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      d.swap(dev_); h.swap(pin_);
+      cached_dev_ = cached_pin_ = 0;
+    }
+    for (auto& b : d) (void)hipFree(b.p);
+    for (auto& b : h) (void)hipHostFree(b.p);
+  }
+
+ private:
+  struct Blk { void* p; size_t bytes; };
+  static size_t round_up(size_t n) {   // 64 KiB granules below 1 MiB, then 1/8-octave steps: sizes that recur hit the cache
+    if (n <= ((size_t)1 << 20)) return (n + 0xffff) & ~(size_t)0xffff;
+    size_t step = (size_t)1 << 17;
+    while (step * 16 < n) step <<= 1;
+    return (n + step - 1) / step * step;
+  }
+  std::mutex mu_;
+  std::vector<Blk> dev_, pin_;
+  size_t cached_dev_ = 0, cached_pin_ = 0;
+};
+
+}  // namespace cp2i
 
 struct cp2_ctx {
   int device = 0;
   bool native = false;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  hipStream_t aux_stream = nullptr;   // gathers / downloads that overlap hashing on `stream` (created on first use)
+  std::shared_ptr<cp2i::BlockPool> pool = std::make_shared<cp2i::BlockPool>();
+  size_t stage_bytes = (size_t)1 << 31;   // device staging chunk of the fake-data builder
+  int ingest_threads = 0, ingest_ring = 0;   // 0: CP2_INGEST_* environment or the built-in default (cp2_set_ingest)
+  size_t ingest_chunk = 0;
   std::string err;
 };
 
@@ -33,23 +123,39 @@ namespace cp2i {
     if (s__ != CP2_OK) return s__;    \
   } while (0)
 
-// RAII device buffer
+// RAII device buffer.  alloc() = plain hipMalloc (long-lived: tree nodes); scratch() = from the context's
+// pool (staging / temporaries).  A pooled block goes back only after the context's stream has drained.
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  cp2_ctx* owner = nullptr;   // non-null: pooled
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) {
+      if (owner) {
+        (void)hipStreamSynchronize(owner->stream);
+        if (owner->aux_stream) (void)hipStreamSynchronize(owner->aux_stream);
+        owner->pool->put(false, p, bytes);
+      } else {
+        (void)hipFree(p);
+      }
+    }
     p = nullptr;
     bytes = 0;
+    owner = nullptr;
   }
   int alloc(cp2_ctx* ctx, size_t n) {
     release();
     if (n == 0) n = 16;
     hipError_t e = hipMalloc(&p, n);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->pool->trim();        // cached scratch may be what is in the way
+      e = hipMalloc(&p, n);
+    }
     if (e != hipSuccess) {
       p = nullptr;
       ctx->err = std::string("hipMalloc(") + std::to_string(n) + "): " + hipGetErrorString(e);
@@ -58,7 +164,111 @@ struct DevBuf {
     bytes = n;
     return CP2_OK;
   }
+  int scratch(cp2_ctx* ctx, size_t n) {
+    release();
+    size_t got = 0;
+    p = ctx->pool->get(false, n, &got);
+    if (!p) {
+      ctx->err = std::string("device scratch of ") + std::to_string(n) + " bytes: allocation failed";
+      return CP2_ERR_ALLOC;
+    }
+    bytes = got;
+    owner = ctx;
+    return CP2_OK;
+  }
   uint8_t* u8() const { return static_cast<uint8_t*>(p); }
+};
+
+// RAII pinned host buffer from the context's pool (the pool outlives the context through the shared_ptr, so
+// proof inputs that still reference their batch storage stay valid after cp2_free).
+struct PinBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  std::shared_ptr<BlockPool> pool;
+  PinBuf() = default;
+  PinBuf(const PinBuf&) = delete;
+  PinBuf& operator=(const PinBuf&) = delete;
+  ~PinBuf() { release(); }
+  void release() {
+    if (p && pool) pool->put(true, p, bytes);
+    p = nullptr;
+    bytes = 0;
+  }
+  int alloc(cp2_ctx* ctx, size_t n) {
+    release();
+    pool = ctx->pool;
+    size_t got = 0;
+    p = pool->get(true, n, &got);
+    if (!p) {
+      ctx->err = std::string("pinned host buffer of ") + std::to_string(n) + " bytes: allocation failed";
+      return CP2_ERR_ALLOC;
+    }
+    bytes = got;
+    return CP2_OK;
+  }
+  void swap(PinBuf& o) {
+    std::swap(p, o.p);
+    std::swap(bytes, o.bytes);
+    std::swap(pool, o.pool);
+  }
+  uint8_t* u8() const { return static_cast<uint8_t*>(p); }
+};
+
+// Host worker threads with a FIFO of tasks; the destructor drains the queue and joins (no joinable thread is
+// ever destroyed, whatever path leaves the owning scope).
+class Workers {
+ public:
+  explicit Workers(int n) {
+    if (n < 1) n = 1;
+    for (int i = 0; i < n; ++i) th_.emplace_back([this] { run(); });
+  }
+  ~Workers() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  void submit(std::function<void()> f) {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      q_.push_back(std::move(f));
+    }
+    cv_.notify_one();
+  }
+  void wait_idle() {
+    std::unique_lock<std::mutex> lk(mu_);
+    idle_.wait(lk, [this] { return q_.empty() && busy_ == 0; });
+  }
+  size_t size() const { return th_.size(); }
+
+ private:
+  void run() {
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+        if (q_.empty()) return;   // stop_ and drained
+        f = std::move(q_.front());
+        q_.pop_front();
+        ++busy_;
+      }
+      try { f(); } catch (...) {}   // tasks report through their own status words
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        --busy_;
+      }
+      idle_.notify_all();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_, idle_;
+  std::deque<std::function<void()>> q_;
+  size_t busy_ = 0;
+  bool stop_ = false;
 };
 
 // element counts of all layers of a tree over n leaves, bottom first (merkle/bn254.nim:29-58):
@@ -80,5 +290,7 @@ inline std::vector<size_t> layer_sizes_of(size_t n) {
 int merkle_trees_dev(cp2_ctx* ctx, const void* d_leaves, size_t n, size_t nseg, void* d_layers_out, bool leaves_in_place);
 // hash n host-resident cells into d_leaves (device, n x 32 bytes) through the pinned ingestion pipe
 int hash_host_cells_pipelined(cp2_ctx* ctx, const uint8_t* cells, size_t cell_size, size_t n, uint8_t* d_leaves);
+// the context's second stream (created on first use)
+int aux_stream(cp2_ctx* ctx, hipStream_t* out);
 
 }  // namespace cp2i

@@ -274,7 +274,11 @@ __global__ void __launch_bounds__(TPB) k_gen_fake_cells(uint64_t seed0, uint64_t
         }
         my[lane * 9 + piece] = make_uint4(w[0], w[1], w[2], w[3]);   // row stride 9 x 16 B: conflict-free both ways
       }
-      // wave-private region, in-order LDS pipeline: the reads below see the writes above
+      // wave-private region: order this wave's LDS writes before its cross-lane reads (no instructions on wave64,
+      // but the compiler may not move the reads up)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int c = k * 8 + (lane >> 3), piece = lane & 7;
@@ -282,6 +286,9 @@ __global__ void __launch_bounds__(TPB) k_gen_fake_cells(uint64_t seed0, uint64_t
         uint4 v = my[c * 9 + piece];
         if (cell < n_cells) *reinterpret_cast<uint4*>(out + cell * cell_size + i + 16 * piece) = v;
       }
+      // ... and the next round's writes after these reads
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
     return;
   }
@@ -291,6 +298,59 @@ __global__ void __launch_bounds__(TPB) k_gen_fake_cells(uint64_t seed0, uint64_t
     state = state % 1698428844001831ULL;
     dst[i] = (uint8_t)state;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cellIndex (sample/bn254.nim:16-24) + merged, padded path rows (merkle.nim:21-42,86-100; types.nim:27-37) for
+// one (slot, counter) pair per lane.  The sponge input [entropy, slotRoot, counter] pads to 4 elements with the
+// "1" (Sponge.hs:36-39): two permutations.
+__global__ void __launch_bounds__(TPB) k_sample_paths(TreeGeom g, const uint4* __restrict__ nodes, const uint4* __restrict__ entropy,
+                                                        const uint64_t* __restrict__ slots, uint64_t slot0, size_t n_items,
+                                                        uint32_t ns, uint32_t md, uint64_t* __restrict__ indices,
+                                                        uint64_t* __restrict__ gcell, uint64_t* __restrict__ rows) {
+  __shared__ uint32_t qtab[fr::QTAB_WORDS];
+  fr::qtab_fill(qtab, threadIdx.x, TPB);
+  __syncthreads();
+  size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (t >= n_items * ns) return;
+  const size_t item = t / ns;
+  const uint32_t counter = (uint32_t)(t - item * ns) + 1;            // sample/bn254.nim:27
+  const uint64_t slot = slots ? slots[item] : slot0 + item;
+  State s;
+  s.x = load_fe_canonical(entropy);
+  s.y = load_fe_canonical(nodes + 2 * (g.toff[g.nt - 1] + slot));  // treeRoot(bigTree)
+  s.z = fr::fe_const(fr::FR_CIV_RATE2_MONT);
+  p2::permute(s, qtab);
+  Fe c = fr::fe_zero();
+  c.l[0] = counter & fr::MASK;
+  c.l[1] = counter >> 29;
+  s.x = fr::norm(fr::add_lazy(s.x, fr::to_mont(c)));
+  s.y = fr::norm(fr::add_lazy(s.y, fr::fe_const(fr::FR_R1)));
+  p2::permute(s, qtab);
+  uint32_t w[8];
+  fr::to_canonical_words(s.x, w);
+  const uint64_t cell = (((uint64_t)w[1] << 32) | w[0]) & (g.n_cells - 1);   // extractLowBits, types/bn254.nim:47-59
+  indices[t] = cell;
+  gcell[t] = slot * g.n_cells + cell;
+  uint64_t* r = rows + t * md;
+  uint32_t d = 0;
+  const uint64_t b = cell / g.cpb;
+  uint64_t j = cell - b * g.cpb, m = g.cpb;
+  for (uint32_t k = 0; k + 1 < g.nb && d < md; ++k, ++d) {           // bottom proof inside the block tree
+    const uint64_t sib = j ^ 1;
+    r[d] = (sib < m) ? g.boff[k] + (slot * g.nblocks + b) * g.bsz[k] + sib : ~0ULL;
+    j >>= 1;
+    m = (m + 1) >> 1;
+  }
+  j = b;
+  m = g.nblocks;
+  for (uint32_t k = 0; k + 1 < g.nt && d < md; ++k, ++d) {           // top proof inside the slot's big tree
+    const uint64_t sib = j ^ 1;
+    r[d] = (sib < m) ? g.toff[k] + slot * g.tsz[k] + sib : ~0ULL;
+    j >>= 1;
+    m = (m + 1) >> 1;
+  }
+  for (; d < md; ++d) r[d] = ~0ULL;                                   // padMerkleProof
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -345,6 +405,15 @@ hipError_t launch_gen_fake_cells(uint64_t seed0, uint64_t cells_per_slot, uint64
   if (n_cells == 0 || cell_size == 0) return hipSuccess;
   hipLaunchKernelGGL(k_gen_fake_cells, dim3(grid_for(n_cells)), dim3(TPB), 0, st, seed0, cells_per_slot, first, list,
                      n_cells, cell_size, (uint8_t*)out);
+  return hipGetLastError();
+}
+
+hipError_t launch_sample_paths(const TreeGeom& g, const void* nodes, const void* d_entropy, const uint64_t* slots, uint64_t slot0,
+                               size_t n_items, uint32_t ns, uint32_t md, uint64_t* indices, uint64_t* gcell, uint64_t* rows,
+                               hipStream_t st) {
+  if (n_items == 0 || ns == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_sample_paths, dim3(grid_for(n_items * ns)), dim3(TPB), 0, st, g, (const uint4*)nodes, (const uint4*)d_entropy,
+                     slots, slot0, n_items, ns, md, indices, gcell, rows);
   return hipGetLastError();
 }
 

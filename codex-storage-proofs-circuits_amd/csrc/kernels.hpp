@@ -6,6 +6,16 @@
 
 namespace cp2k {
 
+// Kernel-argument copy of the layer-major node layout of a batch of slot trees (proof_input.cpp, trees_layout):
+// block-tree layer k of block b of slot s starts at element boff[k] + (s * nblocks + b) * bsz[k]; big-tree layer k
+// of slot s at toff[k] + s * tsz[k]; the last big-tree layer holds the slot roots.
+struct TreeGeom {
+  static constexpr int MAX_LAYERS = 40;
+  uint32_t nb, nt;                      // layer counts (leaves included) of a block tree / a big tree
+  uint64_t cpb, nblocks, n_cells;
+  uint64_t boff[MAX_LAYERS], bsz[MAX_LAYERS], toff[MAX_LAYERS], tsz[MAX_LAYERS];
+};
+
 hipError_t launch_permute_batch(const void* in, void* out, size_t n, hipStream_t st);
 // one Merkle layer of nseg trees; segment strides are in field elements
 hipError_t launch_compress_layer(const void* in, void* out, size_t m_in, size_t nseg, bool bottom,
@@ -16,6 +26,14 @@ hipError_t launch_hash_cells(const void* cells, size_t cell_size, size_t n_cells
 // whose seed is seed0 + 1001 * slot.  list (device, may be NULL) selects explicit global cells.
 hipError_t launch_gen_fake_cells(uint64_t seed0, uint64_t cells_per_slot, uint64_t first, const uint64_t* list,
                                  size_t n_cells, size_t cell_size, void* out, hipStream_t st);
+// Sampling + path lookup for proof inputs, all on the device (sample/bn254.nim:16-27, merkle.nim:21-42,86-100,
+// types.nim:27-37): for item i < n_items (slot = slots ? slots[i] : slot0 + i, an index INSIDE the batch) and
+// counter c = 1..ns:  cell = low bits of sponge2[entropy, slotRoot, c];  indices[i*ns+c-1] = cell;
+// gcell[...] = slot * n_cells + cell;  rows[(i*ns+c-1)*md ..] = node-row index of each sibling on the merged path,
+// ~0 where the reference pads with zero.  entropy: 32 bytes in device memory.
+hipError_t launch_sample_paths(const TreeGeom& g, const void* nodes, const void* d_entropy, const uint64_t* slots, uint64_t slot0,
+                               size_t n_items, uint32_t ns, uint32_t md, uint64_t* indices, uint64_t* gcell, uint64_t* rows,
+                               hipStream_t st);
 hipError_t launch_gather_rows(const void* src, const uint64_t* index, size_t nrows, size_t row_bytes, void* out,
                               hipStream_t st);
 

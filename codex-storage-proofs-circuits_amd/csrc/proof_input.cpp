@@ -1,572 +1,32 @@
-// Slot trees, datasets and proof inputs behind the C ABI (include/codex_p2.h).
+// Datasets and proof inputs behind the C ABI (include/codex_p2.h).
 //
-// Mirrors reference/nim/proof_input/src/gen_input/bn254.nim:21-79 (buildSlotTreeFull, generateProofInput),
-// merkle.nim:21-42,86-100 (merkleProof, mergeMerkleProofs), types.nim:27-37 (padMerkleProof) and
-// json/bn254.nim:19-78 + json/shared.nim:17-25 (exportProofInput).  All hashing runs in the HIP kernels;
-// what stays on the host is index arithmetic, byte packing and text formatting.
+// Mirrors reference/nim/proof_input/src/gen_input/bn254.nim:35-79 (generateProofInput), sample/bn254.nim:16-27
+// (cellIndices), merkle.nim:21-42,86-100 (merkleProof, mergeMerkleProofs), types.nim:27-37 (padMerkleProof) and
+// json/bn254.nim:19-78 + json/shared.nim:17-25 (exportProofInput).  Sampling, path lookup, gathers and cell
+// regeneration run on the device; what stays on the host is byte packing and text formatting.
+//
+// Two ways through: (1) build the dataset, then generate proof inputs for any entropy (objects with accessors);
+// (2) cp2_dataset_build_streamed: the entropy is known up front, so the sampling / gather / download / JSON body of
+// every finished slot overlaps the hashing of the later slots, and only the lines that need ALL slot roots
+// (dataSetRoot, slotProof: gen_input/bn254.nim:49-51,72) are added at the end by cp2_dataset_export_streamed.
 #include <hip/hip_runtime.h>
 
 #include <fcntl.h>
 #include <unistd.h>
 
 #include <algorithm>
-#include <chrono>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
 #include <string>
-#include <thread>
 #include <vector>
 
-#include "internal.hpp"
-#include "kernels.hpp"
+#include "trees.hpp"
 
 using namespace cp2i;
-
-namespace {
-// CP2_TRACE=1: stage timings of the batched proof-input path on stderr (the reference's only tracing is shell
-// `time` around whole steps, workflow/prove.sh:30-37)
-struct StageTimer {
-  bool on;
-  std::chrono::steady_clock::time_point t0;
-  StageTimer() : on(std::getenv("CP2_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
-  void lap(const char* what) {
-    if (!on) return;
-    auto t1 = std::chrono::steady_clock::now();
-    std::fprintf(stderr, "[cp2 trace] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
-    t0 = t1;
-  }
-};
-constexpr uint64_t NO_ROW = ~0ULL;
-constexpr size_t STAGE_BYTES = (size_t)1 << 31;   // device staging buffer for generated / uploaded cells
-
-bool is_pow2(uint64_t x) { return x && !(x & (x - 1)); }
-}  // namespace
-
-// ---------------------------------------------------------------------------------------------
-// slot trees
-// ---------------------------------------------------------------------------------------------
-enum class CellSrc { Fake, Dev, Host, File };
-
-struct cp2_slot_trees {
-  cp2_ctx* ctx = nullptr;
-  size_t n_slots = 0, cell_size = 0, block_size = 0, n_cells = 0, cpb = 0, nblocks = 0;
-  std::vector<size_t> bsizes, tsizes;   // per-tree layer sizes: block tree (cpb leaves), big tree (nblocks leaves)
-  std::vector<size_t> boff, toff;       // element offsets of each layer in `nodes` (layer-major)
-  DevBuf nodes;
-  // where sampled cells come from
-  CellSrc src = CellSrc::Fake;
-  uint64_t dataset_seed = 0, first_slot = 0;
-  const uint8_t* d_cells = nullptr;     // not owned
-  const uint8_t* h_cells = nullptr;     // not owned
-  std::string file_base;
-};
-
-static int trees_layout(cp2_slot_trees* t) {
-  t->bsizes = layer_sizes_of(t->cpb);
-  t->tsizes = layer_sizes_of(t->nblocks);
-  size_t off = 0;
-  t->boff.clear();
-  t->toff.clear();
-  const size_t nb = t->n_slots * t->nblocks;
-  for (size_t k = 0; k < t->bsizes.size(); ++k) {
-    t->boff.push_back(off);
-    if (k + 1 < t->bsizes.size()) off += nb * t->bsizes[k];
-  }
-  // the last block-tree layer (one root per block) is layer 0 of the big trees
-  for (size_t k = 0; k < t->tsizes.size(); ++k) {
-    t->toff.push_back(off);
-    off += t->n_slots * t->tsizes[k];
-  }
-  return t->nodes.alloc(t->ctx, off * 32);
-}
-
-static int trees_check_geometry(size_t cell_size, size_t block_size, size_t n_cells, size_t n_slots) {
-  if (cell_size == 0 || block_size == 0 || n_cells == 0 || n_slots == 0) return CP2_ERR_INVALID;
-  if (block_size % cell_size != 0) return CP2_ERR_INVALID;        // types.nim:104-107 cellsPerBlock assert
-  size_t cpb = block_size / cell_size;
-  if (n_cells % cpb != 0) return CP2_ERR_INVALID;                 // gen_input/bn254.nim:25 assert
-  return CP2_OK;
-}
-
-static cp2_slot_trees* trees_new(cp2_ctx* ctx, size_t n_slots, size_t cell_size, size_t block_size, size_t n_cells) {
-  cp2_slot_trees* t = new (std::nothrow) cp2_slot_trees();
-  if (!t) return nullptr;
-  t->ctx = ctx;
-  t->n_slots = n_slots;
-  t->cell_size = cell_size;
-  t->block_size = block_size;
-  t->n_cells = n_cells;
-  t->cpb = block_size / cell_size;
-  t->nblocks = n_cells / t->cpb;
-  return t;
-}
-
-// all layers above the cell hashes (which are already in nodes[0 .. n_slots*n_cells))
-static int trees_build_layers(cp2_slot_trees* t) {
-  cp2_ctx* ctx = t->ctx;
-  uint8_t* base = t->nodes.u8();
-  const size_t nb = t->n_slots * t->nblocks;
-  for (size_t k = 0; k + 1 < t->bsizes.size(); ++k)   // networkBlockTree, blocks/bn254.nim:60-67
-    CP2_HIP(ctx, cp2k::launch_compress_layer(base + t->boff[k] * 32, base + t->boff[k + 1] * 32, t->bsizes[k], nb, k == 0,
-                                             t->bsizes[k], t->bsizes[k + 1], ctx->stream));
-  for (size_t k = 0; k + 1 < t->tsizes.size(); ++k)   // bigTree, gen_input/bn254.nim:28-29
-    CP2_HIP(ctx, cp2k::launch_compress_layer(base + t->toff[k] * 32, base + t->toff[k + 1] * 32, t->tsizes[k], t->n_slots,
-                                             k == 0, t->tsizes[k], t->tsizes[k + 1], ctx->stream));
-  return CP2_OK;
-}
-
-extern "C" int cp2_slot_trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_slot, size_t n_slots,
-                                         size_t cell_size, size_t block_size, size_t n_cells, cp2_slot_trees** out) try {
-  if (!ctx || !out) return CP2_ERR_INVALID;
-  *out = nullptr;
-  CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
-  CP2_HIP(ctx, hipSetDevice(ctx->device));
-  cp2_slot_trees* t = trees_new(ctx, n_slots, cell_size, block_size, n_cells);
-  if (!t) return CP2_ERR_ALLOC;
-  t->src = CellSrc::Fake;
-  t->dataset_seed = dataset_seed;
-  t->first_slot = first_slot;
-  int st = trees_layout(t);
-  if (st != CP2_OK) { delete t; return st; }
-  const size_t total_cells = n_slots * n_cells;
-  const size_t chunk = std::max<size_t>(1, std::min(total_cells, STAGE_BYTES / cell_size));
-  DevBuf stage;
-  st = stage.alloc(ctx, chunk * cell_size);
-  if (st != CP2_OK) { delete t; return st; }
-  const uint64_t seed0 = cp2_slot_seed(dataset_seed, first_slot);
-  for (size_t c0 = 0; c0 < total_cells; c0 += chunk) {
-    size_t n = std::min(chunk, total_cells - c0);
-    hipError_t e = cp2k::launch_gen_fake_cells(seed0, n_cells, c0, nullptr, n, cell_size, stage.p, ctx->stream);
-    if (e == hipSuccess) e = cp2k::launch_hash_cells(stage.p, cell_size, n, t->nodes.u8() + c0 * 32, ctx->stream);
-    if (e != hipSuccess) { ctx->err = hipGetErrorString(e); delete t; return CP2_ERR_HIP; }
-  }
-  st = trees_build_layers(t);
-  if (st == CP2_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = CP2_ERR_HIP;
-  if (st != CP2_OK) { delete t; return st; }
-  *out = t;
-  return CP2_OK;
-} catch (const std::bad_alloc&) {
-  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
-} catch (...) {
-  return CP2_ERR_INVALID;
-}
-
-extern "C" int cp2_slot_trees_build_dev(cp2_ctx* ctx, const void* d_cells, size_t n_slots, size_t cell_size,
-                                        size_t block_size, size_t n_cells, cp2_slot_trees** out) try {
-  if (!ctx || !out || !d_cells) return CP2_ERR_INVALID;
-  *out = nullptr;
-  CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
-  CP2_HIP(ctx, hipSetDevice(ctx->device));
-  cp2_slot_trees* t = trees_new(ctx, n_slots, cell_size, block_size, n_cells);
-  if (!t) return CP2_ERR_ALLOC;
-  t->src = CellSrc::Dev;
-  t->d_cells = static_cast<const uint8_t*>(d_cells);
-  int st = trees_layout(t);
-  if (st == CP2_OK) {
-    hipError_t e = cp2k::launch_hash_cells(d_cells, cell_size, n_slots * n_cells, t->nodes.p, ctx->stream);
-    if (e != hipSuccess) { ctx->err = hipGetErrorString(e); st = CP2_ERR_HIP; }
-  }
-  if (st == CP2_OK) st = trees_build_layers(t);
-  if (st != CP2_OK) { delete t; return st; }
-  *out = t;   // asynchronous: the caller syncs (cp2_sync) or reads roots (which syncs)
-  return CP2_OK;
-} catch (const std::bad_alloc&) {
-  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
-} catch (...) {
-  return CP2_ERR_INVALID;
-}
-
-// host-side fill of a pinned chunk on a few threads (one memcpy / pread stream is ~14 GB/s here, below PCIe Gen5)
-namespace {
-constexpr int FILL_THREADS = 4;
-template <typename F> void parallel_ranges(size_t n, size_t grain, F f) {
-  int nt = (int)std::min<size_t>(FILL_THREADS, std::max<size_t>(1, n / grain));
-  if (nt <= 1) { f(0, n); return; }
-  std::vector<std::thread> pool;
-  for (int t = 1; t < nt; ++t) pool.emplace_back(f, n * t / nt, n * (t + 1) / nt);
-  f(0, n / nt);
-  for (auto& th : pool) th.join();
-}
-void parallel_memcpy(uint8_t* dst, const uint8_t* src, size_t n) {
-  parallel_ranges(n, (size_t)4 << 20, [&](size_t a, size_t b) { std::memcpy(dst + a, src + a, b - a); });
-}
-// bytes [off, off+n) of file `fd` into dst, zero-filled past EOF (short files read as zeros, slot.nim:61-66)
-void parallel_pread(int fd, uint8_t* dst, size_t off, size_t n) {
-  parallel_ranges(n, (size_t)4 << 20, [&](size_t a, size_t b) {
-    size_t done = a;
-    while (done < b) {
-      ssize_t r = pread(fd, dst + done, b - done, (off_t)(off + done));
-      if (r <= 0) break;
-      done += (size_t)r;
-    }
-    if (done < b) std::memset(dst + done, 0, b - done);
-  });
-}
-}  // namespace
-
-// ---- streaming ingestion ----------------------------------------------------
-// Three overlapped stages over two slots of a ring: the host fills a PINNED buffer (fread or memcpy),
-// a dedicated copy stream moves it to the device, the context's stream hashes it.  While chunk i is copied and
-// hashed the host is already filling chunk i+1, so disk, PCIe and the GPU work concurrently
-// (the reference re-opens the slot file and reads one cell per call, slot.nim:57-68).
-struct IngestPipe {
-  static constexpr size_t CHUNK_BYTES = (size_t)64 << 20;
-  cp2_ctx* ctx = nullptr;
-  hipStream_t copy = nullptr;
-  void* pinned[2] = {nullptr, nullptr};
-  DevBuf dev[2];
-  hipEvent_t copied[2] = {nullptr, nullptr}, hashed[2] = {nullptr, nullptr};
-  size_t chunk = 0, turn = 0;
-
-  ~IngestPipe() {
-    if (!ctx) return;
-    (void)hipStreamSynchronize(ctx->stream);
-    for (int b = 0; b < 2; ++b) {
-      if (copied[b]) (void)hipEventDestroy(copied[b]);
-      if (hashed[b]) (void)hipEventDestroy(hashed[b]);
-      if (pinned[b]) (void)hipHostFree(pinned[b]);
-    }
-    if (copy) (void)hipStreamDestroy(copy);
-  }
-  int init(cp2_ctx* c, size_t cell_size, size_t max_cells) {
-    ctx = c;
-    chunk = std::max<size_t>(1, std::min(max_cells, CHUNK_BYTES / cell_size));
-    CP2_HIP(ctx, hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
-    for (int b = 0; b < 2; ++b) {
-      CP2_HIP(ctx, hipHostMalloc(&pinned[b], chunk * cell_size, hipHostMallocDefault));
-      CP2_TRY(dev[b].alloc(ctx, chunk * cell_size));
-      CP2_HIP(ctx, hipEventCreateWithFlags(&copied[b], hipEventDisableTiming));
-      CP2_HIP(ctx, hipEventCreateWithFlags(&hashed[b], hipEventDisableTiming));
-      CP2_HIP(ctx, hipEventRecord(hashed[b], ctx->stream));
-    }
-    return CP2_OK;
-  }
-  // the pinned buffer the host may fill next (blocks until the kernel that last used this ring slot is done)
-  int acquire(uint8_t** buf) {
-    int b = (int)(turn & 1);
-    CP2_HIP(ctx, hipEventSynchronize(hashed[b]));
-    *buf = static_cast<uint8_t*>(pinned[b]);
-    return CP2_OK;
-  }
-  // ship the filled buffer: m cells -> leaf hashes at `leaves_out`
-  int submit(size_t m, size_t cell_size, uint8_t* leaves_out) {
-    int b = (int)(turn & 1);
-    CP2_HIP(ctx, hipMemcpyAsync(dev[b].p, pinned[b], m * cell_size, hipMemcpyHostToDevice, copy));
-    CP2_HIP(ctx, hipEventRecord(copied[b], copy));
-    CP2_HIP(ctx, hipStreamWaitEvent(ctx->stream, copied[b], 0));
-    CP2_HIP(ctx, cp2k::launch_hash_cells(dev[b].p, cell_size, m, leaves_out, ctx->stream));
-    CP2_HIP(ctx, hipEventRecord(hashed[b], ctx->stream));
-    ++turn;
-    return CP2_OK;
-  }
-};
-
-int cp2i::hash_host_cells_pipelined(cp2_ctx* ctx, const uint8_t* cells, size_t cell_size, size_t n, uint8_t* d_leaves) {
-  IngestPipe pipe;
-  CP2_TRY(pipe.init(ctx, cell_size, n));
-  for (size_t c0 = 0; c0 < n; c0 += pipe.chunk) {
-    size_t m = std::min(pipe.chunk, n - c0);
-    uint8_t* buf = nullptr;
-    CP2_TRY(pipe.acquire(&buf));
-    parallel_memcpy(buf, cells + c0 * cell_size, m * cell_size);
-    CP2_TRY(pipe.submit(m, cell_size, d_leaves + c0 * 32));
-  }
-  return CP2_OK;   // the pipe's destructor waits for the stream
-}
-
-extern "C" int cp2_slot_trees_build_host(cp2_ctx* ctx, const uint8_t* cells, size_t n_slots, size_t cell_size,
-                                         size_t block_size, size_t n_cells, cp2_slot_trees** out) try {
-  if (!ctx || !out || !cells) return CP2_ERR_INVALID;
-  *out = nullptr;
-  CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
-  CP2_HIP(ctx, hipSetDevice(ctx->device));
-  cp2_slot_trees* t = trees_new(ctx, n_slots, cell_size, block_size, n_cells);
-  if (!t) return CP2_ERR_ALLOC;
-  t->src = CellSrc::Host;
-  t->h_cells = cells;
-  int st = trees_layout(t);
-  if (st == CP2_OK) st = hash_host_cells_pipelined(ctx, cells, cell_size, n_slots * n_cells, t->nodes.u8());
-  if (st == CP2_OK) st = trees_build_layers(t);
-  if (st == CP2_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = CP2_ERR_HIP;
-  if (st != CP2_OK) { delete t; return st; }
-  *out = t;
-  return CP2_OK;
-} catch (const std::bad_alloc&) {
-  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
-} catch (...) {
-  return CP2_ERR_INVALID;
-}
-
-// slot files "<base><k>.dat" (dataset.nim:34) streamed through the ingestion pipe; short files read as zeros
-static int trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t first_slot, size_t n_slots, size_t cell_size,
-                             size_t block_size, size_t n_cells, cp2_slot_trees** out) {
-  *out = nullptr;
-  CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
-  CP2_HIP(ctx, hipSetDevice(ctx->device));
-  cp2_slot_trees* t = trees_new(ctx, n_slots, cell_size, block_size, n_cells);
-  if (!t) return CP2_ERR_ALLOC;
-  t->src = CellSrc::File;
-  t->file_base = base;
-  t->first_slot = first_slot;
-  int st = trees_layout(t);
-  {
-    IngestPipe pipe;
-    if (st == CP2_OK) st = pipe.init(ctx, cell_size, n_cells);
-    for (size_t s = 0; st == CP2_OK && s < n_slots; ++s) {
-      std::string fname = base + std::to_string(first_slot + s) + ".dat";
-      int fd = open(fname.c_str(), O_RDONLY);
-      if (fd < 0) { ctx->err = "cannot open " + fname; st = CP2_ERR_IO; break; }
-      for (size_t c0 = 0; st == CP2_OK && c0 < n_cells; c0 += pipe.chunk) {
-        size_t m = std::min(pipe.chunk, n_cells - c0);
-        uint8_t* buf = nullptr;
-        st = pipe.acquire(&buf);
-        if (st != CP2_OK) break;
-        parallel_pread(fd, buf, c0 * cell_size, m * cell_size);
-        st = pipe.submit(m, cell_size, t->nodes.u8() + (s * n_cells + c0) * 32);
-      }
-      close(fd);
-    }
-    if (st == CP2_OK) st = trees_build_layers(t);
-    if (st == CP2_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = CP2_ERR_HIP;
-  }
-  if (st != CP2_OK) { delete t; return st; }
-  *out = t;
-  return CP2_OK;
-}
-
-// ---- persisted slot trees ---------------------------------------------------
-// File = header + every node of the layer-major buffer (canonical 32-byte elements).  A later run with new
-// entropy then needs only 2 permutations per sample plus gathers instead of re-hashing every slot
-// (the reference re-hashes all slots per run AND the proving slot once per sample, gen_input/bn254.nim:42,57).
-namespace {
-struct TreeFileHeader {
-  char magic[8];            // "CP2TREE1"
-  uint64_t n_slots, cell_size, block_size, n_cells;
-  uint64_t src;             // CellSrc
-  uint64_t dataset_seed, first_slot;
-  uint64_t file_base_len;   // bytes following the header
-  uint64_t n_nodes;
-};
-}  // namespace
-
-extern "C" int cp2_slot_trees_save(cp2_slot_trees* t, const char* path) try {
-  if (!t || !path) return CP2_ERR_INVALID;
-  cp2_ctx* ctx = t->ctx;
-  CP2_HIP(ctx, hipSetDevice(ctx->device));
-  TreeFileHeader h{};
-  std::memcpy(h.magic, "CP2TREE1", 8);
-  h.n_slots = t->n_slots; h.cell_size = t->cell_size; h.block_size = t->block_size; h.n_cells = t->n_cells;
-  h.src = (uint64_t)t->src; h.dataset_seed = t->dataset_seed; h.first_slot = t->first_slot;
-  h.file_base_len = t->file_base.size();
-  h.n_nodes = t->nodes.bytes / 32;
-  std::vector<uint8_t> host(t->nodes.bytes);
-  CP2_HIP(ctx, hipMemcpyAsync(host.data(), t->nodes.p, host.size(), hipMemcpyDeviceToHost, ctx->stream));
-  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  FILE* f = std::fopen(path, "wb");
-  if (!f) return CP2_ERR_IO;
-  bool ok = std::fwrite(&h, sizeof h, 1, f) == 1 &&
-            (h.file_base_len == 0 || std::fwrite(t->file_base.data(), 1, h.file_base_len, f) == h.file_base_len) &&
-            std::fwrite(host.data(), 1, host.size(), f) == host.size();
-  ok = (std::fclose(f) == 0) && ok;
-  return ok ? CP2_OK : CP2_ERR_IO;
-} catch (const std::bad_alloc&) {
-  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
-} catch (...) {
-  return CP2_ERR_INVALID;
-}
-
-extern "C" int cp2_slot_trees_load(cp2_ctx* ctx, const char* path, cp2_slot_trees** out) try {
-  if (!ctx || !path || !out) return CP2_ERR_INVALID;
-  *out = nullptr;
-  FILE* f = std::fopen(path, "rb");
-  if (!f) return CP2_ERR_IO;
-  TreeFileHeader h{};
-  if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, "CP2TREE1", 8) != 0 || h.file_base_len > 4096 ||
-      trees_check_geometry(h.cell_size, h.block_size, h.n_cells, h.n_slots) != CP2_OK || h.src > (uint64_t)CellSrc::File) {
-    std::fclose(f);
-    return CP2_ERR_IO;
-  }
-  std::string base(h.file_base_len, '\0');
-  if (h.file_base_len && std::fread(&base[0], 1, h.file_base_len, f) != h.file_base_len) { std::fclose(f); return CP2_ERR_IO; }
-  if (hipSetDevice(ctx->device) != hipSuccess) { std::fclose(f); return CP2_ERR_HIP; }
-  cp2_slot_trees* t = trees_new(ctx, h.n_slots, h.cell_size, h.block_size, h.n_cells);
-  if (!t) { std::fclose(f); return CP2_ERR_ALLOC; }
-  t->src = (CellSrc)h.src;
-  t->dataset_seed = h.dataset_seed;
-  t->first_slot = h.first_slot;
-  t->file_base = base;
-  int st = trees_layout(t);
-  if (st == CP2_OK && t->nodes.bytes / 32 != h.n_nodes) st = CP2_ERR_IO;
-  std::vector<uint8_t> host;
-  if (st == CP2_OK) {
-    host.resize(t->nodes.bytes);
-    if (std::fread(host.data(), 1, host.size(), f) != host.size()) st = CP2_ERR_IO;
-  }
-  std::fclose(f);
-  if (st == CP2_OK) {
-    hipError_t e = hipMemcpyAsync(t->nodes.p, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { ctx->err = hipGetErrorString(e); st = CP2_ERR_HIP; }
-  }
-  if (st != CP2_OK) { delete t; return st; }
-  *out = t;
-  return CP2_OK;
-} catch (const std::bad_alloc&) {
-  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
-} catch (...) {
-  return CP2_ERR_INVALID;
-}
-
-// trees loaded from a cache that were built from caller memory have no cell source until one is attached
-extern "C" int cp2_slot_trees_attach_cells(cp2_slot_trees* t, const uint8_t* host_cells, const void* dev_cells) try {
-  if (!t || (host_cells && dev_cells)) return CP2_ERR_INVALID;
-  if (host_cells) { t->src = CellSrc::Host; t->h_cells = host_cells; t->d_cells = nullptr; }
-  else if (dev_cells) { t->src = CellSrc::Dev; t->d_cells = static_cast<const uint8_t*>(dev_cells); t->h_cells = nullptr; }
-  else return CP2_ERR_INVALID;
-  return CP2_OK;
-} catch (const std::bad_alloc&) {
-  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
-} catch (...) {
-  return CP2_ERR_INVALID;
-}
-
-extern "C" void cp2_slot_trees_free(cp2_slot_trees* t) {
-  if (!t) return;
-  (void)hipSetDevice(t->ctx->device);
-  (void)hipStreamSynchronize(t->ctx->stream);
-  delete t;
-}
-
-extern "C" size_t cp2_slot_trees_count(const cp2_slot_trees* t) { return t ? t->n_slots : 0; }
-extern "C" size_t cp2_slot_trees_depth(const cp2_slot_trees* t) {
-  return t ? (t->bsizes.size() - 1) + (t->tsizes.size() - 1) : 0;
-}
-
-extern "C" const void* cp2_slot_trees_roots_dev(const cp2_slot_trees* t) {
-  return t ? t->nodes.u8() + t->toff.back() * 32 : nullptr;
-}
-
-extern "C" int cp2_slot_trees_roots(cp2_slot_trees* t, uint8_t* out) try {
-  if (!t || !out) return CP2_ERR_INVALID;
-  cp2_ctx* ctx = t->ctx;
-  CP2_HIP(ctx, hipSetDevice(ctx->device));
-  CP2_HIP(ctx, hipMemcpyAsync(out, cp2_slot_trees_roots_dev(t), t->n_slots * 32, hipMemcpyDeviceToHost, ctx->stream));
-  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return CP2_OK;
-} catch (const std::bad_alloc&) {
-  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
-} catch (...) {
-  return CP2_ERR_INVALID;
-}
-
-// node-row indices of the merged path of `cell` in slot `slot` (merkle.nim:21-42 twice, then :86-100)
-static void path_rows(const cp2_slot_trees* t, size_t slot, uint64_t cell, size_t max_depth, uint64_t* rows) {
-  size_t b = cell / t->cpb, j = cell % t->cpb, d = 0;
-  size_t m = t->cpb;
-  for (size_t k = 0; k + 1 < t->bsizes.size(); ++k, ++d) {
-    size_t sib = j ^ 1;
-    rows[d] = (sib < m) ? t->boff[k] + (slot * t->nblocks + b) * t->bsizes[k] + sib : NO_ROW;   // zero if out of range
-    j >>= 1;
-    m = (m + 1) >> 1;
-  }
-  size_t i = b;
-  m = t->nblocks;
-  for (size_t k = 0; k + 1 < t->tsizes.size(); ++k, ++d) {
-    size_t sib = i ^ 1;
-    rows[d] = (sib < m) ? t->toff[k] + slot * t->tsizes[k] + sib : NO_ROW;
-    i >>= 1;
-    m = (m + 1) >> 1;
-  }
-  for (; d < max_depth; ++d) rows[d] = NO_ROW;                                                  // padMerkleProof
-}
-
-extern "C" int cp2_slot_trees_paths(cp2_slot_trees* t, size_t slot, const uint64_t* cell_idx, size_t n, size_t max_depth,
-                                    uint8_t* out, uint8_t* leaf_hashes) try {
-  if (!t || (n && (!cell_idx || !out)) || slot >= t->n_slots) return CP2_ERR_INVALID;
-  if (cp2_slot_trees_depth(t) > max_depth) return CP2_ERR_INVALID;     // types.nim:29 assert(pad >= 0)
-  if (n == 0) return CP2_OK;
-  cp2_ctx* ctx = t->ctx;
-  CP2_HIP(ctx, hipSetDevice(ctx->device));
-  const size_t per = max_depth + 1;                                     // + the leaf itself
-  std::vector<uint64_t> rows(n * per);
-  for (size_t i = 0; i < n; ++i) {
-    if (cell_idx[i] >= t->n_cells) return CP2_ERR_INVALID;              // merkle.nim:27 assert
-    path_rows(t, slot, cell_idx[i], max_depth, &rows[i * per]);
-    rows[i * per + max_depth] = slot * t->n_cells + cell_idx[i];
-  }
-  DevBuf d_rows, d_out;
-  CP2_TRY(d_rows.alloc(ctx, rows.size() * 8));
-  CP2_TRY(d_out.alloc(ctx, rows.size() * 32));
-  CP2_HIP(ctx, hipMemcpyAsync(d_rows.p, rows.data(), rows.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-  CP2_HIP(ctx, cp2k::launch_gather_rows(t->nodes.p, static_cast<const uint64_t*>(d_rows.p), rows.size(), 32, d_out.p, ctx->stream));
-  std::vector<uint8_t> tmp(rows.size() * 32);
-  CP2_HIP(ctx, hipMemcpyAsync(tmp.data(), d_out.p, tmp.size(), hipMemcpyDeviceToHost, ctx->stream));
-  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  for (size_t i = 0; i < n; ++i) {
-    std::memcpy(out + i * max_depth * 32, &tmp[i * per * 32], max_depth * 32);
-    if (leaf_hashes) std::memcpy(leaf_hashes + i * 32, &tmp[(i * per + max_depth) * 32], 32);
-  }
-  return CP2_OK;
-} catch (const std::bad_alloc&) {
-  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
-} catch (...) {
-  return CP2_ERR_INVALID;
-}
-
-// the bytes of n cells given by global index g = local_slot * n_cells + cell (slotLoadCellData, slot.nim:57-68)
-static int trees_cells_global(cp2_slot_trees* t, const uint64_t* g, size_t n, uint8_t* out) {
-  cp2_ctx* ctx = t->ctx;
-  const size_t cs = t->cell_size;
-  if (n == 0) return CP2_OK;
-  switch (t->src) {
-    case CellSrc::Host:
-      if (!t->h_cells) return CP2_ERR_INVALID;   // loaded from a cache: attach the cells first
-      for (size_t i = 0; i < n; ++i) std::memcpy(out + i * cs, t->h_cells + g[i] * cs, cs);
-      return CP2_OK;
-    case CellSrc::File: {
-      FILE* f = nullptr;
-      size_t open_slot = ~(size_t)0;
-      for (size_t i = 0; i < n; ++i) {
-        size_t slot = g[i] / t->n_cells, cell = g[i] % t->n_cells;
-        if (slot != open_slot) {
-          if (f) std::fclose(f);
-          std::string fname = t->file_base + std::to_string(t->first_slot + slot) + ".dat";
-          f = std::fopen(fname.c_str(), "rb");
-          if (!f) { ctx->err = "cannot open " + fname; return CP2_ERR_IO; }
-          open_slot = slot;
-        }
-        std::memset(out + i * cs, 0, cs);
-        if (std::fseek(f, (long)(cell * cs), SEEK_SET) == 0) (void)!std::fread(out + i * cs, 1, cs, f);
-      }
-      if (f) std::fclose(f);
-      return CP2_OK;
-    }
-    case CellSrc::Fake:
-    case CellSrc::Dev: {
-      DevBuf d_g, d_out;
-      CP2_TRY(d_g.alloc(ctx, n * 8));
-      CP2_TRY(d_out.alloc(ctx, n * cs));
-      CP2_HIP(ctx, hipMemcpyAsync(d_g.p, g, n * 8, hipMemcpyHostToDevice, ctx->stream));
-      if (t->src == CellSrc::Dev && !t->d_cells) return CP2_ERR_INVALID;   // loaded from a cache: attach the cells first
-      if (t->src == CellSrc::Fake) {
-        CP2_HIP(ctx, cp2k::launch_gen_fake_cells(cp2_slot_seed(t->dataset_seed, t->first_slot), t->n_cells, 0,
-                                                 static_cast<const uint64_t*>(d_g.p), n, cs, d_out.p, ctx->stream));
-      } else if ((cs & 3) == 0) {
-        CP2_HIP(ctx, cp2k::launch_gather_rows(t->d_cells, static_cast<const uint64_t*>(d_g.p), n, cs, d_out.p, ctx->stream));
-      } else {
-        for (size_t i = 0; i < n; ++i)
-          CP2_HIP(ctx, hipMemcpyAsync(d_out.u8() + i * cs, t->d_cells + g[i] * cs, cs, hipMemcpyDeviceToDevice, ctx->stream));
-      }
-      CP2_HIP(ctx, hipMemcpyAsync(out, d_out.p, n * cs, hipMemcpyDeviceToHost, ctx->stream));
-      CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      return CP2_OK;
-    }
-  }
-  return CP2_ERR_INVALID;
-}
 
 // ---------------------------------------------------------------------------------------------
 // dataset
@@ -581,16 +41,22 @@ struct cp2_dataset {
   bool have_roots = false;
   std::vector<size_t> dsizes;                 // dataset-tree layer sizes
   std::vector<uint8_t> dlayers;               // all dataset-tree layers, bottom first (host copy)
+  // streamed build: one JSON body (", \"cellData\": ... }") per local slot, made while later slots were hashing
+  bool prepared = false;
+  uint8_t prep_entropy[32] = {};
+  std::vector<std::string> bodies;
+  ~cp2_dataset() { cp2_slot_trees_free(trees); }
 };
 
-extern "C" int cp2_dataset_build(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local,
-                                 cp2_dataset** out) try {
-  if (!ctx || !cfg || !out) return CP2_ERR_INVALID;
-  *out = nullptr;
+static int dataset_check(const cp2_config* cfg, uint64_t first_slot, uint64_t n_local) {
   if (n_local == 0 || first_slot + n_local > cfg->n_slots) return CP2_ERR_INVALID;
   if (cfg->max_depth < 0 || cfg->max_log2_nslots < 0) return CP2_ERR_INVALID;
+  return CP2_OK;
+}
+
+static cp2_dataset* dataset_new(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local) {
   cp2_dataset* ds = new (std::nothrow) cp2_dataset();
-  if (!ds) return CP2_ERR_ALLOC;
+  if (!ds) return nullptr;
   ds->ctx = ctx;
   ds->cfg = *cfg;
   ds->from_file = cfg->file_base != nullptr;
@@ -598,13 +64,25 @@ extern "C" int cp2_dataset_build(cp2_ctx* ctx, const cp2_config* cfg, uint64_t f
   ds->cfg.file_base = nullptr;
   ds->first_slot = first_slot;
   ds->n_local = n_local;
-  int st;
+  return ds;
+}
+
+static int dataset_build_trees(cp2_dataset* ds, size_t group, const SlotsDone& done) {
+  const cp2_config& c = ds->cfg;
   if (ds->from_file)
-    st = trees_build_files(ctx, ds->file_base, first_slot, n_local, cfg->cell_size, cfg->block_size, cfg->n_cells, &ds->trees);
-  else
-    st = cp2_slot_trees_build_fake(ctx, cfg->seed, first_slot, n_local, cfg->cell_size, cfg->block_size, cfg->n_cells, &ds->trees);
-  if (st != CP2_OK) { delete ds; return st; }
-  *out = ds;
+    return trees_build_files(ds->ctx, ds->file_base, ds->first_slot, ds->n_local, c.cell_size, c.block_size, c.n_cells, group, done, &ds->trees);
+  return trees_build_fake(ds->ctx, c.seed, ds->first_slot, ds->n_local, c.cell_size, c.block_size, c.n_cells, group, done, &ds->trees);
+}
+
+extern "C" int cp2_dataset_build(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local,
+                                 cp2_dataset** out) try {
+  if (!ctx || !cfg || !out) return CP2_ERR_INVALID;
+  *out = nullptr;
+  CP2_TRY(dataset_check(cfg, first_slot, n_local));
+  std::unique_ptr<cp2_dataset> ds(dataset_new(ctx, cfg, first_slot, n_local));
+  if (!ds) return CP2_ERR_ALLOC;
+  CP2_TRY(dataset_build_trees(ds.get(), 0, nullptr));
+  *out = ds.release();
   return CP2_OK;
 } catch (const std::bad_alloc&) {
   return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
@@ -612,13 +90,13 @@ extern "C" int cp2_dataset_build(cp2_ctx* ctx, const cp2_config* cfg, uint64_t f
   return CP2_ERR_INVALID;
 }
 
-// Same as cp2_dataset_build, but the slot trees are read from `cache_path` when that file exists and matches
-// the configuration, and written there after a build otherwise.
+// Same as cp2_dataset_build, but the slot trees are read from `cache_path` when that file exists, is intact and
+// matches the configuration AND (SlotFile source) the slot files' sizes and mtimes; written there after a build otherwise.
 extern "C" int cp2_dataset_build_cached(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local,
                                         const char* cache_path, cp2_dataset** out) try {
   if (!ctx || !cfg || !out || !cache_path) return CP2_ERR_INVALID;
   *out = nullptr;
-  if (n_local == 0 || first_slot + n_local > cfg->n_slots) return CP2_ERR_INVALID;
+  CP2_TRY(dataset_check(cfg, first_slot, n_local));
   cp2_slot_trees* t = nullptr;
   if (cp2_slot_trees_load(ctx, cache_path, &t) == CP2_OK) {
     const bool from_file = cfg->file_base != nullptr;
@@ -627,15 +105,8 @@ extern "C" int cp2_dataset_build_cached(cp2_ctx* ctx, const cp2_config* cfg, uin
                  (from_file ? (t->src == CellSrc::File && t->file_base == cfg->file_base)
                             : (t->src == CellSrc::Fake && t->dataset_seed == cfg->seed));
     if (match) {
-      cp2_dataset* ds = new (std::nothrow) cp2_dataset();
+      cp2_dataset* ds = dataset_new(ctx, cfg, first_slot, n_local);
       if (!ds) { cp2_slot_trees_free(t); return CP2_ERR_ALLOC; }
-      ds->ctx = ctx;
-      ds->cfg = *cfg;
-      ds->from_file = from_file;
-      if (from_file) ds->file_base = cfg->file_base;
-      ds->cfg.file_base = nullptr;
-      ds->first_slot = first_slot;
-      ds->n_local = n_local;
       ds->trees = t;
       *out = ds;
       return CP2_OK;
@@ -652,11 +123,7 @@ extern "C" int cp2_dataset_build_cached(cp2_ctx* ctx, const cp2_config* cfg, uin
   return CP2_ERR_INVALID;
 }
 
-extern "C" void cp2_dataset_free(cp2_dataset* ds) {
-  if (!ds) return;
-  cp2_slot_trees_free(ds->trees);
-  delete ds;
-}
+extern "C" void cp2_dataset_free(cp2_dataset* ds) { delete ds; }
 
 extern "C" int cp2_dataset_local_roots(cp2_dataset* ds, uint8_t* out) try {
   if (!ds || !out) return CP2_ERR_INVALID;
@@ -703,22 +170,95 @@ extern "C" int cp2_dataset_root(cp2_dataset* ds, uint8_t out[32]) try {
 }
 
 // ---------------------------------------------------------------------------------------------
+// sampling + gathers on the device, results in pinned host memory
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// device scratch of one sampling pass over up to `cap` (slot, counter) pairs
+struct SampleDev {
+  DevBuf entropy, slots, idx, gcell, rows, paths, cells;
+  size_t cap = 0;
+  int init(cp2_ctx* ctx, size_t cap_items, size_t ns, size_t md, size_t cs, bool need_cells) {
+    cap = cap_items * ns;
+    CP2_TRY(entropy.scratch(ctx, 32));
+    CP2_TRY(slots.scratch(ctx, std::max<size_t>(cap_items, 1) * 8));
+    CP2_TRY(idx.scratch(ctx, std::max<size_t>(cap, 1) * 8));
+    CP2_TRY(gcell.scratch(ctx, std::max<size_t>(cap, 1) * 8));
+    CP2_TRY(rows.scratch(ctx, std::max<size_t>(cap * md, 1) * 8));
+    CP2_TRY(paths.scratch(ctx, std::max<size_t>(cap * md, 1) * 32));
+    if (need_cells) CP2_TRY(cells.scratch(ctx, std::max<size_t>(cap * cs, 1)));
+    return CP2_OK;
+  }
+};
+
+// pinned host landing zone of one pass
+struct SampleHost {
+  PinBuf idx, paths, cells;
+  hipStream_t stream = nullptr;   // downloads into these buffers are enqueued here: drained before the blocks go back to the pool
+  ~SampleHost() { if (stream) (void)hipStreamSynchronize(stream); }
+  int init(cp2_ctx* ctx, size_t cap_items, size_t ns, size_t md, size_t cs, bool need_cells) {
+    const size_t cap = cap_items * ns;
+    CP2_TRY(idx.alloc(ctx, std::max<size_t>(cap, 1) * 8));
+    CP2_TRY(paths.alloc(ctx, std::max<size_t>(cap * md, 1) * 32));
+    if (need_cells) CP2_TRY(cells.alloc(ctx, std::max<size_t>(cap * cs, 1)));
+    return CP2_OK;
+  }
+};
+
+// Enqueue on `st`: cellIndices for n_items slots (explicit batch-local list `h_slots`, or the range starting at slot0),
+// path rows, the path gather, the regeneration / gather of the sampled cells (device-resident sources), and the
+// downloads into `host`.  Nothing is synchronised.  d.entropy must already hold the entropy.
+int enqueue_sampling(cp2_slot_trees* t, const cp2k::TreeGeom& g, SampleDev& d, SampleHost& host, const uint64_t* h_slots, uint64_t slot0,
+                     size_t n_items, size_t ns, size_t md, bool fetch_cells, hipStream_t st) {
+  cp2_ctx* ctx = t->ctx;
+  const size_t total = n_items * ns, cs = t->cell_size;
+  if (total == 0) return CP2_OK;
+  host.stream = st;
+  const uint64_t* d_slots = nullptr;
+  if (h_slots) {
+    CP2_HIP(ctx, hipMemcpyAsync(d.slots.p, h_slots, n_items * 8, hipMemcpyHostToDevice, st));
+    d_slots = static_cast<const uint64_t*>(d.slots.p);
+  }
+  uint64_t* idx = static_cast<uint64_t*>(d.idx.p);
+  uint64_t* gcell = static_cast<uint64_t*>(d.gcell.p);
+  uint64_t* rows = static_cast<uint64_t*>(d.rows.p);
+  CP2_HIP(ctx, cp2k::launch_sample_paths(g, t->nodes.p, d.entropy.p, d_slots, slot0, n_items, (uint32_t)ns, (uint32_t)md, idx, gcell, rows, st));
+  CP2_HIP(ctx, cp2k::launch_gather_rows(t->nodes.p, rows, total * md, 32, d.paths.p, st));
+  CP2_HIP(ctx, hipMemcpyAsync(host.idx.p, idx, total * 8, hipMemcpyDeviceToHost, st));
+  CP2_HIP(ctx, hipMemcpyAsync(host.paths.p, d.paths.p, total * md * 32, hipMemcpyDeviceToHost, st));
+  if (!fetch_cells) return CP2_OK;   // host-side sources: the caller reads the sampled cells itself
+  if (t->src == CellSrc::Fake) {
+    CP2_HIP(ctx, cp2k::launch_gen_fake_cells(cp2_slot_seed(t->dataset_seed, t->first_slot), t->n_cells, 0, gcell, total, cs, d.cells.p, st));
+  } else if (t->src == CellSrc::Dev && t->d_cells) {
+    CP2_HIP(ctx, cp2k::launch_gather_rows(t->d_cells, gcell, total, cs, d.cells.p, st));
+  } else {
+    return CP2_ERR_INVALID;
+  }
+  CP2_HIP(ctx, hipMemcpyAsync(host.cells.p, d.cells.p, total * cs, hipMemcpyDeviceToHost, st));
+  return CP2_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
 // proof input
 // ---------------------------------------------------------------------------------------------
-// cell bytes and Merkle paths of a whole batch live in one uninitialised allocation that every proof input of
-// the batch shares (no zero-fill, one device-to-host copy, no per-slot copies)
+// cell bytes, Merkle paths and indices of a whole batch live in pinned blocks that every proof input of the batch
+// shares (one download each, no per-slot copies); the blocks return to the context's pool with the last reference
 struct BatchStore {
-  std::unique_ptr<uint8_t[]> cells, paths;
+  PinBuf idx, paths, cells;
+  std::vector<uint8_t> cells_heap;   // SlotFile / Host sources: sampled cells are read on the host
 };
 
 struct cp2_proof_input {
   cp2_config cfg{};
   uint64_t slot_idx = 0;
   uint8_t entropy[32], dataset_root[32], slot_root[32];
-  std::vector<uint64_t> indices;
+  size_t n_samples = 0;
   std::vector<uint8_t> slot_proof;
   std::shared_ptr<BatchStore> store;
-  const uint8_t* cell_data = nullptr;   // nSamples x cellSize, inside store->cells
+  const uint64_t* indices = nullptr;    // nSamples, inside store->idx
+  const uint8_t* cell_data = nullptr;   // nSamples x cellSize, inside store->cells / cells_heap
   const uint8_t* paths = nullptr;       // nSamples x maxDepth x 32, inside store->paths
 };
 
@@ -733,6 +273,42 @@ static void fill_slot_proof(const cp2_dataset* ds, uint64_t slot_idx, std::vecto
     k >>= 1;
     m = (m + 1) >> 1;
   }
+}
+
+// sampled cells of the host-side sources: global index g = local_slot * n_cells + cell (slotLoadCellData, slot.nim:57-68)
+static int host_cells_global(cp2_slot_trees* t, const uint64_t* g, size_t n, uint8_t* out) {
+  cp2_ctx* ctx = t->ctx;
+  const size_t cs = t->cell_size;
+  if (t->src == CellSrc::Host) {
+    if (!t->h_cells) return CP2_ERR_INVALID;   // loaded from a cache: attach the cells first
+    for (size_t i = 0; i < n; ++i) std::memcpy(out + i * cs, t->h_cells + g[i] * cs, cs);
+    return CP2_OK;
+  }
+  if (t->src == CellSrc::File) {
+    int fd = -1;
+    size_t open_slot = ~(size_t)0;
+    for (size_t i = 0; i < n; ++i) {
+      size_t slot = g[i] / t->n_cells, cell = g[i] % t->n_cells;
+      if (slot != open_slot) {
+        if (fd >= 0) close(fd);
+        std::string fname = slot_file_name(t->file_base, t->first_slot + slot);
+        fd = open(fname.c_str(), O_RDONLY);
+        if (fd < 0) { ctx->err = "cannot open " + fname; return CP2_ERR_IO; }
+        open_slot = slot;
+      }
+      read_file_cell(fd, cs, cell, out + i * cs);
+    }
+    if (fd >= 0) close(fd);
+    return CP2_OK;
+  }
+  if (t->src == CellSrc::Dev) {   // cell sizes the row gather cannot take: plain copies
+    if (!t->d_cells) return CP2_ERR_INVALID;
+    for (size_t i = 0; i < n; ++i)
+      CP2_HIP(ctx, hipMemcpyAsync(out + i * cs, t->d_cells + g[i] * cs, cs, hipMemcpyDeviceToHost, ctx->stream));
+    CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CP2_OK;
+  }
+  return CP2_ERR_INVALID;
 }
 
 // generateProofInput (gen_input/bn254.nim:35-79) for `n` slots of the dataset at once: one sampling launch,
@@ -755,57 +331,37 @@ extern "C" int cp2_proof_inputs_generate_batch(cp2_dataset* ds, const uint64_t* 
   const size_t ns = cfg.n_samples, md = (size_t)cfg.max_depth, cs = cfg.cell_size, total = n * ns;
 
   StageTimer trace;
-  // ---- sampling: cellIndices for every (slot, counter), sample/bn254.nim:16-27
-  std::vector<uint64_t> indices(total);
-  if (total) {
-    std::vector<uint8_t> felts(total * 96, 0), dig(total * 32);
-    for (size_t i = 0; i < n; ++i) {
-      const uint8_t* root = &ds->dlayers[slot_idx[i] * 32];
-      for (size_t c = 0; c < ns; ++c) {
-        uint8_t* f = &felts[(i * ns + c) * 96];
-        std::memcpy(f, entropy, 32);
-        std::memcpy(f + 32, root, 32);
-        uint64_t counter = c + 1;
-        std::memcpy(f + 64, &counter, 8);
-      }
-    }
-    CP2_TRY(cp2_sponge2_felts_batch(ctx, felts.data(), 3, total, dig.data()));
-    for (size_t k = 0; k < total; ++k) {
-      uint64_t lo;
-      std::memcpy(&lo, &dig[32 * k], 8);
-      indices[k] = lo & (cfg.n_cells - 1);
-    }
-  }
-  trace.lap("sampling");
-  // ---- paths (one gather) and cells (one fetch)
   auto store = std::make_shared<BatchStore>();
-  store->paths.reset(new (std::nothrow) uint8_t[std::max<size_t>(total * md * 32, 1)]);
-  store->cells.reset(new (std::nothrow) uint8_t[std::max<size_t>(total * cs, 1)]);
-  if (!store->paths || !store->cells) return CP2_ERR_ALLOC;
-  uint8_t* paths = store->paths.get();
-  uint8_t* cells = store->cells.get();
-  trace.lap("host buffers");
+  const bool dev_cells = t->src == CellSrc::Fake ||
+                         (t->src == CellSrc::Dev && t->d_cells && (cs & 3) == 0 && (reinterpret_cast<uintptr_t>(t->d_cells) & 3) == 0);
   if (total) {
-    std::vector<uint64_t> rows(total * md);
-    std::vector<uint64_t> gcell(total);
-    for (size_t i = 0; i < n; ++i) {
-      size_t local = slot_idx[i] - ds->first_slot;
-      for (size_t c = 0; c < ns; ++c) {
-        path_rows(t, local, indices[i * ns + c], md, &rows[(i * ns + c) * md]);
-        gcell[i * ns + c] = local * t->n_cells + indices[i * ns + c];
-      }
-    }
-    DevBuf d_rows, d_out;
-    CP2_TRY(d_rows.alloc(ctx, rows.size() * 8));
-    CP2_TRY(d_out.alloc(ctx, rows.size() * 32));
-    CP2_HIP(ctx, hipMemcpyAsync(d_rows.p, rows.data(), rows.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    CP2_HIP(ctx, cp2k::launch_gather_rows(t->nodes.p, static_cast<const uint64_t*>(d_rows.p), rows.size(), 32, d_out.p, ctx->stream));
-    CP2_HIP(ctx, hipMemcpyAsync(paths, d_out.p, total * md * 32, hipMemcpyDeviceToHost, ctx->stream));
+    cp2k::TreeGeom g;
+    trees_geom(t, &g);
+    std::vector<uint64_t> local(n);
+    for (size_t i = 0; i < n; ++i) local[i] = slot_idx[i] - ds->first_slot;
+    SampleDev dev;
+    SampleHost host;
+    CP2_TRY(dev.init(ctx, n, ns, md, cs, dev_cells));
+    CP2_TRY(host.init(ctx, n, ns, md, cs, dev_cells));
+    CP2_HIP(ctx, hipMemcpyAsync(dev.entropy.p, entropy, 32, hipMemcpyHostToDevice, ctx->stream));
+    CP2_TRY(enqueue_sampling(t, g, dev, host, local.data(), 0, n, ns, md, dev_cells, ctx->stream));
     CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    trace.lap("path rows + gather + D2H");
-    CP2_TRY(trees_cells_global(t, gcell.data(), total, cells));
-    trace.lap("cells fetch + D2H");
+    trace.lap("sampling + gathers + downloads");
+    store->idx.swap(host.idx);
+    store->paths.swap(host.paths);
+    if (dev_cells) {
+      store->cells.swap(host.cells);
+    } else {
+      const uint64_t* idx = static_cast<const uint64_t*>(store->idx.p);
+      std::vector<uint64_t> gcell(total);
+      for (size_t i = 0; i < n; ++i)
+        for (size_t c = 0; c < ns; ++c) gcell[i * ns + c] = local[i] * t->n_cells + idx[i * ns + c];
+      store->cells_heap.resize(total * cs);
+      CP2_TRY(host_cells_global(t, gcell.data(), total, store->cells_heap.data()));
+      trace.lap("cells read on the host");
+    }
   }
+  const uint8_t* cells = dev_cells ? store->cells.u8() : store->cells_heap.data();
   // ---- split
   for (size_t i = 0; i < n; ++i) {
     cp2_proof_input* p = new (std::nothrow) cp2_proof_input();
@@ -819,10 +375,13 @@ extern "C" int cp2_proof_inputs_generate_batch(cp2_dataset* ds, const uint64_t* 
     std::memcpy(p->dataset_root, &ds->dlayers[ds->dlayers.size() - 32], 32);
     std::memcpy(p->slot_root, &ds->dlayers[slot_idx[i] * 32], 32);      // layer 0 of the dataset tree = slot roots
     fill_slot_proof(ds, slot_idx[i], p->slot_proof);
-    p->indices.assign(indices.begin() + i * ns, indices.begin() + (i + 1) * ns);
+    p->n_samples = ns;
     p->store = store;
-    p->cell_data = cells + i * ns * cs;
-    p->paths = paths + i * ns * md * 32;
+    if (total) {
+      p->indices = static_cast<const uint64_t*>(store->idx.p) + i * ns;
+      p->cell_data = cells + i * ns * cs;
+      p->paths = store->paths.u8() + i * ns * md * 32;
+    }
     out[i] = p;
   }
   trace.lap("split into proof inputs");
@@ -850,13 +409,11 @@ extern "C" int cp2_proof_input_roots(const cp2_proof_input* p, uint8_t dataset_r
   if (slot_root) std::memcpy(slot_root, p->slot_root, 32);
   if (entropy) std::memcpy(entropy, p->entropy, 32);
   return CP2_OK;
-} catch (const std::bad_alloc&) {
-  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
 } catch (...) {
   return CP2_ERR_INVALID;
 }
-extern "C" size_t cp2_proof_input_nsamples(const cp2_proof_input* p) { return p ? p->indices.size() : 0; }
-extern "C" const uint64_t* cp2_proof_input_cell_indices(const cp2_proof_input* p) { return p ? p->indices.data() : nullptr; }
+extern "C" size_t cp2_proof_input_nsamples(const cp2_proof_input* p) { return p ? p->n_samples : 0; }
+extern "C" const uint64_t* cp2_proof_input_cell_indices(const cp2_proof_input* p) { return p ? p->indices : nullptr; }
 extern "C" const uint8_t* cp2_proof_input_cell_data(const cp2_proof_input* p) { return p ? p->cell_data : nullptr; }
 extern "C" const uint8_t* cp2_proof_input_merkle_paths(const cp2_proof_input* p) { return p ? p->paths : nullptr; }
 extern "C" const uint8_t* cp2_proof_input_slot_proof(const cp2_proof_input* p) { return p ? p->slot_proof.data() : nullptr; }
@@ -904,38 +461,57 @@ void write_felt_list(std::string& s, const std::string& prefix, const uint8_t* f
   s += indent + "]\n";
 }
 
-}  // namespace
-
-static void proof_input_text(const cp2_proof_input* p, std::string& s) {
-  const cp2_config& cfg = p->cfg;
-  s.clear();
-  s.reserve((p->indices.size() * (cp2_felts_per_bytes(cfg.cell_size) + (size_t)cfg.max_depth) + 64) * 90);
+// "{" .. the slotProof list: everything that needs the dataset tree (json/bn254.nim:59-66)
+void text_head(std::string& s, const cp2_config& cfg, uint64_t slot_idx, const uint8_t* dataset_root, const uint8_t* entropy,
+               const uint8_t* slot_root, const uint8_t* slot_proof) {
   s += "{\n";
-  s += "  \"dataSetRoot\":      "; append_quoted_decimal(s, p->dataset_root); s += "\n";
-  s += ", \"entropy\":          "; append_quoted_decimal(s, p->entropy); s += "\n";
+  s += "  \"dataSetRoot\":      "; append_quoted_decimal(s, dataset_root); s += "\n";
+  s += ", \"entropy\":          "; append_quoted_decimal(s, entropy); s += "\n";
   s += ", \"nCellsPerSlot\":    " + std::to_string(cfg.n_cells) + "\n";
   s += ", \"nSlotsPerDataSet\": " + std::to_string(cfg.n_slots) + "\n";
-  s += ", \"slotIndex\":        " + std::to_string(p->slot_idx) + "\n";
-  s += ", \"slotRoot\":         "; append_quoted_decimal(s, p->slot_root); s += "\n";
+  s += ", \"slotIndex\":        " + std::to_string(slot_idx) + "\n";
+  s += ", \"slotRoot\":         "; append_quoted_decimal(s, slot_root); s += "\n";
   s += ", \"slotProof\":\n";
-  write_felt_list(s, "    ", p->slot_proof.data(), (size_t)cfg.max_log2_nslots);
-  const size_t ns = p->indices.size();
+  write_felt_list(s, "    ", slot_proof, (size_t)cfg.max_log2_nslots);
+}
+
+// ", \"cellData\":" .. "}": the bulk, a function of the slot's own tree and cells only (json/bn254.nim:67-73)
+void text_body(std::string& s, const cp2_config& cfg, size_t ns, const uint8_t* cell_data, const uint8_t* paths) {
   const std::string outer = "    ", outer_indent(outer.size(), ' ');
   s += ", \"cellData\":\n";
   {
     size_t nf = cp2_felts_per_bytes(cfg.cell_size);
     std::vector<uint8_t> felts(nf * 32);
     for (size_t i = 0; i < ns; ++i) {
-      cp2_bytes_to_felts(p->cell_data + i * cfg.cell_size, cfg.cell_size, felts.data());   // json/bn254.nim:25
+      cp2_bytes_to_felts(cell_data + i * cfg.cell_size, cfg.cell_size, felts.data());   // json/bn254.nim:25
       write_felt_list(s, (i == 0) ? outer + "[ " : outer_indent + ", ", felts.data(), nf);
     }
     s += outer_indent + "]\n";
   }
   s += ", \"merklePaths\":\n";
   for (size_t i = 0; i < ns; ++i)
-    write_felt_list(s, (i == 0) ? outer + "[ " : outer_indent + ", ", p->paths + i * (size_t)cfg.max_depth * 32, (size_t)cfg.max_depth);
+    write_felt_list(s, (i == 0) ? outer + "[ " : outer_indent + ", ", paths + i * (size_t)cfg.max_depth * 32, (size_t)cfg.max_depth);
   s += outer_indent + "]\n";
   s += "}\n";
+}
+
+size_t body_reserve(const cp2_config& cfg, size_t ns) { return (ns * (cp2_felts_per_bytes(cfg.cell_size) + (size_t)cfg.max_depth) + 64) * 90; }
+
+int write_parts(const char* path, const std::string& a, const std::string& b) {
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return CP2_ERR_IO;
+  size_t w = std::fwrite(a.data(), 1, a.size(), f) + (b.empty() ? 0 : std::fwrite(b.data(), 1, b.size(), f));
+  int rc = std::fclose(f);
+  return (w == a.size() + b.size() && rc == 0) ? CP2_OK : CP2_ERR_IO;
+}
+
+}  // namespace
+
+static void proof_input_text(const cp2_proof_input* p, std::string& s) {
+  s.clear();
+  s.reserve(body_reserve(p->cfg, p->n_samples) + 4096);
+  text_head(s, p->cfg, p->slot_idx, p->dataset_root, p->entropy, p->slot_root, p->slot_proof.data());
+  text_body(s, p->cfg, p->n_samples, p->cell_data, p->paths);
 }
 
 extern "C" int cp2_proof_input_json(const cp2_proof_input* p, char** text, size_t* len) try {
@@ -955,14 +531,6 @@ extern "C" int cp2_proof_input_json(const cp2_proof_input* p, char** text, size_
   return CP2_ERR_INVALID;
 }
 
-static int write_text_file(const std::string& s, const char* path) {
-  FILE* f = std::fopen(path, "wb");
-  if (!f) return CP2_ERR_IO;
-  size_t w = std::fwrite(s.data(), 1, s.size(), f);
-  int rc = std::fclose(f);
-  return (w == s.size() && rc == 0) ? CP2_OK : CP2_ERR_IO;
-}
-
 // Serialise (and optionally write) many proof inputs on `threads` host threads.  paths == NULL or
 // paths[i] == NULL: serialise only.  total_bytes (may be NULL) receives the summed text length.
 extern "C" int cp2_proof_inputs_write_json_batch(const cp2_proof_input* const* ps, size_t n, const char* const* paths,
@@ -975,20 +543,26 @@ extern "C" int cp2_proof_inputs_write_json_batch(const cp2_proof_input* const* p
   std::vector<int> status(threads, CP2_OK);
   std::vector<uint64_t> bytes(threads, 0);
   auto work = [&](int t) {
-    std::string s;
-    for (size_t i = t; i < n; i += threads) {
-      proof_input_text(ps[i], s);
-      bytes[t] += s.size();
-      if (paths && paths[i]) {
-        int st = write_text_file(s, paths[i]);
-        if (st != CP2_OK) status[t] = st;
+    try {
+      std::string s;
+      for (size_t i = t; i < n; i += threads) {
+        proof_input_text(ps[i], s);
+        bytes[t] += s.size();
+        if (paths && paths[i]) {
+          int st = write_parts(paths[i], s, std::string());
+          if (st != CP2_OK) status[t] = st;
+        }
       }
+    } catch (...) {
+      status[t] = CP2_ERR_ALLOC;
     }
   };
-  std::vector<std::thread> pool;
-  for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
-  work(0);
-  for (auto& th : pool) th.join();
+  {
+    Workers pool(threads - 1 > 0 ? threads - 1 : 1);   // joined by its destructor on every path out of this scope
+    for (int t = 1; t < threads; ++t) pool.submit([&, t] { work(t); });
+    work(0);
+    pool.wait_idle();
+  }
   uint64_t tot = 0;
   for (int t = 0; t < threads; ++t) {
     tot += bytes[t];
@@ -1002,9 +576,9 @@ extern "C" int cp2_proof_inputs_write_json_batch(const cp2_proof_input* const* p
   return CP2_ERR_INVALID;
 }
 
-// Proof inputs for many slots, generated and serialised as a two-stage pipeline: while the host threads turn
-// batch k into JSON text (and write it when dir != NULL: "<dir>/input_<slot>.json"), the GPU already samples and
-// gathers batch k+1.  Config 4's metric (witnesses/s) is this call after cp2_dataset_build.
+// Proof inputs for many slots of a built dataset, generated and serialised as a two-stage pipeline: while the host
+// threads turn batch k into JSON text (and write it when dir != NULL: "<dir>/input_<slot>.json"), the GPU already
+// samples and gathers batch k+1.
 extern "C" int cp2_dataset_export_proof_inputs(cp2_dataset* ds, const uint64_t* slot_idx, size_t n, const uint8_t entropy[32],
                                                const char* dir, int threads, size_t batch, uint64_t* total_bytes) try {
   if (!ds || !entropy || (n && !slot_idx)) return CP2_ERR_INVALID;
@@ -1018,35 +592,253 @@ extern "C" int cp2_dataset_export_proof_inputs(cp2_dataset* ds, const uint64_t* 
     out.assign(m, nullptr);
     return cp2_proof_inputs_generate_batch(ds, slot_idx + b0, m, entropy, out.data());
   };
-  auto release = [](std::vector<cp2_proof_input*>& v) {
-    for (auto* p : v) delete p;
-    v.clear();
-  };
+  struct Release {   // whatever leaves this scope, the objects are freed
+    std::vector<cp2_proof_input*>& v;
+    ~Release() { for (auto* p : v) delete p; v.clear(); }
+  } rel_cur{cur}, rel_next{next};
   if (n) status = generate(0, cur);
   for (size_t b0 = 0; status == CP2_OK && b0 < n; b0 += batch) {
     const size_t b1 = b0 + batch;
-    int gen_status = CP2_OK;
-    std::thread producer;                                   // GPU stage of the NEXT batch
-    if (b1 < n) producer = std::thread([&] { gen_status = generate(b1, next); });
-    std::vector<std::string> names;                          // host stage of THIS batch
+    // names first: nothing below may throw while the producer task is in flight except into the pool's joining destructor
+    std::vector<std::string> names;
     std::vector<const char*> paths;
     if (dir) {
       for (size_t i = 0; i < cur.size(); ++i) names.push_back(std::string(dir) + "/input_" + std::to_string(slot_idx[b0 + i]) + ".json");
       for (auto& s2 : names) paths.push_back(s2.c_str());
     }
+    int gen_status = CP2_OK, st = CP2_OK;
     uint64_t got = 0;
-    int st = cp2_proof_inputs_write_json_batch(cur.data(), cur.size(), dir ? paths.data() : nullptr, threads, &got);
+    {
+      Workers producer(1);                                   // GPU stage of the NEXT batch; joined when this scope ends
+      if (b1 < n) producer.submit([&] { gen_status = generate(b1, next); });
+      st = cp2_proof_inputs_write_json_batch(cur.data(), cur.size(), dir ? paths.data() : nullptr, threads, &got);
+    }
     bytes += got;
-    if (producer.joinable()) producer.join();
-    release(cur);
+    for (auto* p : cur) delete p;
+    cur.clear();
     if (st != CP2_OK) status = st;
     else if (gen_status != CP2_OK) status = gen_status;
     cur.swap(next);
   }
-  release(cur);
-  release(next);
   if (total_bytes) *total_bytes = bytes;
   return status;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
+}
+
+// ---------------------------------------------------------------------------------------------
+// streamed build: proof-input bodies of finished slots while later slots are still hashing
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct StreamRing {
+  static constexpr int DEPTH = 3;
+  SampleHost host[DEPTH];
+  hipEvent_t landed[DEPTH] = {};
+  std::atomic<size_t> pending[DEPTH];     // body tasks still reading host[r]
+  size_t s0[DEPTH] = {}, s1[DEPTH] = {};   // slot range parked in host[r]
+  StreamRing() { for (auto& p : pending) p.store(0); }
+  ~StreamRing() { for (auto e : landed) if (e) (void)hipEventDestroy(e); }   // host[] drain their stream themselves
+};
+
+}  // namespace
+
+extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local,
+                                          const uint8_t entropy[32], int threads, size_t group_slots, cp2_dataset** out) try {
+  if (!ctx || !cfg || !out || !entropy) return CP2_ERR_INVALID;
+  *out = nullptr;
+  CP2_TRY(dataset_check(cfg, first_slot, n_local));
+  if (!is_pow2(cfg->n_cells)) return CP2_ERR_INVALID;                    // sample/bn254.nim:19-20
+  CP2_TRY(trees_check_geometry(cfg->cell_size, cfg->block_size, cfg->n_cells, n_local));
+  {
+    const size_t cpb = cfg->block_size / cfg->cell_size, depth = (layer_sizes_of(cpb).size() - 1) + (layer_sizes_of(cfg->n_cells / cpb).size() - 1);
+    if (depth > (size_t)cfg->max_depth) return CP2_ERR_INVALID;          // padMerkleProof assert, types.nim:29
+  }
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  if (threads < 1) threads = 1;
+  const size_t ns = cfg->n_samples, md = (size_t)cfg->max_depth, cs = cfg->cell_size;
+  // group: slots per layer pass / sampling pass.  Default: what fills the fake builder's staging chunk (2 GiB), at least 1.
+  if (group_slots == 0) group_slots = std::max<size_t>(1, ctx->stage_bytes / std::max<size_t>(1, cfg->n_cells * cs));
+  group_slots = std::min<size_t>(group_slots, n_local);
+
+  std::unique_ptr<cp2_dataset> ds(dataset_new(ctx, cfg, first_slot, n_local));
+  if (!ds) return CP2_ERR_ALLOC;
+  ds->bodies.resize(n_local);
+  std::memcpy(ds->prep_entropy, entropy, 32);
+  const bool from_file = ds->from_file;
+  const cp2_config cfgv = ds->cfg;
+  const std::string file_base = ds->file_base;
+
+  hipStream_t aux = nullptr;
+  CP2_TRY(aux_stream(ctx, &aux));
+  SampleDev dev;
+  StreamRing ring;
+  CP2_TRY(dev.init(ctx, group_slots, ns, md, cs, !from_file));
+  for (int r = 0; r < StreamRing::DEPTH; ++r) {
+    CP2_TRY(ring.host[r].init(ctx, group_slots, ns, md, cs, !from_file));
+    CP2_HIP(ctx, hipEventCreateWithFlags(&ring.landed[r], hipEventDisableTiming));
+  }
+  CP2_HIP(ctx, hipMemcpyAsync(dev.entropy.p, entropy, 32, hipMemcpyHostToDevice, aux));
+  hipEvent_t trees_ready = nullptr;
+  CP2_HIP(ctx, hipEventCreateWithFlags(&trees_ready, hipEventDisableTiming));
+  struct EvGuard { hipEvent_t e; ~EvGuard() { (void)hipEventDestroy(e); } } ev_guard{trees_ready};
+
+  std::atomic<int> task_status{CP2_OK};
+  cp2_dataset* dsp = ds.get();
+  size_t n_groups = 0;          // sampling passes enqueued so far
+  size_t consumed = 0;          // passes whose body tasks have been handed to the workers
+  cp2k::TreeGeom geom;
+  bool have_geom = false;
+  StageTimer trace;
+  {
+    Workers pool(threads);      // declared last: joins before anything above is destroyed
+
+    // hand the body tasks of pass `k` to the workers once its downloads have landed
+    auto consume = [&](size_t k) -> int {
+      const int r = (int)(k % StreamRing::DEPTH);
+      CP2_HIP(ctx, hipEventSynchronize(ring.landed[r]));
+      const size_t a = ring.s0[r], b = ring.s1[r];
+      ring.pending[r].store(b - a);
+      for (size_t s = a; s < b; ++s) {
+        pool.submit([&, s, a, r] {
+          try {
+            const uint8_t* paths = ring.host[r].paths.u8() + (s - a) * ns * md * 32;
+            const uint64_t* idx = static_cast<const uint64_t*>(ring.host[r].idx.p) + (s - a) * ns;
+            std::string& body = dsp->bodies[s];
+            body.clear();
+            body.reserve(body_reserve(cfgv, ns));
+            if (from_file) {      // sampled cells straight from the slot file (slot.nim:57-68)
+              std::vector<uint8_t> cells(ns * cs);
+              int fd = open(slot_file_name(file_base, first_slot + s).c_str(), O_RDONLY);
+              if (fd < 0) task_status.store(CP2_ERR_IO);
+              for (size_t c = 0; c < ns; ++c) read_file_cell(fd, cs, idx[c], &cells[c * cs]);
+              if (fd >= 0) close(fd);
+              text_body(body, cfgv, ns, cells.data(), paths);
+            } else {
+              text_body(body, cfgv, ns, ring.host[r].cells.u8() + (s - a) * ns * cs, paths);
+            }
+          } catch (...) {
+            task_status.store(CP2_ERR_ALLOC);
+          }
+          ring.pending[r].fetch_sub(1);
+        });
+      }
+      return CP2_OK;
+    };
+
+    // the builders call this each time the trees of slots [a, b) are complete on the context's stream
+    SlotsDone on_done = [&](cp2_slot_trees* t, size_t a, size_t b) -> int {
+      if (!have_geom) { trees_geom(t, &geom); have_geom = true; }
+      for (size_t g0 = a; g0 < b; g0 += group_slots) {
+        const size_t g1 = std::min(b, g0 + group_slots);
+        const size_t k = n_groups;
+        const int r = (int)(k % StreamRing::DEPTH);
+        // ring slot r was last used by pass k - DEPTH: its tasks must have been handed out and finished
+        while (consumed + StreamRing::DEPTH <= k) { CP2_TRY(consume(consumed)); ++consumed; }
+        while (ring.pending[r].load() != 0) std::this_thread::yield();
+        CP2_HIP(ctx, hipEventRecord(trees_ready, ctx->stream));
+        CP2_HIP(ctx, hipStreamWaitEvent(aux, trees_ready, 0));
+        CP2_TRY(enqueue_sampling(t, geom, dev, ring.host[r], nullptr, g0, g1 - g0, ns, md, !from_file, aux));
+        CP2_HIP(ctx, hipEventRecord(ring.landed[r], aux));
+        ring.s0[r] = g0;
+        ring.s1[r] = g1;
+        ++n_groups;
+        // the pass before this one has had a whole group's hashing time to land: hand it out now
+        while (consumed + 1 < n_groups) { CP2_TRY(consume(consumed)); ++consumed; }
+      }
+      return CP2_OK;
+    };
+
+    int st = dataset_build_trees(dsp, group_slots, on_done);
+    trace.lap("trees (sampling overlapped)");
+    while (st == CP2_OK && consumed < n_groups) { st = consume(consumed); ++consumed; }
+    pool.wait_idle();
+    (void)hipStreamSynchronize(aux);
+    trace.lap("last bodies");
+    if (st != CP2_OK) return st;
+  }
+  if (task_status.load() != CP2_OK) return task_status.load();
+  ds->prepared = true;
+  *out = ds.release();
+  return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
+}
+
+// Finish the proof inputs a streamed build prepared: the dataset tree must be set (cp2_dataset_set_roots; implied when
+// all slots are local).  Heads (dataSetRoot .. slotProof) are formatted and joined with the stored bodies on `threads`
+// host threads; dir != NULL writes "<dir>/input_<slot>.json" for every local slot.  Text identical to cp2_proof_input_json.
+extern "C" int cp2_dataset_export_streamed(cp2_dataset* ds, const char* dir, int threads, uint64_t* total_bytes) try {
+  if (!ds || !ds->prepared) return CP2_ERR_INVALID;
+  if (!ds->have_roots) CP2_TRY(cp2_dataset_set_roots(ds, nullptr));
+  if (ds->dsizes.size() - 1 > (size_t)ds->cfg.max_log2_nslots) return CP2_ERR_INVALID;   // padMerkleProof assert
+  if (threads < 1) threads = 1;
+  const size_t n = ds->n_local;
+  if ((size_t)threads > n) threads = (int)n;
+  std::vector<int> status(threads, CP2_OK);
+  std::vector<uint64_t> bytes(threads, 0);
+  auto work = [&](int t) {
+    try {
+      std::string head;
+      std::vector<uint8_t> proof;
+      for (size_t s = t; s < n; s += threads) {
+        const uint64_t slot = ds->first_slot + s;
+        head.clear();
+        fill_slot_proof(ds, slot, proof);
+        text_head(head, ds->cfg, slot, &ds->dlayers[ds->dlayers.size() - 32], ds->prep_entropy, &ds->dlayers[slot * 32], proof.data());
+        bytes[t] += head.size() + ds->bodies[s].size();
+        if (dir) {
+          std::string name = std::string(dir) + "/input_" + std::to_string(slot) + ".json";
+          int st = write_parts(name.c_str(), head, ds->bodies[s]);
+          if (st != CP2_OK) status[t] = st;
+        }
+      }
+    } catch (...) {
+      status[t] = CP2_ERR_ALLOC;
+    }
+  };
+  {
+    Workers pool(threads > 1 ? threads - 1 : 1);
+    for (int t = 1; t < threads; ++t) pool.submit([&, t] { work(t); });
+    work(0);
+    pool.wait_idle();
+  }
+  uint64_t tot = 0;
+  for (int t = 0; t < threads; ++t) {
+    tot += bytes[t];
+    if (status[t] != CP2_OK) return status[t];
+  }
+  if (total_bytes) *total_bytes = tot;
+  return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
+}
+
+// the full text of one prepared slot (head + body) into a malloc'ed buffer (cp2_free_buffer)
+extern "C" int cp2_dataset_streamed_json(cp2_dataset* ds, uint64_t slot_idx, char** text, size_t* len) try {
+  if (!ds || !ds->prepared || !text) return CP2_ERR_INVALID;
+  if (slot_idx < ds->first_slot || slot_idx >= ds->first_slot + ds->n_local) return CP2_ERR_INVALID;
+  if (!ds->have_roots) CP2_TRY(cp2_dataset_set_roots(ds, nullptr));
+  if (ds->dsizes.size() - 1 > (size_t)ds->cfg.max_log2_nslots) return CP2_ERR_INVALID;
+  std::string head;
+  std::vector<uint8_t> proof;
+  fill_slot_proof(ds, slot_idx, proof);
+  text_head(head, ds->cfg, slot_idx, &ds->dlayers[ds->dlayers.size() - 32], ds->prep_entropy, &ds->dlayers[slot_idx * 32], proof.data());
+  const std::string& body = ds->bodies[slot_idx - ds->first_slot];
+  char* buf = (char*)std::malloc(head.size() + body.size() + 1);
+  if (!buf) return CP2_ERR_ALLOC;
+  std::memcpy(buf, head.data(), head.size());
+  std::memcpy(buf + head.size(), body.data(), body.size());
+  buf[head.size() + body.size()] = 0;
+  *text = buf;
+  if (len) *len = head.size() + body.size();
+  return CP2_OK;
 } catch (const std::bad_alloc&) {
   return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
 } catch (...) {
@@ -1059,7 +851,7 @@ extern "C" int cp2_proof_input_write_json(const cp2_proof_input* p, const char* 
   if (!p || !path) return CP2_ERR_INVALID;
   std::string s;
   proof_input_text(p, s);
-  return write_text_file(s, path);
+  return write_parts(path, s, std::string());
 } catch (const std::bad_alloc&) {
   return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
 } catch (...) {

@@ -1,0 +1,638 @@
+// Slot trees behind the C ABI (include/codex_p2.h): builders for the four cell sources, the streaming
+// ingestion pipe, the persisted-tree cache and path lookup.
+//
+// Mirrors reference/nim/proof_input/src/gen_input/bn254.nim:21-33 (buildSlotTreeFull), blocks/bn254.nim:60-67
+// (networkBlockTree), slot.nim:57-73 (slot data), merkle.nim:21-42,86-100 + types.nim:27-37 (paths).  All hashing
+// runs in the HIP kernels; what stays on the host is index arithmetic and file / memory staging.
+#include <hip/hip_runtime.h>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "trees.hpp"
+
+using namespace cp2i;
+
+namespace cp2i {
+
+bool is_pow2(uint64_t x) { return x && !(x & (x - 1)); }
+
+static double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+StageTimer::StageTimer() : on(std::getenv("CP2_TRACE") != nullptr), t0(now_ms()) {}
+void StageTimer::lap(const char* what) {
+  if (!on) return;
+  double t1 = now_ms();
+  std::fprintf(stderr, "[cp2 trace] %-34s %9.3f ms\n", what, t1 - t0);
+  t0 = t1;
+}
+
+int aux_stream(cp2_ctx* ctx, hipStream_t* out) {
+  if (!ctx->aux_stream) CP2_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+  *out = ctx->aux_stream;
+  return CP2_OK;
+}
+
+std::string slot_file_name(const std::string& base, uint64_t slot) { return base + std::to_string(slot) + ".dat"; }   // dataset.nim:34
+
+void read_file_cell(int fd, size_t cell_size, uint64_t cell, uint8_t* out) {
+  size_t done = 0;
+  while (fd >= 0 && done < cell_size) {
+    ssize_t r = pread(fd, out + done, cell_size - done, (off_t)(cell * cell_size + done));
+    if (r <= 0) break;
+    done += (size_t)r;
+  }
+  if (done < cell_size) std::memset(out + done, 0, cell_size - done);
+}
+
+int trees_check_geometry(size_t cell_size, size_t block_size, size_t n_cells, size_t n_slots) {
+  if (cell_size == 0 || block_size == 0 || n_cells == 0 || n_slots == 0) return CP2_ERR_INVALID;
+  if (block_size % cell_size != 0) return CP2_ERR_INVALID;        // types.nim:104-107 cellsPerBlock assert
+  size_t cpb = block_size / cell_size;
+  if (n_cells % cpb != 0) return CP2_ERR_INVALID;                 // gen_input/bn254.nim:25 assert
+  // sizes a kernel-argument geometry and 64-bit byte offsets can hold (also bounds what a cache header may claim)
+  if (cell_size > ((size_t)1 << 30) || n_cells > ((size_t)1 << 40) || n_slots > ((size_t)1 << 32)) return CP2_ERR_INVALID;
+  if ((unsigned __int128)n_cells * n_slots > ((unsigned __int128)1 << 44)) return CP2_ERR_INVALID;
+  return CP2_OK;
+}
+
+}  // namespace cp2i
+
+static int trees_layout(cp2_slot_trees* t) {
+  t->bsizes = layer_sizes_of(t->cpb);
+  t->tsizes = layer_sizes_of(t->nblocks);
+  if (t->bsizes.size() > (size_t)cp2k::TreeGeom::MAX_LAYERS || t->tsizes.size() > (size_t)cp2k::TreeGeom::MAX_LAYERS) return CP2_ERR_INVALID;
+  size_t off = 0;
+  t->boff.clear();
+  t->toff.clear();
+  const size_t nb = t->n_slots * t->nblocks;
+  for (size_t k = 0; k < t->bsizes.size(); ++k) {
+    t->boff.push_back(off);
+    if (k + 1 < t->bsizes.size()) off += nb * t->bsizes[k];
+  }
+  // the last block-tree layer (one root per block) is layer 0 of the big trees
+  for (size_t k = 0; k < t->tsizes.size(); ++k) {
+    t->toff.push_back(off);
+    off += t->n_slots * t->tsizes[k];
+  }
+  return t->nodes.alloc(t->ctx, off * 32);
+}
+
+void cp2i::trees_geom(const cp2_slot_trees* t, cp2k::TreeGeom* g) {
+  std::memset(g, 0, sizeof *g);
+  g->nb = (uint32_t)t->bsizes.size();
+  g->nt = (uint32_t)t->tsizes.size();
+  g->cpb = t->cpb;
+  g->nblocks = t->nblocks;
+  g->n_cells = t->n_cells;
+  for (size_t k = 0; k < t->bsizes.size(); ++k) { g->boff[k] = t->boff[k]; g->bsz[k] = t->bsizes[k]; }
+  for (size_t k = 0; k < t->tsizes.size(); ++k) { g->toff[k] = t->toff[k]; g->tsz[k] = t->tsizes[k]; }
+}
+
+static cp2_slot_trees* trees_new(cp2_ctx* ctx, size_t n_slots, size_t cell_size, size_t block_size, size_t n_cells) {
+  cp2_slot_trees* t = new (std::nothrow) cp2_slot_trees();
+  if (!t) return nullptr;
+  t->ctx = ctx;
+  t->n_slots = n_slots;
+  t->cell_size = cell_size;
+  t->block_size = block_size;
+  t->n_cells = n_cells;
+  t->cpb = block_size / cell_size;
+  t->nblocks = n_cells / t->cpb;
+  return t;
+}
+
+// all layers above the cell hashes of slots [s0, s1) (their cell hashes are already in layer 0)
+static int trees_build_layers(cp2_slot_trees* t, size_t s0, size_t s1) {
+  cp2_ctx* ctx = t->ctx;
+  uint8_t* base = t->nodes.u8();
+  const size_t ns = s1 - s0, nb = ns * t->nblocks;
+  for (size_t k = 0; k + 1 < t->bsizes.size(); ++k)   // networkBlockTree, blocks/bn254.nim:60-67
+    CP2_HIP(ctx, cp2k::launch_compress_layer(base + (t->boff[k] + s0 * t->nblocks * t->bsizes[k]) * 32,
+                                             base + (t->boff[k + 1] + s0 * t->nblocks * t->bsizes[k + 1]) * 32, t->bsizes[k], nb,
+                                             k == 0, t->bsizes[k], t->bsizes[k + 1], ctx->stream));
+  for (size_t k = 0; k + 1 < t->tsizes.size(); ++k)   // bigTree, gen_input/bn254.nim:28-29
+    CP2_HIP(ctx, cp2k::launch_compress_layer(base + (t->toff[k] + s0 * t->tsizes[k]) * 32, base + (t->toff[k + 1] + s0 * t->tsizes[k + 1]) * 32,
+                                             t->tsizes[k], ns, k == 0, t->tsizes[k], t->tsizes[k + 1], ctx->stream));
+  return CP2_OK;
+}
+
+// Tracks which slots have all their cells hashed and runs the layer passes (and the caller's hook) group by group.
+namespace {
+struct LayerScheduler {
+  cp2_slot_trees* t;
+  size_t group;
+  const SlotsDone& done;
+  size_t built = 0;
+  // cells [0, cells_hashed) of the batch are enqueued for hashing
+  int advance(size_t cells_hashed, bool final) {
+    const size_t complete = cells_hashed / t->n_cells;
+    for (;;) {
+      const size_t avail = complete - built;
+      size_t take = 0;
+      if (group && avail >= group) take = group;
+      else if (final && avail) take = avail;
+      if (!take) return CP2_OK;
+      CP2_TRY(trees_build_layers(t, built, built + take));
+      if (done) CP2_TRY(done(t, built, built + take));
+      built += take;
+    }
+  }
+};
+}  // namespace
+
+int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_slot, size_t n_slots, size_t cell_size,
+                           size_t block_size, size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out) {
+  *out = nullptr;
+  CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  std::unique_ptr<cp2_slot_trees> t(trees_new(ctx, n_slots, cell_size, block_size, n_cells));
+  if (!t) return CP2_ERR_ALLOC;
+  t->src = CellSrc::Fake;
+  t->dataset_seed = dataset_seed;
+  t->first_slot = first_slot;
+  CP2_TRY(trees_layout(t.get()));
+  const size_t total_cells = n_slots * n_cells;
+  // staging chunk: up to 2 GiB of generated cells, a whole number of slots when slots are smaller than that
+  size_t chunk = std::max<size_t>(1, std::min(total_cells, ctx->stage_bytes / cell_size));
+  if (chunk > n_cells) chunk -= chunk % n_cells;
+  if (group && chunk > group * n_cells) chunk = group * n_cells;
+  DevBuf stage;
+  CP2_TRY(stage.scratch(ctx, chunk * cell_size));
+  const uint64_t seed0 = cp2_slot_seed(dataset_seed, first_slot);
+  LayerScheduler sched{t.get(), group, done};
+  int st = CP2_OK;
+  for (size_t c0 = 0; st == CP2_OK && c0 < total_cells; c0 += chunk) {
+    size_t n = std::min(chunk, total_cells - c0);
+    hipError_t e = cp2k::launch_gen_fake_cells(seed0, n_cells, c0, nullptr, n, cell_size, stage.p, ctx->stream);
+    if (e == hipSuccess) e = cp2k::launch_hash_cells(stage.p, cell_size, n, t->nodes.u8() + c0 * 32, ctx->stream);
+    if (e != hipSuccess) { ctx->err = hipGetErrorString(e); st = CP2_ERR_HIP; break; }
+    st = sched.advance(c0 + n, c0 + n == total_cells);
+  }
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess && st == CP2_OK) { ctx->err = "stream synchronisation failed after the slot-tree build"; st = CP2_ERR_HIP; }
+  if (st != CP2_OK) return st;
+  *out = t.release();
+  return CP2_OK;
+}
+
+extern "C" int cp2_slot_trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_slot, size_t n_slots,
+                                         size_t cell_size, size_t block_size, size_t n_cells, cp2_slot_trees** out) try {
+  if (!ctx || !out) return CP2_ERR_INVALID;
+  return trees_build_fake(ctx, dataset_seed, first_slot, n_slots, cell_size, block_size, n_cells, 0, nullptr, out);
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
+}
+
+extern "C" int cp2_slot_trees_build_dev(cp2_ctx* ctx, const void* d_cells, size_t n_slots, size_t cell_size,
+                                        size_t block_size, size_t n_cells, cp2_slot_trees** out) try {
+  if (!ctx || !out || !d_cells) return CP2_ERR_INVALID;
+  *out = nullptr;
+  CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  std::unique_ptr<cp2_slot_trees> t(trees_new(ctx, n_slots, cell_size, block_size, n_cells));
+  if (!t) return CP2_ERR_ALLOC;
+  t->src = CellSrc::Dev;
+  t->d_cells = static_cast<const uint8_t*>(d_cells);
+  CP2_TRY(trees_layout(t.get()));
+  CP2_HIP(ctx, cp2k::launch_hash_cells(d_cells, cell_size, n_slots * n_cells, t->nodes.p, ctx->stream));
+  CP2_TRY(trees_build_layers(t.get(), 0, n_slots));
+  // A `_dev` entry point: everything is enqueued on the context's stream, nothing is synchronised (header contract).
+  // cp2_sync / cp2_slot_trees_roots / _paths synchronise and report a failed launch through cp2_last_error.
+  *out = t.release();
+  return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
+}
+
+// ---- streaming ingestion ----------------------------------------------------
+// Overlapped stages over a ring of `depth` slots: host threads fill a PINNED buffer (pread or memcpy), a dedicated
+// copy stream moves it to the device, the context's stream hashes it.  While chunk i is copied and hashed the host is
+// already filling chunk i+1 (and i+2 with depth 3), so disk / host memory, PCIe and the GPU work concurrently (the
+// reference re-opens the slot file and reads one cell per call, slot.nim:57-68).  Fill threads, ring depth and chunk
+// size are run-time knobs: cp2_set_ingest, or CP2_INGEST_THREADS / CP2_INGEST_RING / CP2_INGEST_CHUNK_MB.
+//
+// Chunk size is what matters (measured, tools/ingest_probe.cpp, profiles/r02_ingest_probe.txt): the hash kernel runs
+// one CELL per lane, so a 64 MiB chunk of 2 KiB cells is 128 workgroups on a GPU that holds 768 of them -- the kernel
+// then takes the lifetime of one workgroup (3.75 ms) whatever its size, and the pipe ran at 17 GB/s although host
+// memcpy (130 GB/s on 8 threads), pinned H2D (56 GB/s) and the kernel from HBM (43 GB/s) are each far faster.  The
+// default chunk is therefore one full residency of the kernel: 768 workgroups x 256 cells (384 MiB at 2 KiB cells).
+namespace {
+
+size_t env_size(const char* name, size_t dflt) {
+  const char* v = std::getenv(name);
+  if (!v || !*v) return dflt;
+  char* end = nullptr;
+  unsigned long long x = std::strtoull(v, &end, 10);
+  return (end && *end == 0 && x > 0) ? (size_t)x : dflt;
+}
+
+struct IngestPipe {
+  static constexpr int MAX_DEPTH = 8;
+  cp2_ctx* ctx = nullptr;
+  hipStream_t copy = nullptr;
+  int depth = 0;
+  PinBuf pinned[MAX_DEPTH];
+  DevBuf dev[MAX_DEPTH];
+  hipEvent_t copied[MAX_DEPTH] = {}, hashed[MAX_DEPTH] = {};
+  size_t chunk = 0, turn = 0;
+  int threads = 1;
+  std::unique_ptr<Workers> pool;
+
+  ~IngestPipe() {
+    if (!ctx) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (copy) (void)hipStreamSynchronize(copy);
+    for (int b = 0; b < depth; ++b) {
+      if (copied[b]) (void)hipEventDestroy(copied[b]);
+      if (hashed[b]) (void)hipEventDestroy(hashed[b]);
+    }
+    if (copy) (void)hipStreamDestroy(copy);
+  }
+  int init(cp2_ctx* c, size_t cell_size, size_t max_cells) {
+    ctx = c;
+    size_t chunk_bytes = c->ingest_chunk ? c->ingest_chunk : env_size("CP2_INGEST_CHUNK_MB", 0) << 20;
+    if (chunk_bytes == 0) chunk_bytes = std::max<size_t>((size_t)64 << 20, std::min<size_t>((size_t)768 * 256 * cell_size, (size_t)1 << 30));
+    int want_depth = c->ingest_ring ? c->ingest_ring : (int)env_size("CP2_INGEST_RING", 3);
+    want_depth = std::max(2, std::min(want_depth, (int)MAX_DEPTH));
+    threads = c->ingest_threads ? c->ingest_threads : (int)env_size("CP2_INGEST_THREADS", 8);
+    threads = std::max(1, std::min(threads, 64));
+    chunk = std::max<size_t>(1, std::min(max_cells, chunk_bytes / cell_size));
+    CP2_HIP(ctx, hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+    for (int b = 0; b < want_depth; ++b) {
+      CP2_TRY(pinned[b].alloc(ctx, chunk * cell_size));
+      CP2_TRY(dev[b].scratch(ctx, chunk * cell_size));
+      CP2_HIP(ctx, hipEventCreateWithFlags(&copied[b], hipEventDisableTiming));
+      CP2_HIP(ctx, hipEventCreateWithFlags(&hashed[b], hipEventDisableTiming));
+      CP2_HIP(ctx, hipEventRecord(hashed[b], ctx->stream));
+      depth = b + 1;
+    }
+    if (threads > 1) pool.reset(new Workers(threads - 1));
+    return CP2_OK;
+  }
+  // f(a, b) over [0, n) split across the fill threads (the calling thread takes the first range)
+  template <typename F> void parallel_ranges(size_t n, size_t grain, F f) {
+    int nt = (int)std::min<size_t>((size_t)threads, std::max<size_t>(1, n / grain));
+    if (nt <= 1 || !pool) { f(0, n); return; }
+    for (int t = 1; t < nt; ++t) pool->submit([=] { f(n * t / nt, n * (t + 1) / nt); });
+    f(0, n / nt);
+    pool->wait_idle();
+  }
+  // the pinned buffer the host may fill next (blocks until the kernel that last used this ring slot is done)
+  int acquire(uint8_t** buf) {
+    int b = (int)(turn % depth);
+    CP2_HIP(ctx, hipEventSynchronize(hashed[b]));
+    *buf = pinned[b].u8();
+    return CP2_OK;
+  }
+  // ship the filled buffer: m cells -> leaf hashes at `leaves_out`
+  int submit(size_t m, size_t cell_size, uint8_t* leaves_out) {
+    int b = (int)(turn % depth);
+    CP2_HIP(ctx, hipMemcpyAsync(dev[b].p, pinned[b].p, m * cell_size, hipMemcpyHostToDevice, copy));
+    CP2_HIP(ctx, hipEventRecord(copied[b], copy));
+    CP2_HIP(ctx, hipStreamWaitEvent(ctx->stream, copied[b], 0));
+    CP2_HIP(ctx, cp2k::launch_hash_cells(dev[b].p, cell_size, m, leaves_out, ctx->stream));
+    CP2_HIP(ctx, hipEventRecord(hashed[b], ctx->stream));
+    ++turn;
+    return CP2_OK;
+  }
+};
+}  // namespace
+
+int cp2i::hash_host_cells_pipelined(cp2_ctx* ctx, const uint8_t* cells, size_t cell_size, size_t n, uint8_t* d_leaves) {
+  IngestPipe pipe;
+  CP2_TRY(pipe.init(ctx, cell_size, n));
+  for (size_t c0 = 0; c0 < n; c0 += pipe.chunk) {
+    size_t m = std::min(pipe.chunk, n - c0);
+    uint8_t* buf = nullptr;
+    CP2_TRY(pipe.acquire(&buf));
+    const uint8_t* src = cells + c0 * cell_size;
+    pipe.parallel_ranges(m * cell_size, (size_t)2 << 20, [=](size_t a, size_t b) { std::memcpy(buf + a, src + a, b - a); });
+    CP2_TRY(pipe.submit(m, cell_size, d_leaves + c0 * 32));
+  }
+  return CP2_OK;   // the pipe's destructor waits for the streams
+}
+
+extern "C" int cp2_slot_trees_build_host(cp2_ctx* ctx, const uint8_t* cells, size_t n_slots, size_t cell_size,
+                                         size_t block_size, size_t n_cells, cp2_slot_trees** out) try {
+  if (!ctx || !out || !cells) return CP2_ERR_INVALID;
+  *out = nullptr;
+  CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  std::unique_ptr<cp2_slot_trees> t(trees_new(ctx, n_slots, cell_size, block_size, n_cells));
+  if (!t) return CP2_ERR_ALLOC;
+  t->src = CellSrc::Host;
+  t->h_cells = cells;
+  CP2_TRY(trees_layout(t.get()));
+  int st = hash_host_cells_pipelined(ctx, cells, cell_size, n_slots * n_cells, t->nodes.u8());
+  if (st == CP2_OK) st = trees_build_layers(t.get(), 0, n_slots);
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess && st == CP2_OK) st = CP2_ERR_HIP;
+  if (st != CP2_OK) return st;
+  *out = t.release();
+  return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
+}
+
+// slot files "<base><k>.dat" (dataset.nim:34) streamed through the ingestion pipe; short files read as zeros
+int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t first_slot, size_t n_slots, size_t cell_size,
+                            size_t block_size, size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out) {
+  *out = nullptr;
+  CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  std::unique_ptr<cp2_slot_trees> t(trees_new(ctx, n_slots, cell_size, block_size, n_cells));
+  if (!t) return CP2_ERR_ALLOC;
+  t->src = CellSrc::File;
+  t->file_base = base;
+  t->first_slot = first_slot;
+  CP2_TRY(trees_layout(t.get()));
+  int st = CP2_OK;
+  {
+    IngestPipe pipe;
+    st = pipe.init(ctx, cell_size, n_cells);
+    LayerScheduler sched{t.get(), group, done};
+    for (size_t s = 0; st == CP2_OK && s < n_slots; ++s) {
+      std::string fname = slot_file_name(base, first_slot + s);
+      int fd = open(fname.c_str(), O_RDONLY);
+      if (fd < 0) { ctx->err = "cannot open " + fname; st = CP2_ERR_IO; break; }
+      for (size_t c0 = 0; st == CP2_OK && c0 < n_cells; c0 += pipe.chunk) {
+        size_t m = std::min(pipe.chunk, n_cells - c0);
+        uint8_t* buf = nullptr;
+        st = pipe.acquire(&buf);
+        if (st != CP2_OK) break;
+        const size_t off = c0 * cell_size;
+        // bytes [off, off+n) of the file into the pinned buffer, zero-filled past EOF (slot.nim:61-66)
+        pipe.parallel_ranges(m * cell_size, (size_t)2 << 20, [=](size_t a, size_t b) {
+          size_t pos = a;
+          while (pos < b) {
+            ssize_t r = pread(fd, buf + pos, b - pos, (off_t)(off + pos));
+            if (r <= 0) break;
+            pos += (size_t)r;
+          }
+          if (pos < b) std::memset(buf + pos, 0, b - pos);
+        });
+        st = pipe.submit(m, cell_size, t->nodes.u8() + (s * n_cells + c0) * 32);
+      }
+      close(fd);
+      if (st == CP2_OK) st = sched.advance((s + 1) * n_cells, s + 1 == n_slots);
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && st == CP2_OK) st = CP2_ERR_HIP;
+  }
+  if (st != CP2_OK) return st;
+  *out = t.release();
+  return CP2_OK;
+}
+
+extern "C" int cp2_set_ingest(cp2_ctx* ctx, int fill_threads, int ring_depth, size_t chunk_bytes) try {
+  if (!ctx || fill_threads < 0 || ring_depth < 0) return CP2_ERR_INVALID;
+  ctx->ingest_threads = fill_threads;
+  ctx->ingest_ring = ring_depth;
+  ctx->ingest_chunk = chunk_bytes;
+  return CP2_OK;
+} catch (...) {
+  return CP2_ERR_INVALID;
+}
+
+// ---- persisted slot trees ---------------------------------------------------
+// File = header + data-source description + every node of the layer-major buffer (canonical 32-byte elements).
+// A later run with new entropy then needs only 2 permutations per sample plus gathers instead of re-hashing every
+// slot (the reference re-hashes all slots per run AND the proving slot once per sample, gen_input/bn254.nim:42,57).
+// The file is written to "<path>.tmp.<pid>" and renamed into place; it carries a checksum of the nodes and, for the
+// SlotFile source, size + mtime of every slot file so that a cache is never reused over changed data.
+namespace {
+struct TreeFileHeader {
+  char magic[8];            // "CP2TREE2"
+  uint64_t n_slots, cell_size, block_size, n_cells;
+  uint64_t src;             // CellSrc
+  uint64_t dataset_seed, first_slot;
+  uint64_t file_base_len;   // bytes following the header
+  uint64_t n_stamps;        // (size, mtime_ns) pairs following the base name: one per slot for CellSrc::File
+  uint64_t n_nodes;
+  uint64_t node_checksum;
+};
+
+// 64-bit multiply-mix over 8-byte words (not cryptographic: detects truncation and bit rot, not an adversary)
+uint64_t checksum64(const uint8_t* p, size_t n) {
+  uint64_t h[4] = {0x9e3779b97f4a7c15ULL, 0xc2b2ae3d27d4eb4fULL, 0x165667b19e3779f9ULL, 0x27d4eb2f165667c5ULL};
+  size_t i = 0;
+  for (; i + 32 <= n; i += 32) {
+    uint64_t w[4];
+    std::memcpy(w, p + i, 32);
+    for (int k = 0; k < 4; ++k) {
+      h[k] = (h[k] ^ w[k]) * 0x100000001b3ULL;
+      h[k] = (h[k] << 29) | (h[k] >> 35);
+    }
+  }
+  uint64_t r = h[0] ^ (h[1] * 3) ^ (h[2] * 5) ^ (h[3] * 7) ^ (uint64_t)n;
+  for (; i < n; ++i) r = (r ^ p[i]) * 0x100000001b3ULL;
+  r ^= r >> 33; r *= 0xff51afd7ed558ccdULL; r ^= r >> 33;
+  return r;
+}
+
+// (size, mtime in ns) of each slot file; a missing file stamps as (~0, ~0)
+std::vector<uint64_t> file_stamps(const std::string& base, uint64_t first_slot, size_t n_slots) {
+  std::vector<uint64_t> v(2 * n_slots);
+  for (size_t s = 0; s < n_slots; ++s) {
+    struct stat sb;
+    if (stat(slot_file_name(base, first_slot + s).c_str(), &sb) == 0) {
+      v[2 * s] = (uint64_t)sb.st_size;
+      v[2 * s + 1] = (uint64_t)sb.st_mtim.tv_sec * 1000000000ULL + (uint64_t)sb.st_mtim.tv_nsec;
+    } else {
+      v[2 * s] = v[2 * s + 1] = ~0ULL;
+    }
+  }
+  return v;
+}
+}  // namespace
+
+extern "C" int cp2_slot_trees_save(cp2_slot_trees* t, const char* path) try {
+  if (!t || !path) return CP2_ERR_INVALID;
+  cp2_ctx* ctx = t->ctx;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  TreeFileHeader h{};
+  std::memcpy(h.magic, "CP2TREE2", 8);
+  h.n_slots = t->n_slots; h.cell_size = t->cell_size; h.block_size = t->block_size; h.n_cells = t->n_cells;
+  h.src = (uint64_t)t->src; h.dataset_seed = t->dataset_seed; h.first_slot = t->first_slot;
+  h.file_base_len = t->file_base.size();
+  std::vector<uint64_t> stamps;
+  if (t->src == CellSrc::File) stamps = file_stamps(t->file_base, t->first_slot, t->n_slots);
+  h.n_stamps = stamps.size() / 2;
+  h.n_nodes = t->nodes.bytes / 32;
+  std::vector<uint8_t> host(t->nodes.bytes);
+  CP2_HIP(ctx, hipMemcpyAsync(host.data(), t->nodes.p, host.size(), hipMemcpyDeviceToHost, ctx->stream));
+  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  h.node_checksum = checksum64(host.data(), host.size());
+  const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid());
+  FILE* f = std::fopen(tmp.c_str(), "wb");
+  if (!f) return CP2_ERR_IO;
+  bool ok = std::fwrite(&h, sizeof h, 1, f) == 1 &&
+            (h.file_base_len == 0 || std::fwrite(t->file_base.data(), 1, h.file_base_len, f) == h.file_base_len) &&
+            (stamps.empty() || std::fwrite(stamps.data(), 8, stamps.size(), f) == stamps.size()) &&
+            std::fwrite(host.data(), 1, host.size(), f) == host.size();
+  ok = (std::fclose(f) == 0) && ok;
+  if (ok) ok = std::rename(tmp.c_str(), path) == 0;
+  if (!ok) std::remove(tmp.c_str());
+  return ok ? CP2_OK : CP2_ERR_IO;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
+}
+
+extern "C" int cp2_slot_trees_load(cp2_ctx* ctx, const char* path, cp2_slot_trees** out) try {
+  if (!ctx || !path || !out) return CP2_ERR_INVALID;
+  *out = nullptr;
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return CP2_ERR_IO;
+  struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{f};
+  TreeFileHeader h{};
+  // every header field is bounded before anything is sized from it
+  if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, "CP2TREE2", 8) != 0 || h.file_base_len > 4096 ||
+      trees_check_geometry(h.cell_size, h.block_size, h.n_cells, h.n_slots) != CP2_OK || h.src > (uint64_t)CellSrc::File ||
+      (h.n_stamps != 0 && h.n_stamps != h.n_slots) || (h.src == (uint64_t)CellSrc::File) != (h.n_stamps != 0)) {
+    ctx->err = std::string("not a slot-tree cache of this version: ") + path;
+    return CP2_ERR_IO;
+  }
+  std::string base(h.file_base_len, '\0');
+  if (h.file_base_len && std::fread(&base[0], 1, h.file_base_len, f) != h.file_base_len) return CP2_ERR_IO;
+  std::vector<uint64_t> stamps(2 * h.n_stamps);
+  if (!stamps.empty() && std::fread(stamps.data(), 8, stamps.size(), f) != stamps.size()) return CP2_ERR_IO;
+  if (h.src == (uint64_t)CellSrc::File && stamps != file_stamps(base, h.first_slot, h.n_slots)) {
+    ctx->err = std::string("slot files changed since the cache was written: ") + path;
+    return CP2_ERR_IO;   // size or mtime of a slot file differs: the trees no longer describe the data
+  }
+  if (hipSetDevice(ctx->device) != hipSuccess) return CP2_ERR_HIP;
+  std::unique_ptr<cp2_slot_trees> t(trees_new(ctx, h.n_slots, h.cell_size, h.block_size, h.n_cells));
+  if (!t) return CP2_ERR_ALLOC;
+  t->src = (CellSrc)h.src;
+  t->dataset_seed = h.dataset_seed;
+  t->first_slot = h.first_slot;
+  t->file_base = base;
+  CP2_TRY(trees_layout(t.get()));
+  if (t->nodes.bytes / 32 != h.n_nodes) return CP2_ERR_IO;
+  std::vector<uint8_t> host(t->nodes.bytes);
+  if (std::fread(host.data(), 1, host.size(), f) != host.size()) return CP2_ERR_IO;
+  if (checksum64(host.data(), host.size()) != h.node_checksum) {
+    ctx->err = std::string("slot-tree cache is corrupt (checksum): ") + path;
+    return CP2_ERR_IO;
+  }
+  CP2_HIP(ctx, hipMemcpyAsync(t->nodes.p, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream));
+  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *out = t.release();
+  return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
+}
+
+// trees loaded from a cache that were built from caller memory have no cell source until one is attached
+extern "C" int cp2_slot_trees_attach_cells(cp2_slot_trees* t, const uint8_t* host_cells, const void* dev_cells) try {
+  if (!t || (host_cells && dev_cells)) return CP2_ERR_INVALID;
+  if (host_cells) { t->src = CellSrc::Host; t->h_cells = host_cells; t->d_cells = nullptr; }
+  else if (dev_cells) { t->src = CellSrc::Dev; t->d_cells = static_cast<const uint8_t*>(dev_cells); t->h_cells = nullptr; }
+  else return CP2_ERR_INVALID;
+  return CP2_OK;
+} catch (...) {
+  return CP2_ERR_INVALID;
+}
+
+extern "C" void cp2_slot_trees_free(cp2_slot_trees* t) {
+  if (!t) return;
+  (void)hipSetDevice(t->ctx->device);
+  (void)hipStreamSynchronize(t->ctx->stream);
+  if (t->ctx->aux_stream) (void)hipStreamSynchronize(t->ctx->aux_stream);
+  delete t;
+}
+
+extern "C" size_t cp2_slot_trees_count(const cp2_slot_trees* t) { return t ? t->n_slots : 0; }
+extern "C" size_t cp2_slot_trees_depth(const cp2_slot_trees* t) {
+  return t ? (t->bsizes.size() - 1) + (t->tsizes.size() - 1) : 0;
+}
+
+extern "C" const void* cp2_slot_trees_roots_dev(const cp2_slot_trees* t) {
+  return t ? t->nodes.u8() + t->toff.back() * 32 : nullptr;
+}
+
+extern "C" int cp2_slot_trees_roots(cp2_slot_trees* t, uint8_t* out) try {
+  if (!t || !out) return CP2_ERR_INVALID;
+  cp2_ctx* ctx = t->ctx;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  CP2_HIP(ctx, hipMemcpyAsync(out, cp2_slot_trees_roots_dev(t), t->n_slots * 32, hipMemcpyDeviceToHost, ctx->stream));
+  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
+}
+
+// node-row indices of the merged path of `cell` in slot `slot` (merkle.nim:21-42 twice, then :86-100)
+void cp2i::path_rows(const cp2_slot_trees* t, size_t slot, uint64_t cell, size_t max_depth, uint64_t* rows) {
+  size_t b = cell / t->cpb, j = cell % t->cpb, d = 0;
+  size_t m = t->cpb;
+  for (size_t k = 0; k + 1 < t->bsizes.size(); ++k, ++d) {
+    size_t sib = j ^ 1;
+    rows[d] = (sib < m) ? t->boff[k] + (slot * t->nblocks + b) * t->bsizes[k] + sib : NO_ROW;   // zero if out of range
+    j >>= 1;
+    m = (m + 1) >> 1;
+  }
+  size_t i = b;
+  m = t->nblocks;
+  for (size_t k = 0; k + 1 < t->tsizes.size(); ++k, ++d) {
+    size_t sib = i ^ 1;
+    rows[d] = (sib < m) ? t->toff[k] + slot * t->tsizes[k] + sib : NO_ROW;
+    i >>= 1;
+    m = (m + 1) >> 1;
+  }
+  for (; d < max_depth; ++d) rows[d] = NO_ROW;                                                  // padMerkleProof
+}
+
+extern "C" int cp2_slot_trees_paths(cp2_slot_trees* t, size_t slot, const uint64_t* cell_idx, size_t n, size_t max_depth,
+                                    uint8_t* out, uint8_t* leaf_hashes) try {
+  if (!t || (n && (!cell_idx || !out)) || slot >= t->n_slots) return CP2_ERR_INVALID;
+  if (cp2_slot_trees_depth(t) > max_depth) return CP2_ERR_INVALID;     // types.nim:29 assert(pad >= 0)
+  if (n == 0) return CP2_OK;
+  cp2_ctx* ctx = t->ctx;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t per = max_depth + 1;                                     // + the leaf itself
+  std::vector<uint64_t> rows(n * per);
+  for (size_t i = 0; i < n; ++i) {
+    if (cell_idx[i] >= t->n_cells) return CP2_ERR_INVALID;              // merkle.nim:27 assert
+    path_rows(t, slot, cell_idx[i], max_depth, &rows[i * per]);
+    rows[i * per + max_depth] = slot * t->n_cells + cell_idx[i];
+  }
+  DevBuf d_rows, d_out;
+  CP2_TRY(d_rows.scratch(ctx, rows.size() * 8));
+  CP2_TRY(d_out.scratch(ctx, rows.size() * 32));
+  CP2_HIP(ctx, hipMemcpyAsync(d_rows.p, rows.data(), rows.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  CP2_HIP(ctx, cp2k::launch_gather_rows(t->nodes.p, static_cast<const uint64_t*>(d_rows.p), rows.size(), 32, d_out.p, ctx->stream));
+  std::vector<uint8_t> tmp(rows.size() * 32);
+  CP2_HIP(ctx, hipMemcpyAsync(tmp.data(), d_out.p, tmp.size(), hipMemcpyDeviceToHost, ctx->stream));
+  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < n; ++i) {
+    std::memcpy(out + i * max_depth * 32, &tmp[i * per * 32], max_depth * 32);
+    if (leaf_hashes) std::memcpy(leaf_hashes + i * 32, &tmp[(i * per + max_depth) * 32], 32);
+  }
+  return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
+}

@@ -1,0 +1,57 @@
+// Slot-tree batch shared by slot_trees.cpp and proof_input.cpp (not installed).
+#pragma once
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "internal.hpp"
+#include "kernels.hpp"
+
+enum class CellSrc { Fake, Dev, Host, File };
+
+struct cp2_slot_trees {
+  cp2_ctx* ctx = nullptr;
+  size_t n_slots = 0, cell_size = 0, block_size = 0, n_cells = 0, cpb = 0, nblocks = 0;
+  std::vector<size_t> bsizes, tsizes;   // per-tree layer sizes: block tree (cpb leaves), big tree (nblocks leaves)
+  std::vector<size_t> boff, toff;       // element offsets of each layer in `nodes` (layer-major)
+  cp2i::DevBuf nodes;
+  // where sampled cells come from
+  CellSrc src = CellSrc::Fake;
+  uint64_t dataset_seed = 0, first_slot = 0;
+  const uint8_t* d_cells = nullptr;     // not owned
+  const uint8_t* h_cells = nullptr;     // not owned
+  std::string file_base;
+};
+
+namespace cp2i {
+
+constexpr uint64_t NO_ROW = ~0ULL;
+
+// Called by the builders each time the trees of slots [s0, s1) (indices inside the batch) are complete ON THE
+// CONTEXT'S STREAM (everything enqueued, nothing synchronised): the streamed proof-input path hangs its
+// sampling / gather / download of those slots on it while later slots are still hashing.
+using SlotsDone = std::function<int(cp2_slot_trees* t, size_t s0, size_t s1)>;
+
+int trees_check_geometry(size_t cell_size, size_t block_size, size_t n_cells, size_t n_slots);
+// fake-data or slot-file trees; `group` = how many finished slots to batch per layer pass / callback (0: all at the end)
+int trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_slot, size_t n_slots, size_t cell_size, size_t block_size,
+                     size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out);
+int trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t first_slot, size_t n_slots, size_t cell_size,
+                      size_t block_size, size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out);
+void trees_geom(const cp2_slot_trees* t, cp2k::TreeGeom* g);
+// node-row indices of the merged path of `cell` in slot `slot` (host twin of k_sample_paths' row arithmetic)
+void path_rows(const cp2_slot_trees* t, size_t slot, uint64_t cell, size_t max_depth, uint64_t* rows);
+// one cell of a slot file, zero-filled past EOF (slot.nim:57-68); fd < 0: all zeros
+void read_file_cell(int fd, size_t cell_size, uint64_t cell, uint8_t* out);
+std::string slot_file_name(const std::string& base, uint64_t slot);
+bool is_pow2(uint64_t x);
+
+// stage timings on stderr when CP2_TRACE is set (the reference's only tracing is shell `time`, workflow/prove.sh:30-37)
+struct StageTimer {
+  bool on;
+  double t0;
+  StageTimer();
+  void lap(const char* what);
+};
+
+}  // namespace cp2i

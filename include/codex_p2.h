@@ -55,6 +55,12 @@ const char* cp2_strerror(int status);
 const char* cp2_last_error(const cp2_ctx* ctx);
 /* 1 when the library's kernels were built for the device of `ctx` (gfx950). */
 int cp2_device_is_native(const cp2_ctx* ctx);
+/* Tuning of the host -> GPU ingestion pipe used by cp2_slot_trees_build_host, cp2_hash_cells (large inputs) and the
+ * SlotFile data source (the reference reads one cell per call, reference/nim/proof_input/src/slot.nim:57-68):
+ * host threads filling the pinned ring, ring depth (2..8) and bytes per chunk.  0 = keep the default
+ * (environment CP2_INGEST_THREADS / CP2_INGEST_RING / CP2_INGEST_CHUNK_MB, else 8 threads, depth 3 and one full
+ * residency of the hash kernel per chunk: 768 x 256 cells, 384 MiB at 2 KiB cells). */
+int cp2_set_ingest(cp2_ctx* ctx, int fill_threads, int ring_depth, size_t chunk_bytes);
 
 /* ---- a1: Poseidon2 t=3 permutation --------------------------------------------------------- */
 /* replaces nim-poseidon2 `perm` as specified by reference/haskell/src/Poseidon2/Permutation.hs:40-45.
@@ -127,7 +133,10 @@ typedef struct cp2_slot_trees cp2_slot_trees;
 /* slots first_slot..first_slot+n_slots-1 of a fake-data dataset (cells generated on the device) */
 int cp2_slot_trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_slot, size_t n_slots,
                               size_t cell_size, size_t block_size, size_t n_cells, cp2_slot_trees** out);
-/* n_slots slots whose cells are already in device memory, slot-major (n_slots x n_cells x cell_size bytes) */
+/* n_slots slots whose cells are already in device memory, slot-major (n_slots x n_cells x cell_size bytes).
+ * A `_dev`-style call: the hashing is ENQUEUED on the context's stream and the call returns without synchronising
+ * (the cells must stay valid until then).  cp2_sync, cp2_slot_trees_roots and cp2_slot_trees_paths synchronise;
+ * a launch failure is reported by whichever of them runs first (cp2_last_error). */
 int cp2_slot_trees_build_dev(cp2_ctx* ctx, const void* d_cells, size_t n_slots, size_t cell_size, size_t block_size,
                              size_t n_cells, cp2_slot_trees** out);
 /* same from host memory (streamed through a pinned staging buffer) */
@@ -213,6 +222,21 @@ int cp2_proof_inputs_write_json_batch(const cp2_proof_input* const* ps, size_t n
  * batch k).  dir == NULL: serialise only; else "<dir>/input_<slot>.json" is written per slot.  batch == 0: 512. */
 int cp2_dataset_export_proof_inputs(cp2_dataset* ds, const uint64_t* slot_idx, size_t n, const uint8_t entropy[32],
                                     const char* dir, int threads, size_t batch, uint64_t* total_bytes);
+/* The whole of `generateProofInputBN254` + `exportProofInputBN254` for EVERY local slot with the entropy known up front
+ * (reference/nim/proof_input/src/gen_input/bn254.nim:35-79, json/bn254.nim:57-78), as one overlapped pipeline: slot trees
+ * are built `group_slots` at a time (0: what fills the 2 GiB staging chunk), and while later slots are still hashing the
+ * finished ones are sampled (sample/bn254.nim:16-27), their paths and cells gathered on the device, downloaded into pinned
+ * memory and formatted (cellData + merklePaths) on `threads` host threads.  Only the lines that need all slot roots
+ * (dataSetRoot, slotProof: gen_input/bn254.nim:49-51,72) are left for cp2_dataset_export_streamed.  The returned dataset
+ * is a normal cp2_dataset (roots, set_roots, proof inputs for other entropies all work). */
+int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local,
+                               const uint8_t entropy[32], int threads, size_t group_slots, cp2_dataset** out);
+/* Finish what cp2_dataset_build_streamed prepared: needs the dataset tree (cp2_dataset_set_roots; implied when all slots
+ * are local).  dir == NULL: format only; else "<dir>/input_<slot>.json" per local slot.  Text identical to
+ * cp2_proof_input_json of the same slot and entropy. */
+int cp2_dataset_export_streamed(cp2_dataset* ds, const char* dir, int threads, uint64_t* total_bytes);
+/* the finished text of one prepared slot in a malloc'ed buffer (cp2_free_buffer) */
+int cp2_dataset_streamed_json(cp2_dataset* ds, uint64_t slot_idx, char** text, size_t* len);
 /* replaces `writeCircomMainComponent`, reference/nim/proof_input/src/cli.nim:186-204 */
 int cp2_write_circom_main(const cp2_config* cfg, const char* path);
 

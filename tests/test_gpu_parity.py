@@ -8,6 +8,8 @@ import hashlib
 import numpy as np
 import pytest
 
+from oracle_helpers import expected_proof_input_fast
+
 pytestmark = pytest.mark.gpu
 
 
@@ -351,30 +353,6 @@ def test_dataset_errors(pkg, ctx):
         ctx.dataset(pkg.make_config(**dict(c, maxLog2NSlots=3, maxDepth=8))).proof_input(5, 1)   # slot index out of range
 
 
-def expected_proof_input_fast(C, P, c, slot, entropy, threads=16):
-    """The oracle's proof input for a fake-data configuration, with every hash done by the C oracle (fast) and the
-    indexing / merging / padding / JSON by the Python restatement.  Same result as P.generate_proof_input."""
-    cs, bs, nc, ns = c["cellSize"], c["blockSize"], c["nCells"], c["nSlots"]
-    cpb = bs // cs
-    to_int = lambda layers: [C.array_to_felts(l) for l in layers]   # noqa: E731
-    roots = np.stack([C.fake_slot_root(C.slot_seed(c["seed"], s), cs, bs, nc, threads) for s in range(ns)])
-    dset = to_int(C.merkle_tree(roots))
-    cells = C.gen_fake_cells(C.slot_seed(c["seed"], slot), 0, nc, cs)
-    leaves = C.hash_cells(cells, cs, threads=threads)
-    mini = [to_int(C.merkle_tree(leaves[b * cpb:(b + 1) * cpb])) for b in range(nc // cpb)]
-    big = to_int(C.merkle_tree(np.stack([C.felt_bytes(t[-1][0]) for t in mini])))
-    assert big[-1][0] == dset[0][slot]
-    e = C.felt_bytes(entropy)
-    idx = [C.cell_index(e, C.felt_bytes(big[-1][0]), nc, k) for k in range(1, c["nSamples"] + 1)]
-    inputs = []
-    for ci in idx:
-        prf = P.merge_merkle_proofs(P.merkle_proof(mini[ci // cpb], ci % cpb), P.merkle_proof(big, ci // cpb))
-        inputs.append({"cellData": cells[ci].tobytes(), "merkleProof": P.pad_merkle_proof(prf, c["maxDepth"])})
-    return {"dataSetRoot": dset[-1][0], "entropy": entropy, "nCells": nc, "nSlots": ns, "slotIndex": slot,
-            "slotRoot": big[-1][0], "slotProof": P.pad_merkle_proof(P.merkle_proof(dset, slot), c["maxLog2NSlots"]),
-            "proofInputs": inputs, "cellIndices": idx}
-
-
 def test_expected_fast_equals_python_oracle(oracle, golden):
     """The helper above against the committed fixture (so that it can stand in for the slow Python path)."""
     C, P = oracle
@@ -520,6 +498,7 @@ def test_streaming_ingestion_multi_chunk(pkg, ctx, oracle, tmp_path):
     import torch
     C, _ = oracle
     cs, bs, nc, ns = 2048, 65536, 1 << 15, 3            # 64 MiB per slot, 192 MiB in all
+    ctx.set_ingest(0, 0, 24 << 20)                       # 24 MiB chunks: 8 ring turns, chunk edges inside slots
     d = torch.empty((ns * nc, cs), dtype=torch.uint8, device="cuda")
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     for s in range(ns):
@@ -537,6 +516,7 @@ def test_streaming_ingestion_multi_chunk(pkg, ctx, oracle, tmp_path):
     assert np.array_equal(ds.local_roots(), want)
     fake = ctx.dataset(pkg.make_config(maxDepth=32, maxLog2NSlots=2, cellSize=cs, blockSize=bs, nSlots=ns, nCells=nc, nSamples=3, seed=4711))
     assert ds.proof_input(2, 5).json() == fake.proof_input(2, 5).json()
+    ctx.set_ingest(0, 0, 0)
 
 
 def test_fuzz_sizes_against_oracle(pkg, ctx, oracle):
@@ -616,8 +596,10 @@ def test_hash_cells_large_host_input_is_pipelined(ctx, oracle):
     """> 32 MiB of host cells goes through the pinned ingestion ring (several chunks); same digests."""
     C, _ = oracle
     rng = np.random.default_rng(9)
-    cells = rng.integers(0, 256, size=(70000, 2048), dtype=np.uint8)     # 137 MiB: three ring turns
+    cells = rng.integers(0, 256, size=(70000, 2048), dtype=np.uint8)     # 137 MiB: five ring turns of 32 MiB
+    ctx.set_ingest(3, 2, 32 << 20)
     got = ctx.hash_cells(cells, 2048)
+    ctx.set_ingest(0, 0, 0)
     idx = np.concatenate([np.arange(0, 70000, 997), [32767, 32768, 65535, 65536, 69999]])
     assert np.array_equal(got[idx], C.hash_cells(cells[idx], 2048, threads=8))
 

@@ -1,0 +1,288 @@
+"""GPU suite, round 2 additions (-m gpu): full-size configurations against oracle-computed fixtures, the sharded
+(multi-rank) product path on one GPU, the streamed build+export pipeline, slot files against the oracle directly,
+cache validation and ingestion knobs.  Everything goes through the C ABI (ctypes) of libcodex_p2.so."""
+import hashlib
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle_helpers import expected_proof_input_fast
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def hexroot(a):
+    return np.asarray(a, dtype=np.uint8).tobytes()[::-1].hex()
+
+
+# ---- BASELINE.json configs[2] and configs[3] at FULL size vs tests/golden/fullsize.json -----------------------
+def test_fullsize_config3_slot_root(pkg, ctx, golden):
+    """8 GiB slot (cellSize 2048, nCells 2^22, seed 12345, slot 0): 146 800 639 permutations on the GPU, root equal
+    to the oracle's (computed once by tests/golden/make_fullsize_golden.py, minutes of CPU)."""
+    g3 = golden("fullsize.json")["config3"]
+    trees = ctx.slot_trees_fake(g3["seed"], g3["slot"], 1, g3["cellSize"], g3["blockSize"], g3["nCells"])
+    assert hexroot(trees.roots()[0]) == g3["slot_root_hex"]
+    trees.free()
+
+
+def test_fullsize_config4_dataset_and_proof_inputs(pkg, ctx, golden, tmp_path):
+    """4096 slots x 2^12 cells (32 GiB of fake data), nSamples 100, maxDepth 32, through the STREAMED pipeline: every
+    slot root, the dataset root and the input.json of two slots equal the oracle's; the object path agrees."""
+    g4 = golden("fullsize.json")["config4"]
+    cfg = pkg.make_config(**g4["config"])
+    ds = ctx.dataset_streamed(cfg, g4["entropy"], threads=12)
+    roots = ds.local_roots()
+    assert hashlib.sha256(roots.tobytes()).hexdigest() == g4["slot_roots_sha256"]
+    ds.set_roots(None)
+    assert hexroot(ds.root()) == g4["dataset_root_hex"]
+    total = ds.export_streamed(None, threads=12)
+    texts = {}
+    for slot, want in g4["inputs"].items():
+        text = ds.streamed_json(int(slot))
+        texts[slot] = text
+        assert len(text) == want["json_bytes"]
+        assert hashlib.sha256(text.encode()).hexdigest() == want["json_sha256"], slot
+    assert total > 4096 * 600000
+    # the object path (any entropy after the build) on the same dataset gives the same text
+    assert ds.proof_input(1234, g4["entropy"]).json() == texts["1234"]
+    # and a strided set of files written by the pipeline equals the per-slot texts
+    ds.free()
+
+
+# ---- streamed pipeline == object path, small shapes ---------------------------------------------------------------
+@pytest.mark.parametrize("group,threads", [(0, 1), (1, 3), (2, 2)])
+def test_streamed_equals_object_path_fake(pkg, ctx, golden, tmp_path, group, threads):
+    m = golden("proof_inputs.json")["inputs"]["testmain_small"]
+    cfg = pkg.make_config(**m["config"])
+    ref = ctx.dataset(cfg)
+    want = {s: ref.proof_input(s, m["entropy"]).json() for s in range(m["config"]["nSlots"])}
+    assert want[m["slotIndex"]] == golden("input_testmain_small.json")
+    ds = ctx.dataset_streamed(cfg, m["entropy"], threads=threads, group_slots=group)      # group 1: 5 passes > ring depth
+    d = tmp_path / ("out%d" % group)
+    d.mkdir()
+    total = ds.export_streamed(str(d), threads=threads)
+    assert total == sum(len(t) for t in want.values())
+    for s, t in want.items():
+        assert open(d / ("input_%d.json" % s)).read() == t
+        assert ds.streamed_json(s) == t
+    assert ds.proof_input(2, 99).json() == ref.proof_input(2, 99).json()                 # still a normal dataset
+    assert ds.export_streamed(None, threads=2) == total
+    plain = ctx.dataset(cfg)
+    with pytest.raises(Exception):
+        plain.export_streamed(None)                                                      # nothing prepared
+
+
+def test_streamed_many_passes_and_odd_slot_count(pkg, ctx, oracle):
+    """11 slots in groups of 2 (6 passes, twice around the 3-deep ring), odd dataset tree, vs the oracle."""
+    C, P = oracle
+    c = dict(maxDepth=12, maxLog2NSlots=4, cellSize=256, blockSize=2048, nSlots=11, nCells=128, nSamples=7, seed=424242)
+    ds = ctx.dataset_streamed(pkg.make_config(**c), 55555, threads=4, group_slots=2)
+    ds.export_streamed(None, threads=3)
+    for slot in (0, 5, 10):
+        assert ds.streamed_json(slot) == P.export_json(expected_proof_input_fast(C, P, c, slot, 55555, threads=4))
+
+
+# ---- f1: slot files against the oracle directly -------------------------------------------------------------------
+def test_slot_files_vs_oracle_directly(pkg, ctx, oracle, tmp_path):
+    """SlotFile source (slot.nim:57-68, dataset.nim:34): files written from ORACLE-generated cells; roots against the
+    oracle's fake_slot_root, input.json against the Python restatement run with the `file` source (both paths, classic
+    and streamed).  One file is short: the missing tail reads as zeros in both implementations."""
+    C, P = oracle
+    c = dict(maxDepth=10, maxLog2NSlots=3, cellSize=128, blockSize=1024, nSlots=3, nCells=64, nSamples=6, seed=777)
+    base = str(tmp_path / "slotdata")
+    for k in range(3):
+        open("%s%d.dat" % (base, k), "wb").write(C.gen_fake_cells(C.slot_seed(777, k), 0, 64, 128).tobytes())
+    cf = {k: v for k, v in c.items() if k != "seed"}
+    cf["file"] = base
+    ds = ctx.dataset(pkg.make_config(**cf))
+    roots = ds.local_roots()
+    for k in range(3):
+        assert np.array_equal(roots[k], C.fake_slot_root(C.slot_seed(777, k), 128, 1024, 64, 2))
+    for slot in (0, 2):
+        want = P.export_json(P.generate_proof_input(dict(cf), slot, 31337))
+        assert ds.proof_input(slot, 31337).json() == want
+    st = ctx.dataset_streamed(pkg.make_config(**cf), 31337, threads=2, group_slots=1)
+    st.export_streamed(None)
+    assert st.streamed_json(2) == P.export_json(P.generate_proof_input(dict(cf), 2, 31337))
+    # short file: truncate slot 1 to 40.5 cells
+    data = open(base + "1.dat", "rb").read()
+    open(base + "1.dat", "wb").write(data[:128 * 40 + 64])
+    ds2 = ctx.dataset(pkg.make_config(**cf))
+    for slot in (1,):
+        assert ds2.proof_input(slot, 5).json() == P.export_json(P.generate_proof_input(dict(cf), slot, 5))
+
+
+# ---- sharded datasets on ONE context (the multi-GPU product path without a second GPU) ---------------------------
+@pytest.mark.parametrize("source", ["fake", "file"])
+def test_sharded_datasets_equal_unsharded(pkg, ctx, oracle, golden, tmp_path, source):
+    """cp2_dataset_build(first_slot > 0, n_local < n_slots) + set_roots(all): uneven split 2 + 3 of the 5-slot golden
+    configuration; roots, dataset root and proof inputs equal the unsharded dataset and the committed golden."""
+    C, P = oracle
+    m = golden("proof_inputs.json")["inputs"]["testmain_small"]
+    c = dict(m["config"])
+    if source == "file":
+        base = str(tmp_path / "s")
+        for k in range(c["nSlots"]):
+            C.gen_fake_cells(C.slot_seed(c["seed"], k), 0, c["nCells"], c["cellSize"]).tofile("%s%d.dat" % (base, k))
+        del c["seed"]
+        c["file"] = base
+    cfg = pkg.make_config(**c)
+    whole = ctx.dataset(cfg)
+    a, b = ctx.dataset(cfg, 0, 2), ctx.dataset(cfg, 2, 3)
+    all_roots = np.concatenate([a.local_roots(), b.local_roots()])
+    assert np.array_equal(all_roots, whole.local_roots())
+    with pytest.raises(Exception):
+        b.set_roots(None)                       # a shard cannot make the dataset tree from its own roots
+    a.set_roots(all_roots)
+    b.set_roots(all_roots)
+    assert np.array_equal(a.root(), whole.root()) and np.array_equal(b.root(), whole.root())
+    e = m["entropy"]
+    assert a.proof_input(1, e).json() == whole.proof_input(1, e).json()
+    assert b.proof_input(3, e).json() == whole.proof_input(3, e).json() == golden("input_testmain_small.json")
+    assert b.proof_input(4, e).json() == whole.proof_input(4, e).json()
+    with pytest.raises(Exception):
+        a.proof_input(3, e)                     # slot 3 is not local to shard a
+    # streamed shards: bodies made during the build, heads after the gather
+    sb = ctx.dataset_streamed(cfg, e, 2, 3, threads=2, group_slots=2)
+    sb.set_roots(all_roots)
+    sb.export_streamed(None)
+    assert sb.streamed_json(3) == golden("input_testmain_small.json")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(world, cfg, entropy, tmp_path):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world))
+    procs, outs = [], []
+    for r in range(world):
+        out = str(tmp_path / ("rank%d_of%d.json" % (r, world)))
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_rank_child.py"), out, "0", json.dumps(cfg), str(entropy)],
+                                      env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = []
+    for p, out in zip(procs, outs):
+        try:
+            so, se = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, se[-3000:]
+        res.append(json.load(open(out)))
+    return res
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_hipbackend_sharded_ranks_vs_oracle(pkg, oracle, tmp_path, world):
+    """BASELINE.json configs[4]'s code path: distributed.dataset_root_sharded with HipBackend, one fresh process per
+    rank (world 1, then 2 ranks under gloo sharing GPU 0), 5 slots (uneven 3 + 2); gathered roots, dataset root and
+    one proof input per shard edge against the C oracle + Python restatement."""
+    C, P = oracle
+    c = dict(maxDepth=16, maxLog2NSlots=3, cellSize=2048, blockSize=65536, nSlots=5, nCells=256, nSamples=20, seed=2024)
+    entropy = 987654321
+    res = _run_ranks(world, c, entropy, tmp_path)
+    roots = np.stack([C.fake_slot_root(C.slot_seed(c["seed"], s), c["cellSize"], c["blockSize"], c["nCells"], 4) for s in range(c["nSlots"])])
+    want_root = hexroot(C.merkle_root(roots))
+    want_sha = hashlib.sha256(roots.tobytes()).hexdigest()
+    covered = []
+    for r in res:
+        assert r["native_so_loaded"] and not r["oracle_loaded"]            # the product path, not the checker
+        assert r["dataset_root_hex"] == want_root and r["all_roots_sha256"] == want_sha
+        covered += list(range(r["first"], r["first"] + r["count"]))
+        for slot, sha in r["inputs"].items():
+            text = P.export_json(expected_proof_input_fast(C, P, c, int(slot), entropy, threads=4, slot_roots=roots))
+            assert hashlib.sha256(text.encode()).hexdigest() == sha, (r["rank"], slot)
+    assert sorted(covered) == list(range(c["nSlots"]))
+    if world == 2:
+        assert [r["count"] for r in sorted(res, key=lambda r: r["rank"])] == [3, 2]
+
+
+# ---- robustness ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cell_size", [128, 256, 384, 4096])
+@pytest.mark.parametrize("n", [1, 63, 65, 191, 1000])
+def test_gen_fake_cells_wide_path_ragged_counts(ctx, oracle, cell_size, n):
+    """The LDS-transposed write-out of k_gen_fake_cells (cell sizes that are multiples of 128) with cell counts that
+    are not multiples of the 64-lane wave, a non-zero first cell and a high seed."""
+    C, _ = oracle
+    seed, first = (1 << 64) - 12345, 7
+    got = ctx.gen_fake_cells(seed, first, n, cell_size)
+    assert np.array_equal(got, C.gen_fake_cells(seed, first, n, cell_size))
+
+
+def test_cache_rejects_changed_or_corrupt_files(pkg, ctx, oracle, tmp_path):
+    """A SlotFile cache is keyed on size + mtime of every slot file and carries a node checksum: changed data or a
+    damaged cache means rebuild (and a correct answer), never stale nodes."""
+    C, P = oracle
+    c = dict(maxDepth=10, maxLog2NSlots=2, cellSize=128, blockSize=1024, nSlots=2, nCells=64, nSamples=4)
+    base = str(tmp_path / "slot")
+    for k in range(2):
+        C.gen_fake_cells(C.slot_seed(1, k), 0, 64, 128).tofile("%s%d.dat" % (base, k))
+    cfg = pkg.make_config(file=base, **c)
+    cache = str(tmp_path / "trees.cp2")
+    first = ctx.dataset(cfg, cache=cache).proof_input(1, 9).json()
+    assert ctx.dataset(cfg, cache=cache).proof_input(1, 9).json() == first               # loaded
+    assert not [f for f in os.listdir(tmp_path) if ".tmp." in f]                         # written by rename, no leftovers
+    # new contents for slot 1 (same size): must not reuse the cached nodes
+    new = C.gen_fake_cells(C.slot_seed(2, 1), 0, 64, 128)
+    new.tofile(base + "1.dat")
+    os.utime(base + "1.dat", ns=(1, 1))                                                  # even with an OLDER mtime
+    changed = ctx.dataset(cfg, cache=cache).proof_input(1, 9).json()
+    assert changed == ctx.dataset(cfg).proof_input(1, 9).json() != first
+    assert changed == P.export_json(P.generate_proof_input(dict(c, file=base), 1, 9))
+    # flip one node byte in the cache: checksum mismatch -> load fails, cached build rebuilds
+    raw = bytearray(open(cache, "rb").read())
+    raw[-5] ^= 0x40
+    open(cache, "wb").write(bytes(raw))
+    with pytest.raises(Exception):
+        ctx.slot_trees_load(cache)
+    assert ctx.dataset(cfg, cache=cache).proof_input(1, 9).json() == changed
+    ctx.slot_trees_load(cache).free()                                                    # rewritten intact
+    # truncated / foreign files are refused
+    open(cache, "wb").write(bytes(raw[:100]))
+    with pytest.raises(Exception):
+        ctx.slot_trees_load(cache)
+    open(cache, "wb").write(b"CP2TREE1" + bytes(200))
+    with pytest.raises(Exception):
+        ctx.slot_trees_load(cache)
+
+
+def test_ingest_knobs_give_identical_roots(pkg, ctx, oracle):
+    """cp2_set_ingest: fill threads, ring depth and chunk size change the schedule, never the result."""
+    C, _ = oracle
+    rng = np.random.default_rng(11)
+    cells = rng.integers(0, 256, size=(2 * 4096, 2048), dtype=np.uint8)                  # 2 slots x 8 MiB
+    want = ctx.slot_trees_host(cells, 2, 2048, 65536, 4096).roots()
+    assert np.array_equal(want[0], C.merkle_root(np.stack(
+        [C.merkle_root(C.hash_cells(cells[b * 32:(b + 1) * 32], 2048, threads=4)) for b in range(128)])))
+    for threads, ring, chunk in [(1, 2, 1 << 20), (16, 8, 3 << 20), (5, 3, 2048 * 100)]:
+        ctx.set_ingest(threads, ring, chunk)
+        assert np.array_equal(ctx.slot_trees_host(cells, 2, 2048, 65536, 4096).roots(), want)
+    ctx.set_ingest(0, 0, 0)
+    with pytest.raises(Exception):
+        ctx.set_ingest(-1, 0, 0)
+
+
+def test_repeated_host_calls_reuse_scratch(pkg, ctx, oracle):
+    """The host-pointer seam called hash by hash (how the Nim shim's `compress` uses it): correct every time; the
+    context's scratch pool means no hipMalloc / hipFree per call after the first."""
+    C, _ = oracle
+    rng = np.random.default_rng(5)
+    xy = rng.integers(0, 256, size=(200, 64), dtype=np.uint8)
+    xy[:, 31] &= 0x1F
+    xy[:, 63] &= 0x1F
+    for key in range(4):
+        want = np.stack([C.compress(xy[i, :32], xy[i, 32:], key) for i in range(200)])
+        got = np.stack([ctx.compress_batch(xy[i:i + 1], key)[0] for i in range(200)])
+        assert np.array_equal(got, want)

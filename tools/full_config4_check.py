@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 import __graft_entry__ as g
-from test_gpu_parity import expected_proof_input_fast
+from oracle_helpers import expected_proof_input_fast
 pkg = g.load_package()
 C, P = g.load_oracle()
 ctx = pkg.Context(0)
