@@ -137,6 +137,8 @@ def load_library():
         "cp2_proof_input_cell_data": (vp, [vp]),
         "cp2_proof_input_merkle_paths": (vp, [vp]),
         "cp2_proof_input_slot_proof": (vp, [vp]),
+        "cp2_proof_input_leaf_hashes": (vp, [vp]),
+        "cp2_proof_input_create": (i32, [ctypes.POINTER(Config), u64, vp, vp, vp, vp, sz, vp, vp, vp, vp, pvp]),
         "cp2_proof_input_write_json": (i32, [vp, cp]),
         "cp2_proof_input_json": (i32, [vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz)]),
         "cp2_free_buffer": (None, [vp]),
@@ -467,7 +469,9 @@ class Dataset:
         e = _u8(entropy if not isinstance(entropy, int) else felt_bytes(entropy))
         h = ctypes.c_void_p()
         self.ctx._ck(self.ctx.L.cp2_proof_input_generate(self.h, slot_idx, _p(e), ctypes.byref(h)), "cp2_proof_input_generate")
-        return ProofInput(self.ctx, h, self.cfg)
+        pi = ProofInput(self.ctx, h, self.cfg)
+        pi.slot_idx = slot_idx
+        return pi
 
 
     def export_proof_inputs(self, slot_indices, entropy, directory=None, threads=1, batch=0):
@@ -557,6 +561,24 @@ class ProofInput:
 
     def slot_proof(self):
         return self._arr(self.ctx.L.cp2_proof_input_slot_proof(self.h), (self.cfg.max_log2_nslots, 32))
+
+    def leaf_hashes(self):
+        n = self.ctx.L.cp2_proof_input_nsamples(self.h)
+        return self._arr(self.ctx.L.cp2_proof_input_leaf_hashes(self.h), (n, 32))
+
+    def recreate(self):
+        """A copy made through cp2_proof_input_create from this object's accessor arrays (what the Nim shim's
+        exportProofInputBN254 does with a SlotProofInput value)."""
+        d, s, e = self.roots()
+        sp, idx, cells, paths, leaves = (np.ascontiguousarray(a) for a in
+                                         (self.slot_proof(), self.cell_indices(), self.cell_data(), self.merkle_paths(), self.leaf_hashes()))
+        slot_idx = getattr(self, "slot_idx", 0)
+        h = ctypes.c_void_p()
+        self.ctx._ck(self.ctx.L.cp2_proof_input_create(ctypes.byref(self.cfg), slot_idx, _p(d), _p(e), _p(s), _p(sp), idx.size,
+                                                       _p(idx), _p(cells), _p(paths), _p(leaves), ctypes.byref(h)), "cp2_proof_input_create")
+        q = ProofInput(self.ctx, h, self.cfg)
+        q.slot_idx = slot_idx
+        return q
 
     def json(self):
         text, ln = ctypes.c_void_p(), ctypes.c_size_t()

@@ -176,7 +176,7 @@ namespace {
 
 // device scratch of one sampling pass over up to `cap` (slot, counter) pairs
 struct SampleDev {
-  DevBuf entropy, slots, idx, gcell, rows, paths, cells;
+  DevBuf entropy, slots, idx, gcell, rows, paths, leaves, cells;
   size_t cap = 0;
   int init(cp2_ctx* ctx, size_t cap_items, size_t ns, size_t md, size_t cs, bool need_cells) {
     cap = cap_items * ns;
@@ -186,6 +186,7 @@ struct SampleDev {
     CP2_TRY(gcell.scratch(ctx, std::max<size_t>(cap, 1) * 8));
     CP2_TRY(rows.scratch(ctx, std::max<size_t>(cap * md, 1) * 8));
     CP2_TRY(paths.scratch(ctx, std::max<size_t>(cap * md, 1) * 32));
+    CP2_TRY(leaves.scratch(ctx, std::max<size_t>(cap, 1) * 32));
     if (need_cells) CP2_TRY(cells.scratch(ctx, std::max<size_t>(cap * cs, 1)));
     return CP2_OK;
   }
@@ -193,13 +194,14 @@ struct SampleDev {
 
 // pinned host landing zone of one pass
 struct SampleHost {
-  PinBuf idx, paths, cells;
+  PinBuf idx, paths, leaves, cells;
   hipStream_t stream = nullptr;   // downloads into these buffers are enqueued here: drained before the blocks go back to the pool
   ~SampleHost() { if (stream) (void)hipStreamSynchronize(stream); }
   int init(cp2_ctx* ctx, size_t cap_items, size_t ns, size_t md, size_t cs, bool need_cells) {
     const size_t cap = cap_items * ns;
     CP2_TRY(idx.alloc(ctx, std::max<size_t>(cap, 1) * 8));
     CP2_TRY(paths.alloc(ctx, std::max<size_t>(cap * md, 1) * 32));
+    CP2_TRY(leaves.alloc(ctx, std::max<size_t>(cap, 1) * 32));
     if (need_cells) CP2_TRY(cells.alloc(ctx, std::max<size_t>(cap * cs, 1)));
     return CP2_OK;
   }
@@ -226,6 +228,9 @@ int enqueue_sampling(cp2_slot_trees* t, const cp2k::TreeGeom& g, SampleDev& d, S
   CP2_HIP(ctx, cp2k::launch_gather_rows(t->nodes.p, rows, total * md, 32, d.paths.p, st));
   CP2_HIP(ctx, hipMemcpyAsync(host.idx.p, idx, total * 8, hipMemcpyDeviceToHost, st));
   CP2_HIP(ctx, hipMemcpyAsync(host.paths.p, d.paths.p, total * md * 32, hipMemcpyDeviceToHost, st));
+  // the sampled cells' own hashes (leafValue of the merged proof, merkle.nim:86-100): layer 0 rows are slot * n_cells + cell
+  CP2_HIP(ctx, cp2k::launch_gather_rows(t->nodes.p, gcell, total, 32, d.leaves.p, st));
+  CP2_HIP(ctx, hipMemcpyAsync(host.leaves.p, d.leaves.p, total * 32, hipMemcpyDeviceToHost, st));
   if (!fetch_cells) return CP2_OK;   // host-side sources: the caller reads the sampled cells itself
   if (t->src == CellSrc::Fake) {
     CP2_HIP(ctx, cp2k::launch_gen_fake_cells(cp2_slot_seed(t->dataset_seed, t->first_slot), t->n_cells, 0, gcell, total, cs, d.cells.p, st));
@@ -246,8 +251,9 @@ int enqueue_sampling(cp2_slot_trees* t, const cp2k::TreeGeom& g, SampleDev& d, S
 // cell bytes, Merkle paths and indices of a whole batch live in pinned blocks that every proof input of the batch
 // shares (one download each, no per-slot copies); the blocks return to the context's pool with the last reference
 struct BatchStore {
-  PinBuf idx, paths, cells;
+  PinBuf idx, paths, leaves, cells;
   std::vector<uint8_t> cells_heap;   // SlotFile / Host sources: sampled cells are read on the host
+  std::vector<uint8_t> heap;         // cp2_proof_input_create: everything copied from the caller
 };
 
 struct cp2_proof_input {
@@ -260,6 +266,7 @@ struct cp2_proof_input {
   const uint64_t* indices = nullptr;    // nSamples, inside store->idx
   const uint8_t* cell_data = nullptr;   // nSamples x cellSize, inside store->cells / cells_heap
   const uint8_t* paths = nullptr;       // nSamples x maxDepth x 32, inside store->paths
+  const uint8_t* leaves = nullptr;      // nSamples x 32: hash of each sampled cell (may be null for caller-made inputs)
 };
 
 // slotProof = padMerkleProof(merkleProof(dsetTree, slotIdx), maxLog2NSlots), gen_input/bn254.nim:51,72
@@ -349,6 +356,7 @@ extern "C" int cp2_proof_inputs_generate_batch(cp2_dataset* ds, const uint64_t* 
     trace.lap("sampling + gathers + downloads");
     store->idx.swap(host.idx);
     store->paths.swap(host.paths);
+    store->leaves.swap(host.leaves);
     if (dev_cells) {
       store->cells.swap(host.cells);
     } else {
@@ -381,6 +389,7 @@ extern "C" int cp2_proof_inputs_generate_batch(cp2_dataset* ds, const uint64_t* 
       p->indices = static_cast<const uint64_t*>(store->idx.p) + i * ns;
       p->cell_data = cells + i * ns * cs;
       p->paths = store->paths.u8() + i * ns * md * 32;
+      p->leaves = store->leaves.u8() + i * ns * 32;
     }
     out[i] = p;
   }
@@ -417,6 +426,51 @@ extern "C" const uint64_t* cp2_proof_input_cell_indices(const cp2_proof_input* p
 extern "C" const uint8_t* cp2_proof_input_cell_data(const cp2_proof_input* p) { return p ? p->cell_data : nullptr; }
 extern "C" const uint8_t* cp2_proof_input_merkle_paths(const cp2_proof_input* p) { return p ? p->paths : nullptr; }
 extern "C" const uint8_t* cp2_proof_input_slot_proof(const cp2_proof_input* p) { return p ? p->slot_proof.data() : nullptr; }
+extern "C" const uint8_t* cp2_proof_input_leaf_hashes(const cp2_proof_input* p) { return p ? p->leaves : nullptr; }
+
+// A proof input assembled from caller arrays (what the Nim shim's exportProofInputBN254 holds: a SlotProofInput[Hash]
+// value, types.nim:52-60), so that the byte-exact writer below can be used on it.  Everything is copied.
+extern "C" int cp2_proof_input_create(const cp2_config* cfg, uint64_t slot_idx, const uint8_t dataset_root[32], const uint8_t entropy[32],
+                                      const uint8_t slot_root[32], const uint8_t* slot_proof, size_t n_samples, const uint64_t* cell_indices,
+                                      const uint8_t* cell_data, const uint8_t* merkle_paths, const uint8_t* leaf_hashes,
+                                      cp2_proof_input** out) try {
+  if (!cfg || !dataset_root || !entropy || !slot_root || !out) return CP2_ERR_INVALID;
+  if (cfg->max_depth < 0 || cfg->max_log2_nslots < 0 || (cfg->max_log2_nslots && !slot_proof)) return CP2_ERR_INVALID;
+  if (n_samples && (!cell_data || !merkle_paths)) return CP2_ERR_INVALID;
+  *out = nullptr;
+  std::unique_ptr<cp2_proof_input> p(new cp2_proof_input());
+  p->cfg = *cfg;
+  p->cfg.file_base = nullptr;
+  p->cfg.n_samples = n_samples;
+  p->slot_idx = slot_idx;
+  std::memcpy(p->dataset_root, dataset_root, 32);
+  std::memcpy(p->entropy, entropy, 32);
+  std::memcpy(p->slot_root, slot_root, 32);
+  p->slot_proof.assign(slot_proof, slot_proof + (size_t)cfg->max_log2_nslots * 32);
+  p->n_samples = n_samples;
+  auto store = std::make_shared<BatchStore>();
+  const size_t md = (size_t)cfg->max_depth, cs = cfg->cell_size;
+  const size_t o_idx = 0, o_cells = o_idx + n_samples * 8, o_paths = o_cells + n_samples * cs, o_leaves = o_paths + n_samples * md * 32;
+  store->heap.assign(o_leaves + n_samples * 32 + 8, 0);
+  uint8_t* h = store->heap.data();
+  if (n_samples) {
+    if (cell_indices) std::memcpy(h + o_idx, cell_indices, n_samples * 8);
+    std::memcpy(h + o_cells, cell_data, n_samples * cs);
+    std::memcpy(h + o_paths, merkle_paths, n_samples * md * 32);
+    if (leaf_hashes) std::memcpy(h + o_leaves, leaf_hashes, n_samples * 32);
+  }
+  p->store = store;
+  p->indices = reinterpret_cast<const uint64_t*>(h + o_idx);   // the vector's storage is 16-byte aligned
+  p->cell_data = h + o_cells;
+  p->paths = h + o_paths;
+  p->leaves = leaf_hashes ? h + o_leaves : nullptr;
+  *out = p.release();
+  return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
+}
 
 // ---- JSON (json/bn254.nim:57-74, json/shared.nim:17-25, types/bn254.nim:29-43) -----------------
 namespace {

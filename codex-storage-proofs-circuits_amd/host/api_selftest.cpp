@@ -61,6 +61,29 @@ int main(int argc, char** argv) {
     std::printf("cellIndices");
     for (auto v : idx) std::printf(" %lld", (long long)v);
     std::printf("\n");
+    // the two top-level procs with the reference's own signatures (gen_input/bn254.nim:78, json/bn254.nim:77):
+    // every proof input carries the hash of its cell as leafValue, and a SlotProofInput VALUE (not an engine handle)
+    // exports to the byte-exact text (argv[2] = directory: pi.json, and pi_edited.json with entropy replaced)
+    {
+      GlobalConfig g2{10, 3, 128, 1024};
+      DataSetConfig d2;
+      d2.nSlots = 5; d2.nCells = 64; d2.nSamples = 6;
+      d2.dataSrc.kind = DataSourceKind::FakeData;
+      d2.dataSrc.seed = 777;
+      SlotProofInput pi = generateProofInputBN254(e, hashcfg, g2, d2, 3, intToBN254(31337));
+      bool leaves_ok = pi.proofInputs.size() == 6;
+      for (const CellProofInput& c : pi.proofInputs)
+        leaves_ok = leaves_ok && hashCell(e, hashcfg, g2, c.cellData) == c.merkleProof.leafValue && c.merkleProof.numberOfLeaves == 64;
+      std::printf("proof input leafValues: %s\n", leaves_ok ? "OK." : "FAILED!!");
+      all = all && leaves_ok;
+      if (argc > 2) {
+        std::string dir = argv[2];
+        exportProofInputBN254(hashcfg, dir + "/pi.json", pi);
+        SlotProofInput edited = pi;            // a plain value: no engine object behind it
+        edited.entropy = intToBN254(42);
+        exportProofInputBN254(hashcfg, dir + "/pi_edited.json", edited);
+      }
+    }
     bool threw = false;
     try { hashCell(e, hashcfg, glob, Cell(63)); } catch (const AssertionDefect&) { threw = true; }
     std::printf("hashCell wrong size asserts: %s\n", threw ? "yes" : "NO");

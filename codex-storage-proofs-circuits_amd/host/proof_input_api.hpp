@@ -69,7 +69,6 @@ struct SlotProofInput {         // types.nim:52-60
   SlotIdx slotIndex = 0;
   MerkleProof slotProof;
   std::vector<CellProofInput> proofInputs;
-  std::shared_ptr<cp2_proof_input> handle;   // keeps the engine-side object for exportProofInputBN254
 };
 
 inline int64_t cellsPerBlock(const GlobalConfig& glob) {   // types.nim:104-107
@@ -300,7 +299,7 @@ inline SlotProofInput generateProofInputBN254(Engine& e, const HashConfig& hashC
   cp2_proof_input* pi = nullptr;
   e.check(cp2_proof_input_generate(ds, (uint64_t)slotIdx, entropy.data(), &pi), "generateProofInput");
   SlotProofInput out;
-  out.handle = std::shared_ptr<cp2_proof_input>(pi, cp2_proof_input_free);
+  std::shared_ptr<cp2_proof_input> pi_guard(pi, cp2_proof_input_free);   // `out` is a plain value, as in the reference
   cp2_proof_input_roots(pi, out.dataSetRoot.data(), out.slotRoot.data(), out.entropy.data());
   out.nSlots = dsetCfg.nSlots; out.nCells = dsetCfg.nCells; out.slotIndex = slotIdx;
   out.slotProof.leafIndex = slotIdx; out.slotProof.leafValue = out.slotRoot; out.slotProof.numberOfLeaves = dsetCfg.nSlots;
@@ -310,10 +309,12 @@ inline SlotProofInput generateProofInputBN254(Engine& e, const HashConfig& hashC
   const uint64_t* idx = cp2_proof_input_cell_indices(pi);
   const uint8_t* cells = cp2_proof_input_cell_data(pi);
   const uint8_t* paths = cp2_proof_input_merkle_paths(pi);
+  const uint8_t* leaves = cp2_proof_input_leaf_hashes(pi);
   for (size_t i = 0; i < ns; ++i) {
     CellProofInput c;
     c.cellData.assign(cells + i * globCfg.cellSize, cells + (i + 1) * globCfg.cellSize);
     c.merkleProof.leafIndex = (int64_t)idx[i];
+    if (leaves) std::memcpy(c.merkleProof.leafValue.data(), leaves + 32 * i, 32);   // mergeMerkleProofs keeps the bottom leaf, merkle.nim:94
     c.merkleProof.numberOfLeaves = dsetCfg.nCells;
     c.merkleProof.merklePath.resize(globCfg.maxDepth);
     if (globCfg.maxDepth) std::memcpy(c.merkleProof.merklePath[0].data(), paths + i * globCfg.maxDepth * 32, globCfg.maxDepth * 32);
@@ -322,10 +323,34 @@ inline SlotProofInput generateProofInputBN254(Engine& e, const HashConfig& hashC
   return out;
 }
 
+// json/bn254.nim:77.  Works on ANY SlotProofInput value (as the reference's does): the fields are marshalled into an
+// engine object (cp2_proof_input_create) and written by the byte-exact writer.
 inline void exportProofInputBN254(const HashConfig& hashcfg, const std::string& fname, const SlotProofInput& prfInput) {
   doAssert(hashcfg.field == FieldSelect::BN254, "exportProofInputBN254: BN254 only");
-  doAssert((bool)prfInput.handle, "exportProofInputBN254: proof input was not produced by generateProofInputBN254");
-  int st = cp2_proof_input_write_json(prfInput.handle.get(), fname.c_str());
+  const size_t ns = prfInput.proofInputs.size();
+  cp2_config cfg{};
+  cfg.max_log2_nslots = (int32_t)prfInput.slotProof.merklePath.size();
+  cfg.max_depth = ns ? (int32_t)prfInput.proofInputs[0].merkleProof.merklePath.size() : 0;
+  cfg.cell_size = ns ? prfInput.proofInputs[0].cellData.size() : 0;
+  cfg.n_slots = (uint64_t)prfInput.nSlots;
+  cfg.n_cells = (uint64_t)prfInput.nCells;
+  std::vector<uint8_t> proof((size_t)cfg.max_log2_nslots * 32), cells(ns * cfg.cell_size), paths(ns * (size_t)cfg.max_depth * 32);
+  std::vector<uint64_t> idx(ns);
+  for (size_t i = 0; i < proof.size() / 32; ++i) std::memcpy(&proof[32 * i], prfInput.slotProof.merklePath[i].data(), 32);
+  for (size_t i = 0; i < ns; ++i) {
+    const CellProofInput& c = prfInput.proofInputs[i];
+    doAssert(c.cellData.size() == cfg.cell_size && c.merkleProof.merklePath.size() == (size_t)cfg.max_depth, "exportProofInput: ragged proof inputs");
+    idx[i] = (uint64_t)c.merkleProof.leafIndex;
+    std::memcpy(&cells[i * cfg.cell_size], c.cellData.data(), cfg.cell_size);
+    for (size_t d = 0; d < (size_t)cfg.max_depth; ++d) std::memcpy(&paths[(i * cfg.max_depth + d) * 32], c.merkleProof.merklePath[d].data(), 32);
+  }
+  cp2_proof_input* pi = nullptr;
+  int st = cp2_proof_input_create(&cfg, (uint64_t)prfInput.slotIndex, prfInput.dataSetRoot.data(), prfInput.entropy.data(), prfInput.slotRoot.data(),
+                                  proof.data(), ns, idx.data(), cells.data(), paths.data(), nullptr, &pi);
+  if (st == CP2_OK) {
+    st = cp2_proof_input_write_json(pi, fname.c_str());
+    cp2_proof_input_free(pi);
+  }
   if (st != CP2_OK) throw std::runtime_error(std::string("exportProofInput: ") + cp2_strerror(st));
 }
 

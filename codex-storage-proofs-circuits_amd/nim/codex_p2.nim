@@ -6,10 +6,10 @@
 ## never been compiled.  It is deliberately thin and mechanical: one `importc` per C entry point, plus the
 ## handful of procs whose names the reference's modules import.
 ##
-## Usage inside the reference tree: replace
-##   import poseidon2/types, poseidon2/io, poseidon2/sponge, poseidon2/compress, poseidon2/merkle
-## in src/types/bn254.nim, src/blocks/bn254.nim, src/merkle/bn254.nim, src/sample/bn254.nim,
-## src/json/bn254.nim by `import codex_p2`, and build with
+## Usage inside the reference tree (INTEGRATION.md section 2): copy this file to reference/nim/proof_input/src/ and
+## copy nim/overlay/src/* over the same-named modules there.  The overlay modules export the reference's own
+## procs with the reference's own signatures (generateProofInputBN254, exportProofInputBN254, merkleTreeBN254,
+## hashCell, cellIndices, ...), so cli.nim and every other importer compile unchanged; build with
 ##   nim c -d:release --passL:"-L<repo>/codex-storage-proofs-circuits_amd -lcodex_p2" src/cli.nim
 
 const libName = "libcodex_p2.so"
@@ -48,6 +48,16 @@ proc cp2_dataset_free(ds: Cp2Dataset) {.importc.}
 proc cp2_proof_input_generate(ds: Cp2Dataset, slotIdx: uint64, entropy: ptr byte, p: ptr Cp2ProofInput): cint {.importc.}
 proc cp2_proof_input_free(p: Cp2ProofInput) {.importc.}
 proc cp2_proof_input_write_json(p: Cp2ProofInput, path: cstring): cint {.importc.}
+proc cp2_proof_input_roots(p: Cp2ProofInput, datasetRoot, slotRoot, entropy: ptr byte): cint {.importc.}
+proc cp2_proof_input_nsamples(p: Cp2ProofInput): csize_t {.importc.}
+proc cp2_proof_input_cell_indices(p: Cp2ProofInput): ptr UncheckedArray[uint64] {.importc.}
+proc cp2_proof_input_cell_data(p: Cp2ProofInput): ptr UncheckedArray[byte] {.importc.}
+proc cp2_proof_input_merkle_paths(p: Cp2ProofInput): ptr UncheckedArray[byte] {.importc.}
+proc cp2_proof_input_slot_proof(p: Cp2ProofInput): ptr UncheckedArray[byte] {.importc.}
+proc cp2_proof_input_leaf_hashes(p: Cp2ProofInput): ptr UncheckedArray[byte] {.importc.}
+proc cp2_proof_input_create(cfg: ptr Cp2Config, slotIdx: uint64, datasetRoot, entropy, slotRoot, slotProof: ptr byte,
+                            nSamples: csize_t, cellIndices: ptr uint64, cellData, merklePaths, leafHashes: ptr byte,
+                            p: ptr Cp2ProofInput): cint {.importc.}
 proc cp2_write_circom_main(cfg: ptr Cp2Config, path: cstring): cint {.importc.}
 {.pop.}
 
@@ -91,6 +101,13 @@ proc digest*(_: type Sponge, input: openArray[byte], rate: static int = 2): F =
   static: doAssert rate == 2
   check(cp2_hash_cells(ctx(), unsafeAddr input[0], csize_t(input.len), 1, addr result[0]), "Sponge.digest(bytes)")
 
+proc hashCells*(data: openArray[byte], cellSize: int): seq[F] =
+  ## data.len / cellSize cells hashed in one launch (blocks/bn254.nim:23-29 applied to every cell of a block)
+  doAssert cellSize > 0 and data.len mod cellSize == 0
+  result = newSeq[F](data.len div cellSize)
+  if result.len > 0:
+    check(cp2_hash_cells(ctx(), unsafeAddr data[0], csize_t(cellSize), csize_t(result.len), cast[ptr byte](addr result[0])), "hashCells")
+
 proc digest*(_: type Merkle, xs: openArray[F]): F =
   ## Merkle.digest (merkle/bn254.nim:20)
   check(cp2_merkle_root(ctx(), cast[ptr byte](unsafeAddr xs[0]), csize_t(xs.len), addr result[0]), "Merkle.digest")
@@ -123,9 +140,22 @@ func toDecimal*(a: F): string =
 func bit*(a: F, i: int): uint64 = uint64((a[i shr 3] shr (i and 7)) and 1)   ## constantine `bit` (types/bn254.nim:51)
 func toBig*(a: F): F = a                                                      ## already canonical
 
-# ---- the whole-path entry points (gen_input/bn254.nim:78, json/bn254.nim:77, cli.nim:186) -------------------
-proc generateAndExportProofInputBN254*(cfg: var Cp2Config, slotIdx: int, entropy: F, fname: string) =
-  ## generateProofInputBN254 + exportProofInputBN254 in one call: builds every slot tree once on the GPU
+# ---- the whole path as plain Nim values (used by overlay/src/gen_input/bn254.nim and overlay/src/json/bn254.nim) ------
+type EngineProofInput* = object
+  ## what cp2_proof_input's accessors return, copied into GC-owned Nim values
+  dataSetRoot*, slotRoot*, entropy*: F
+  slotProof*:   seq[F]            ## maxLog2NSlots elements, zero padded
+  cellIndices*: seq[int]
+  cellData*:    seq[seq[byte]]    ## nSamples cells
+  merklePaths*: seq[seq[F]]       ## nSamples x maxDepth, zero padded
+  leafHashes*:  seq[F]            ## hash of each sampled cell
+
+proc felt(p: ptr UncheckedArray[byte], i: int): F =
+  for k in 0 ..< 32: result[k] = p[32 * i + k]
+
+proc engineGenerateProofInput*(cfg: var Cp2Config, slotIdx: int, entropy: F): EngineProofInput =
+  ## every slot tree built once on the GPU, then sampling + paths + cells for `slotIdx`
+  ## (the whole of gen_input/bn254.nim:35-74)
   var ds: Cp2Dataset
   check(cp2_dataset_build(ctx(), addr cfg, 0, cfg.nSlots, addr ds), "cp2_dataset_build")
   defer: cp2_dataset_free(ds)
@@ -133,7 +163,73 @@ proc generateAndExportProofInputBN254*(cfg: var Cp2Config, slotIdx: int, entropy
   var e = entropy
   check(cp2_proof_input_generate(ds, uint64(slotIdx), addr e[0], addr p), "cp2_proof_input_generate")
   defer: cp2_proof_input_free(p)
+  check(cp2_proof_input_roots(p, addr result.dataSetRoot[0], addr result.slotRoot[0], addr result.entropy[0]), "cp2_proof_input_roots")
+  let ns = int(cp2_proof_input_nsamples(p))
+  let md = int(cfg.maxDepth)
+  let cs = int(cfg.cellSize)
+  let sp = cp2_proof_input_slot_proof(p)
+  for i in 0 ..< int(cfg.maxLog2NSlots): result.slotProof.add(felt(sp, i))
+  let idx = cp2_proof_input_cell_indices(p)
+  let cells = cp2_proof_input_cell_data(p)
+  let paths = cp2_proof_input_merkle_paths(p)
+  let leaves = cp2_proof_input_leaf_hashes(p)
+  for i in 0 ..< ns:
+    result.cellIndices.add(int(idx[i]))
+    var cell = newSeq[byte](cs)
+    for k in 0 ..< cs: cell[k] = cells[i * cs + k]
+    result.cellData.add(cell)
+    var path = newSeq[F](md)
+    for d in 0 ..< md: path[d] = felt(paths, i * md + d)
+    result.merklePaths.add(path)
+    result.leafHashes.add(felt(leaves, i))
+
+proc engineWriteProofInputJson*(cfg: var Cp2Config, slotIdx: int, v: EngineProofInput, fname: string) =
+  ## json/bn254.nim:57-74 through the engine's byte-exact writer, from plain values
+  let ns = v.cellData.len
+  let md = int(cfg.maxDepth)
+  let cs = int(cfg.cellSize)
+  var proof = newSeq[byte](max(1, v.slotProof.len * 32))
+  for i in 0 ..< v.slotProof.len:
+    for k in 0 ..< 32: proof[32 * i + k] = v.slotProof[i][k]
+  var idx = newSeq[uint64](max(1, ns))
+  var cells = newSeq[byte](max(1, ns * cs))
+  var paths = newSeq[byte](max(1, ns * md * 32))
+  for i in 0 ..< ns:
+    if i < v.cellIndices.len: idx[i] = uint64(v.cellIndices[i])
+    doAssert v.cellData[i].len == cs and v.merklePaths[i].len == md
+    for k in 0 ..< cs: cells[i * cs + k] = v.cellData[i][k]
+    for d in 0 ..< md:
+      for k in 0 ..< 32: paths[(i * md + d) * 32 + k] = v.merklePaths[i][d][k]
+  var dr = v.dataSetRoot
+  var en = v.entropy
+  var sr = v.slotRoot
+  var p: Cp2ProofInput
+  check(cp2_proof_input_create(addr cfg, uint64(slotIdx), addr dr[0], addr en[0], addr sr[0], addr proof[0], csize_t(ns),
+                               addr idx[0], addr cells[0], addr paths[0], nil, addr p), "cp2_proof_input_create")
+  defer: cp2_proof_input_free(p)
   check(cp2_proof_input_write_json(p, cstring(fname)), "cp2_proof_input_write_json")
+
+proc engineMerkleLayers*(xs: openArray[F]): seq[seq[F]] =
+  ## all layers, bottom first (merkle/bn254.nim:24-63), through cp2_merkle_tree
+  doAssert xs.len > 0
+  let total = int(cp2_merkle_total(csize_t(xs.len)))
+  var flat = newSeq[F](total)
+  var sizes = newSeq[csize_t](80)
+  var nl: csize_t
+  check(cp2_merkle_tree(ctx(), cast[ptr byte](unsafeAddr xs[0]), csize_t(xs.len), cast[ptr byte](addr flat[0]),
+                        addr sizes[0], addr nl), "cp2_merkle_tree")
+  var off = 0
+  for k in 0 ..< int(nl):
+    result.add(flat[off ..< off + int(sizes[k])])
+    off += int(sizes[k])
+
+proc engineCellIndices*(entropy, slotRoot: F, numberOfCells, nSamples: int): seq[int] =
+  ## sample/bn254.nim:16-27 for counters 1..nSamples in one launch
+  var raw = newSeq[uint64](max(1, nSamples))
+  var e = entropy
+  var r = slotRoot
+  check(cp2_cell_indices(ctx(), addr e[0], addr r[0], uint64(numberOfCells), csize_t(nSamples), addr raw[0]), "cp2_cell_indices")
+  for i in 0 ..< nSamples: result.add(int(raw[i]))
 
 proc writeCircomMainComponentP2*(cfg: var Cp2Config, fname: string) =
   check(cp2_write_circom_main(addr cfg, cstring(fname)), "cp2_write_circom_main")

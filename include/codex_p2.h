@@ -209,6 +209,17 @@ const uint64_t* cp2_proof_input_cell_indices(const cp2_proof_input* p);
 const uint8_t* cp2_proof_input_cell_data(const cp2_proof_input* p);     /* nSamples x cellSize bytes      */
 const uint8_t* cp2_proof_input_merkle_paths(const cp2_proof_input* p);  /* nSamples x maxDepth x 32 bytes */
 const uint8_t* cp2_proof_input_slot_proof(const cp2_proof_input* p);    /* maxLog2NSlots x 32 bytes       */
+/* hash of each sampled cell = `leafValue` of its merged proof (merkle.nim:86-100); nSamples x 32 bytes, or NULL for an
+ * object made by cp2_proof_input_create without them */
+const uint8_t* cp2_proof_input_leaf_hashes(const cp2_proof_input* p);
+/* A proof input assembled from caller arrays -- what a `SlotProofInput[Hash]` value holds (types.nim:52-60) -- so that
+ * `exportProofInputBN254(hashcfg, fname, prfInput)` (json/bn254.nim:77) can hand any such value to the byte-exact writer.
+ * cfg supplies maxDepth, maxLog2NSlots, cellSize, nCells, nSlots; arrays as the accessors above return them; cell_indices
+ * and leaf_hashes may be NULL (neither is printed).  Everything is copied; free with cp2_proof_input_free. */
+int cp2_proof_input_create(const cp2_config* cfg, uint64_t slot_idx, const uint8_t dataset_root[32], const uint8_t entropy[32],
+                           const uint8_t slot_root[32], const uint8_t* slot_proof, size_t n_samples, const uint64_t* cell_indices,
+                           const uint8_t* cell_data, const uint8_t* merkle_paths, const uint8_t* leaf_hashes,
+                           cp2_proof_input** out);
 /* replaces `exportProofInputBN254`, reference/nim/proof_input/src/json/bn254.nim:57-78: byte-exact JSON */
 int cp2_proof_input_write_json(const cp2_proof_input* p, const char* path);
 /* the same text into a malloc'ed buffer (caller frees with cp2_free_buffer) */

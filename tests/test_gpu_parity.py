@@ -413,15 +413,22 @@ def test_cli_twin_params_sh_defaults(pkg, golden, tmp_path):
     assert r.returncode != 0 and "bn254" in r.stderr
 
 
-def test_cpp_mirror_of_nim_interface(pkg, oracle):
+def test_cpp_mirror_of_nim_interface(pkg, oracle, tmp_path):
     import os
     import subprocess
     C, P = oracle
     exe = os.path.join(os.path.dirname(pkg.LIB_PATH), "api_selftest")
-    r = subprocess.run([exe, "12"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, "12", str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = r.stdout.strip().split("\n")
     assert lines[-1] == "ALL OK"
+    assert "proof input leafValues: OK." in lines
+    # generateProofInputBN254 / exportProofInputBN254 with the reference's signatures: a SlotProofInput VALUE exports to
+    # the oracle's text; an edited copy of the value exports with the edit (nothing hidden behind an engine handle)
+    c = dict(maxDepth=10, maxLog2NSlots=3, cellSize=128, blockSize=1024, nSlots=5, nCells=64, nSamples=6, seed=777)
+    want = P.generate_proof_input(c, 3, 31337)
+    assert open(tmp_path / "pi.json").read() == P.export_json(want)
+    assert open(tmp_path / "pi_edited.json").read() == P.export_json(dict(want, entropy=42))
     vals = {l.split(" ")[0]: l.split(" ")[1] for l in lines if " 0x" in l}
     for n in range(1, 13):
         assert int(vals["root[%d]" % n], 16) == P.merkle_root([100 + i for i in range(n)])
@@ -433,6 +440,19 @@ def test_cpp_mirror_of_nim_interface(pkg, oracle):
     assert [int(vals["path[%d]" % i], 16) for i in range(8)] == want["merklePath"]
     idx_line = [l for l in lines if l.startswith("cellIndices")][0]
     assert [int(v) for v in idx_line.split()[1:]] == P.cell_indices(1234567, big[-1][0], 16, 6)
+
+
+def test_leaf_hashes_and_proof_input_from_parts(pkg, ctx, oracle, golden):
+    """cp2_proof_input_leaf_hashes = hash of each sampled cell (leafValue of the merged proof, merkle.nim:86-100);
+    cp2_proof_input_create from the accessor arrays gives the same text (the Nim shim's exportProofInputBN254 route)."""
+    C, _ = oracle
+    m = golden("proof_inputs.json")["inputs"]["testmain_small"]
+    cfg = pkg.make_config(**m["config"])
+    pi = ctx.dataset(cfg).proof_input(m["slotIndex"], m["entropy"])
+    assert np.array_equal(pi.leaf_hashes(), C.hash_cells(pi.cell_data(), m["config"]["cellSize"], threads=2))
+    copy = pi.recreate()
+    assert copy.json() == pi.json() == golden("input_testmain_small.json")
+    assert np.array_equal(copy.leaf_hashes(), pi.leaf_hashes()) and np.array_equal(copy.cell_indices(), pi.cell_indices())
 
 
 def test_batched_proof_inputs_equal_single(pkg, ctx, golden, tmp_path):
