@@ -227,9 +227,11 @@ class Context:
         self._ck(self.L.cp2_set_ingest(self.h, fill_threads, ring_depth, chunk_bytes), "cp2_set_ingest")
 
     # -- a1
-    def permute_batch(self, states):
+    def permute_batch(self, states, out=None):
         s = _u8(states).reshape(-1, 96)
-        out = np.empty_like(s)
+        if out is None:
+            out = np.empty_like(s)
+        assert out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"] and out.size == s.size
         self._ck(self.L.cp2_permute_batch(self.h, _p(s), _p(out), s.shape[0]), "cp2_permute_batch")
         return out
 

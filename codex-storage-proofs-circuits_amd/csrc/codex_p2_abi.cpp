@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -125,18 +126,109 @@ extern "C" int cp2_permute_batch_dev(cp2_ctx* ctx, const void* d_in, void* d_out
   return CP2_ERR_INVALID;
 }
 
+// Host arrays through the GPU in chunks: out[i] = kernel(in[i]) for n items.  Three stages on three streams over a
+// 3-deep ring of pinned + device buffers -- upload of chunk i+1, kernel of chunk i and download of chunk i-1 overlap
+// (PCIe is full duplex), and a few host threads copy between the caller's pageable arrays and the pinned ring.
+// Small inputs take one upload / launch / download on the context's stream with pooled scratch.
+namespace {
+template <typename Launch>
+int stream_map(cp2_ctx* ctx, const uint8_t* in, size_t in_item, uint8_t* out, size_t out_item, size_t n, Launch launch) {
+  constexpr size_t CHUNK = (size_t)1 << 20;   // items per chunk: 4096 workgroups, several residencies of any kernel here
+  constexpr int DEPTH = 3;
+  if (n <= CHUNK) {
+    DevBuf d_in, d_out;
+    CP2_TRY(d_in.scratch(ctx, n * in_item));
+    CP2_TRY(d_out.scratch(ctx, n * out_item));
+    CP2_HIP(ctx, hipMemcpyAsync(d_in.p, in, n * in_item, hipMemcpyHostToDevice, ctx->stream));
+    CP2_HIP(ctx, launch(d_in.p, d_out.p, n, ctx->stream));
+    CP2_HIP(ctx, hipMemcpyAsync(out, d_out.p, n * out_item, hipMemcpyDeviceToHost, ctx->stream));
+    CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CP2_OK;
+  }
+  struct Ring {
+    cp2_ctx* ctx;
+    hipStream_t up = nullptr, down = nullptr;
+    hipEvent_t e_up[DEPTH] = {}, e_k[DEPTH] = {}, e_down[DEPTH] = {};
+    PinBuf pin_in[DEPTH], pin_out[DEPTH];
+    DevBuf d_in[DEPTH], d_out[DEPTH];
+    ~Ring() {   // drain everything before the buffers go back to the pools
+      if (up) (void)hipStreamSynchronize(up);
+      (void)hipStreamSynchronize(ctx->stream);
+      if (down) (void)hipStreamSynchronize(down);
+      for (int r = 0; r < DEPTH; ++r) {
+        if (e_up[r]) (void)hipEventDestroy(e_up[r]);
+        if (e_k[r]) (void)hipEventDestroy(e_k[r]);
+        if (e_down[r]) (void)hipEventDestroy(e_down[r]);
+      }
+      if (up) (void)hipStreamDestroy(up);
+      if (down) (void)hipStreamDestroy(down);
+    }
+  } ring{ctx};
+  CP2_HIP(ctx, hipStreamCreateWithFlags(&ring.up, hipStreamNonBlocking));
+  CP2_HIP(ctx, hipStreamCreateWithFlags(&ring.down, hipStreamNonBlocking));
+  for (int r = 0; r < DEPTH; ++r) {
+    CP2_HIP(ctx, hipEventCreateWithFlags(&ring.e_up[r], hipEventDisableTiming));
+    CP2_HIP(ctx, hipEventCreateWithFlags(&ring.e_k[r], hipEventDisableTiming));
+    CP2_HIP(ctx, hipEventCreateWithFlags(&ring.e_down[r], hipEventDisableTiming));
+    CP2_TRY(ring.pin_in[r].alloc(ctx, CHUNK * in_item));
+    CP2_TRY(ring.pin_out[r].alloc(ctx, CHUNK * out_item));
+    CP2_TRY(ring.d_in[r].scratch(ctx, CHUNK * in_item));
+    CP2_TRY(ring.d_out[r].scratch(ctx, CHUNK * out_item));
+  }
+  const int threads = ctx->ingest_threads > 0 ? ctx->ingest_threads : 8;
+  Workers pool(threads > 1 ? threads - 1 : 1);
+  auto par_copy = [&](uint8_t* dst, const uint8_t* src, size_t bytes) {
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, bytes >> 21));
+    for (int t = 1; t < nt; ++t) pool.submit([=] { std::memcpy(dst + bytes * t / nt, src + bytes * t / nt, bytes * (t + 1) / nt - bytes * t / nt); });
+    std::memcpy(dst, src, bytes / nt);
+    pool.wait_idle();
+  };
+  const size_t n_chunks = (n + CHUNK - 1) / CHUNK;
+  const bool trace = std::getenv("CP2_TRACE") != nullptr;
+  double t_wait = 0, t_drain = 0, t_fill = 0, t_enq = 0;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  auto drain = [&](size_t c) -> int {   // chunk c's results from the pinned ring into the caller's array
+    const int r = (int)(c % DEPTH);
+    double a = now();
+    CP2_HIP(ctx, hipEventSynchronize(ring.e_down[r]));
+    double b = now();
+    const size_t m = std::min(CHUNK, n - c * CHUNK);
+    par_copy(out + c * CHUNK * out_item, ring.pin_out[r].u8(), m * out_item);
+    t_wait += b - a;
+    t_drain += now() - b;
+    return CP2_OK;
+  };
+  for (size_t c = 0; c < n_chunks; ++c) {
+    const int r = (int)(c % DEPTH);
+    if (c >= DEPTH) CP2_TRY(drain(c - DEPTH));   // frees ring slot r (its upload and kernel finished before its download)
+    const size_t m = std::min(CHUNK, n - c * CHUNK);
+    double a = now();
+    par_copy(ring.pin_in[r].u8(), in + c * CHUNK * in_item, m * in_item);
+    double b = now();
+    t_fill += b - a;
+    CP2_HIP(ctx, hipMemcpyAsync(ring.d_in[r].p, ring.pin_in[r].p, m * in_item, hipMemcpyHostToDevice, ring.up));
+    CP2_HIP(ctx, hipEventRecord(ring.e_up[r], ring.up));
+    CP2_HIP(ctx, hipStreamWaitEvent(ctx->stream, ring.e_up[r], 0));
+    CP2_HIP(ctx, launch(ring.d_in[r].p, ring.d_out[r].p, m, ctx->stream));
+    CP2_HIP(ctx, hipEventRecord(ring.e_k[r], ctx->stream));
+    CP2_HIP(ctx, hipStreamWaitEvent(ring.down, ring.e_k[r], 0));
+    CP2_HIP(ctx, hipMemcpyAsync(ring.pin_out[r].p, ring.d_out[r].p, m * out_item, hipMemcpyDeviceToHost, ring.down));
+    CP2_HIP(ctx, hipEventRecord(ring.e_down[r], ring.down));
+    t_enq += now() - b;
+  }
+  for (size_t c = n_chunks > DEPTH ? n_chunks - DEPTH : 0; c < n_chunks; ++c) CP2_TRY(drain(c));
+  if (trace)
+    std::fprintf(stderr, "[cp2 trace] stream_map %zu chunks: fill %.2f ms, enqueue %.2f ms, wait for downloads %.2f ms, drain %.2f ms\n",
+                 n_chunks, t_fill, t_enq, t_wait, t_drain);
+  return CP2_OK;
+}
+}  // namespace
+
 extern "C" int cp2_permute_batch(cp2_ctx* ctx, const uint8_t* in, uint8_t* out, size_t n) try {
   if (!ctx || (n && (!in || !out))) return CP2_ERR_INVALID;
   if (n == 0) return CP2_OK;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
-  DevBuf d_in, d_out;
-  CP2_TRY(d_in.scratch(ctx, n * 96));
-  CP2_TRY(d_out.scratch(ctx, n * 96));
-  CP2_HIP(ctx, hipMemcpyAsync(d_in.p, in, n * 96, hipMemcpyHostToDevice, ctx->stream));
-  CP2_TRY(cp2_permute_batch_dev(ctx, d_in.p, d_out.p, n));
-  CP2_HIP(ctx, hipMemcpyAsync(out, d_out.p, n * 96, hipMemcpyDeviceToHost, ctx->stream));
-  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return CP2_OK;
+  return stream_map(ctx, in, 96, out, 96, n, [](const void* i, void* o, size_t m, hipStream_t st) { return cp2k::launch_permute_batch(i, o, m, st); });
 } catch (const std::bad_alloc&) {
   return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
 } catch (...) {
@@ -150,15 +242,8 @@ extern "C" int cp2_compress_batch(cp2_ctx* ctx, const uint8_t* xy, uint32_t key,
   if (!ctx || key > 3 || (n && (!xy || !out))) return CP2_ERR_INVALID;
   if (n == 0) return CP2_OK;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
-  // build (x, y, key) states and run the permutation kernel; keep the first element of each result
-  std::vector<uint8_t> st(n * 96, 0), res(n * 96);
-  for (size_t i = 0; i < n; ++i) {
-    std::memcpy(&st[96 * i], xy + 64 * i, 64);
-    st[96 * i + 64] = (uint8_t)key;
-  }
-  CP2_TRY(cp2_permute_batch(ctx, st.data(), res.data(), n));
-  for (size_t i = 0; i < n; ++i) std::memcpy(out + 32 * i, &res[96 * i], 32);
-  return CP2_OK;
+  return stream_map(ctx, xy, 64, out, 32, n,
+                    [key](const void* i, void* o, size_t m, hipStream_t st) { return cp2k::launch_compress_pairs(i, key, o, m, st); });
 } catch (const std::bad_alloc&) {
   return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
 } catch (...) {

@@ -122,6 +122,25 @@ template <typename... T> inline void tie(acc_t&, T&...) {}
 #include "fr_tie.inc"
 #endif
 
+// Experiment hook (tools/pad_probe.py; never defined in a product build): CP2_PAD_ASM is one instruction on the dummy
+// operands %0, %1, %3 (32-bit VGPRs) and %2, %4 (64-bit VGPR pairs); it is issued CP2_PAD_N times after every column of every
+// multiplication.  The slowdown per added instruction is that instruction's MARGINAL cost inside this kernel, which is
+// what decides whether trading one instruction for another pays.
+#if defined(CP2_PAD_ASM) && !defined(CP2_HOST_CHECK)
+#ifndef CP2_PAD_N
+#define CP2_PAD_N 2
+#endif
+#define CP2_PAD_DECL uint32_t pad0__ = a_in.l[0], pad1__ = a_in.l[1], pad3__ = a_in.l[3]; uint64_t pad2__ = a_in.l[2], pad4__ = a_in.l[4];
+#define CP2_PAD()                                                                                         \
+  do {                                                                                                    \
+    _Pragma("unroll") for (int p__ = 0; p__ < CP2_PAD_N; ++p__)                                           \
+        asm volatile(CP2_PAD_ASM : "+v"(pad0__), "+v"(pad1__), "+v"(pad2__), "+v"(pad3__), "+v"(pad4__) : : "vcc");  \
+  } while (0)
+#else
+#define CP2_PAD_DECL
+#define CP2_PAD() ((void)0)
+#endif
+
 template <int A0, int M0, int... I>
 __device__ __forceinline__ void tie_cols(acc_t& acc, uint32_t (&a)[NL], uint32_t (&m)[NL], std::integer_sequence<int, I...>,
                                          std::integer_sequence<int>) {
@@ -143,6 +162,7 @@ __device__ __forceinline__ Fe mont_mul(const Fe& a_in, const Fe& b) {
   for (int i = 0; i < NL; ++i)   // La * Lb < 6.1 U^2 (column sum < 2^64); checked limb by limb against the worst partner
     CP2_BOUND((uint64_t)a_in.l[i] < ((uint64_t)5 << 29) && (uint64_t)b.l[i] < ((uint64_t)5 << 29), "mont_mul operand limb >= 5U");
   acc_t acc = 0;
+  CP2_PAD_DECL
   auto lo_col = [&](auto kc) {
     constexpr int k = decltype(kc)::value;
     if constexpr (k > 0) tie_cols<0, 0>(acc, a, m, std::make_integer_sequence<int, k + 1>{}, std::make_integer_sequence<int, k>{});
@@ -153,6 +173,7 @@ __device__ __forceinline__ Fe mont_mul(const Fe& a_in, const Fe& b) {
     m[k] = ((uint32_t)acc * FR_NPRIME) & MASK;
     acc += (uint64_t)m[k] * FR_N[0];
     acc >>= 29;
+    CP2_PAD();
   };
   auto hi_col = [&](auto kc) {
     constexpr int k = decltype(kc)::value;
@@ -164,6 +185,7 @@ __device__ __forceinline__ Fe mont_mul(const Fe& a_in, const Fe& b) {
     for (int i = lo; i < NL; ++i) acc += (uint64_t)m[i] * FR_N[k - i];
     r.l[k - NL] = (uint32_t)acc & MASK;
     acc >>= 29;
+    CP2_PAD();
   };
   lo_col(std::integral_constant<int, 0>{}); lo_col(std::integral_constant<int, 1>{}); lo_col(std::integral_constant<int, 2>{});
   lo_col(std::integral_constant<int, 3>{}); lo_col(std::integral_constant<int, 4>{}); lo_col(std::integral_constant<int, 5>{});
@@ -193,6 +215,7 @@ __device__ __forceinline__ Fe mont_sqr(const Fe& a_in) {
     d[i] = a[i] << 1;   // limbs < 2.47 U  =>  doubled < 2^32
   }
   acc_t acc = 0;
+  CP2_PAD_DECL
   auto lo_col = [&](auto kc) {
     constexpr int k = decltype(kc)::value;
     if constexpr (k > 0) tie_sq<0>(acc, a, d, m, std::make_integer_sequence<int, k + 1>{}, std::make_integer_sequence<int, k>{});
@@ -204,6 +227,7 @@ __device__ __forceinline__ Fe mont_sqr(const Fe& a_in) {
     m[k] = ((uint32_t)acc * FR_NPRIME) & MASK;
     acc += (uint64_t)m[k] * FR_N[0];
     acc >>= 29;
+    CP2_PAD();
   };
   auto hi_col = [&](auto kc) {
     constexpr int k = decltype(kc)::value;
@@ -216,6 +240,7 @@ __device__ __forceinline__ Fe mont_sqr(const Fe& a_in) {
     for (int i = lo; i < NL; ++i) acc += (uint64_t)m[i] * FR_N[k - i];
     r.l[k - NL] = (uint32_t)acc & MASK;
     acc >>= 29;
+    CP2_PAD();
   };
   lo_col(std::integral_constant<int, 0>{}); lo_col(std::integral_constant<int, 1>{}); lo_col(std::integral_constant<int, 2>{});
   lo_col(std::integral_constant<int, 3>{}); lo_col(std::integral_constant<int, 4>{}); lo_col(std::integral_constant<int, 5>{});

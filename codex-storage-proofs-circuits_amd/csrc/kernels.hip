@@ -89,6 +89,22 @@ __global__ void __launch_bounds__(TPB) k_compress_layer(const uint4* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// compress(x, y, key) for n independent pairs (merkle/bn254.nim:18): the seam call `compressWithKey`, batched.
+__global__ void __launch_bounds__(TPB) k_compress_pairs(const uint4* __restrict__ xy, uint32_t key, uint4* __restrict__ out, size_t n) {
+  __shared__ uint32_t qtab[fr::QTAB_WORDS];
+  fr::qtab_fill(qtab, threadIdx.x, TPB);
+  __syncthreads();
+  size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (t >= n) return;
+  State s;
+  s.x = load_fe_canonical(xy + 4 * t);
+  s.y = load_fe_canonical(xy + 4 * t + 2);
+  s.z = key_fe(key);
+  p2::permute(s, qtab);
+  store_fe_canonical(out + 2 * t, s.x);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Batched rate-2 sponge over field elements (Sponge.hs:30-43): item i hashes felts[i*nf .. i*nf+nf).
 __global__ void __launch_bounds__(TPB) k_sponge2_felts(const uint4* __restrict__ felts, size_t nf, size_t nitems,
                                                          uint4* __restrict__ out) {
@@ -385,6 +401,12 @@ hipError_t launch_compress_layer(const void* in, void* out, size_t m_in, size_t 
   if (m_out * nseg == 0) return hipSuccess;
   hipLaunchKernelGGL(k_compress_layer, dim3(grid_for(m_out * nseg)), dim3(TPB), 0, st, (const uint4*)in, (uint4*)out,
                      m_in, m_out, nseg, bottom ? 1u : 0u, in_seg_stride, out_seg_stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_compress_pairs(const void* xy, uint32_t key, void* out, size_t n, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_compress_pairs, dim3(grid_for(n)), dim3(TPB), 0, st, (const uint4*)xy, key, (uint4*)out, n);
   return hipGetLastError();
 }
 

@@ -20,6 +20,8 @@ hipError_t launch_permute_batch(const void* in, void* out, size_t n, hipStream_t
 // one Merkle layer of nseg trees; segment strides are in field elements
 hipError_t launch_compress_layer(const void* in, void* out, size_t m_in, size_t nseg, bool bottom,
                                  size_t in_seg_stride, size_t out_seg_stride, hipStream_t st);
+// n pairs (x, y) of canonical elements -> compress(x, y, key), key in {0,1,2,3}
+hipError_t launch_compress_pairs(const void* xy, uint32_t key, void* out, size_t n, hipStream_t st);
 hipError_t launch_sponge2_felts(const void* felts, size_t nf, size_t nitems, void* out, hipStream_t st);
 hipError_t launch_hash_cells(const void* cells, size_t cell_size, size_t n_cells, void* out, hipStream_t st);
 // cells_per_slot == 0: one slot with seed `seed0`; otherwise global cell g belongs to slot g / cells_per_slot

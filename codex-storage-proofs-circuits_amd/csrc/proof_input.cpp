@@ -783,7 +783,7 @@ extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, u
     };
 
     // the builders call this each time the trees of slots [a, b) are complete on the context's stream
-    SlotsDone on_done = [&](cp2_slot_trees* t, size_t a, size_t b) -> int {
+    SlotsDone on_done = [&](cp2_slot_trees* t, size_t a, size_t b, hipStream_t tree_stream) -> int {
       if (!have_geom) { trees_geom(t, &geom); have_geom = true; }
       for (size_t g0 = a; g0 < b; g0 += group_slots) {
         const size_t g1 = std::min(b, g0 + group_slots);
@@ -792,8 +792,10 @@ extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, u
         // ring slot r was last used by pass k - DEPTH: its tasks must have been handed out and finished
         while (consumed + StreamRing::DEPTH <= k) { CP2_TRY(consume(consumed)); ++consumed; }
         while (ring.pending[r].load() != 0) std::this_thread::yield();
-        CP2_HIP(ctx, hipEventRecord(trees_ready, ctx->stream));
-        CP2_HIP(ctx, hipStreamWaitEvent(aux, trees_ready, 0));
+        if (tree_stream != aux) {   // the builders run a group's layers on the second stream already; otherwise order after them
+          CP2_HIP(ctx, hipEventRecord(trees_ready, tree_stream));
+          CP2_HIP(ctx, hipStreamWaitEvent(aux, trees_ready, 0));
+        }
         CP2_TRY(enqueue_sampling(t, geom, dev, ring.host[r], nullptr, g0, g1 - g0, ns, md, !from_file, aux));
         CP2_HIP(ctx, hipEventRecord(ring.landed[r], aux));
         ring.s0[r] = g0;

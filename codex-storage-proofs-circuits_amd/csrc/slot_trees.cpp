@@ -114,29 +114,46 @@ static cp2_slot_trees* trees_new(cp2_ctx* ctx, size_t n_slots, size_t cell_size,
 }
 
 // all layers above the cell hashes of slots [s0, s1) (their cell hashes are already in layer 0)
-static int trees_build_layers(cp2_slot_trees* t, size_t s0, size_t s1) {
+static int trees_build_layers(cp2_slot_trees* t, size_t s0, size_t s1, hipStream_t st) {
   cp2_ctx* ctx = t->ctx;
   uint8_t* base = t->nodes.u8();
   const size_t ns = s1 - s0, nb = ns * t->nblocks;
   for (size_t k = 0; k + 1 < t->bsizes.size(); ++k)   // networkBlockTree, blocks/bn254.nim:60-67
     CP2_HIP(ctx, cp2k::launch_compress_layer(base + (t->boff[k] + s0 * t->nblocks * t->bsizes[k]) * 32,
                                              base + (t->boff[k + 1] + s0 * t->nblocks * t->bsizes[k + 1]) * 32, t->bsizes[k], nb,
-                                             k == 0, t->bsizes[k], t->bsizes[k + 1], ctx->stream));
+                                             k == 0, t->bsizes[k], t->bsizes[k + 1], st));
   for (size_t k = 0; k + 1 < t->tsizes.size(); ++k)   // bigTree, gen_input/bn254.nim:28-29
     CP2_HIP(ctx, cp2k::launch_compress_layer(base + (t->toff[k] + s0 * t->tsizes[k]) * 32, base + (t->toff[k + 1] + s0 * t->tsizes[k + 1]) * 32,
-                                             t->tsizes[k], ns, k == 0, t->tsizes[k], t->tsizes[k + 1], ctx->stream));
+                                             t->tsizes[k], ns, k == 0, t->tsizes[k], t->tsizes[k + 1], st));
   return CP2_OK;
 }
 
 // Tracks which slots have all their cells hashed and runs the layer passes (and the caller's hook) group by group.
+// With groups, the layer passes go to the context's SECOND stream: the upper layers of a group are small launches
+// whose duration is the latency of one permutation chain each (~0.1 ms), and on their own stream that latency hides
+// behind the next group's cell hashing instead of idling the GPU between two big kernels.
 namespace {
 struct LayerScheduler {
   cp2_slot_trees* t;
   size_t group;
   const SlotsDone& done;
   size_t built = 0;
-  // cells [0, cells_hashed) of the batch are enqueued for hashing
+  hipStream_t tree_stream = nullptr;
+  hipEvent_t hashed = nullptr;
+  ~LayerScheduler() {
+    if (tree_stream && tree_stream != t->ctx->stream) (void)hipStreamSynchronize(tree_stream);
+    if (hashed) (void)hipEventDestroy(hashed);
+  }
+  int init() {
+    cp2_ctx* ctx = t->ctx;
+    if (group == 0) { tree_stream = ctx->stream; return CP2_OK; }
+    CP2_TRY(aux_stream(ctx, &tree_stream));
+    CP2_HIP(ctx, hipEventCreateWithFlags(&hashed, hipEventDisableTiming));
+    return CP2_OK;
+  }
+  // cells [0, cells_hashed) of the batch are enqueued for hashing on the context's stream
   int advance(size_t cells_hashed, bool final) {
+    cp2_ctx* ctx = t->ctx;
     const size_t complete = cells_hashed / t->n_cells;
     for (;;) {
       const size_t avail = complete - built;
@@ -144,10 +161,20 @@ struct LayerScheduler {
       if (group && avail >= group) take = group;
       else if (final && avail) take = avail;
       if (!take) return CP2_OK;
-      CP2_TRY(trees_build_layers(t, built, built + take));
-      if (done) CP2_TRY(done(t, built, built + take));
+      if (tree_stream != ctx->stream) {
+        CP2_HIP(ctx, hipEventRecord(hashed, ctx->stream));
+        CP2_HIP(ctx, hipStreamWaitEvent(tree_stream, hashed, 0));
+      }
+      CP2_TRY(trees_build_layers(t, built, built + take, tree_stream));
+      if (done) CP2_TRY(done(t, built, built + take, tree_stream));
       built += take;
     }
+  }
+  int finish() {   // everything of both streams done
+    cp2_ctx* ctx = t->ctx;
+    CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (tree_stream && tree_stream != ctx->stream) CP2_HIP(ctx, hipStreamSynchronize(tree_stream));
+    return CP2_OK;
   }
 };
 }  // namespace
@@ -172,7 +199,7 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
   CP2_TRY(stage.scratch(ctx, chunk * cell_size));
   const uint64_t seed0 = cp2_slot_seed(dataset_seed, first_slot);
   LayerScheduler sched{t.get(), group, done};
-  int st = CP2_OK;
+  int st = sched.init();
   for (size_t c0 = 0; st == CP2_OK && c0 < total_cells; c0 += chunk) {
     size_t n = std::min(chunk, total_cells - c0);
     hipError_t e = cp2k::launch_gen_fake_cells(seed0, n_cells, c0, nullptr, n, cell_size, stage.p, ctx->stream);
@@ -180,7 +207,8 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
     if (e != hipSuccess) { ctx->err = hipGetErrorString(e); st = CP2_ERR_HIP; break; }
     st = sched.advance(c0 + n, c0 + n == total_cells);
   }
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess && st == CP2_OK) { ctx->err = "stream synchronisation failed after the slot-tree build"; st = CP2_ERR_HIP; }
+  int fin = sched.finish();
+  if (st == CP2_OK) st = fin;
   if (st != CP2_OK) return st;
   *out = t.release();
   return CP2_OK;
@@ -208,7 +236,7 @@ extern "C" int cp2_slot_trees_build_dev(cp2_ctx* ctx, const void* d_cells, size_
   t->d_cells = static_cast<const uint8_t*>(d_cells);
   CP2_TRY(trees_layout(t.get()));
   CP2_HIP(ctx, cp2k::launch_hash_cells(d_cells, cell_size, n_slots * n_cells, t->nodes.p, ctx->stream));
-  CP2_TRY(trees_build_layers(t.get(), 0, n_slots));
+  CP2_TRY(trees_build_layers(t.get(), 0, n_slots, ctx->stream));
   // A `_dev` entry point: everything is enqueued on the context's stream, nothing is synchronised (header contract).
   // cp2_sync / cp2_slot_trees_roots / _paths synchronise and report a failed launch through cp2_last_error.
   *out = t.release();
@@ -339,7 +367,7 @@ extern "C" int cp2_slot_trees_build_host(cp2_ctx* ctx, const uint8_t* cells, siz
   t->h_cells = cells;
   CP2_TRY(trees_layout(t.get()));
   int st = hash_host_cells_pipelined(ctx, cells, cell_size, n_slots * n_cells, t->nodes.u8());
-  if (st == CP2_OK) st = trees_build_layers(t.get(), 0, n_slots);
+  if (st == CP2_OK) st = trees_build_layers(t.get(), 0, n_slots, ctx->stream);
   if (hipStreamSynchronize(ctx->stream) != hipSuccess && st == CP2_OK) st = CP2_ERR_HIP;
   if (st != CP2_OK) return st;
   *out = t.release();
@@ -367,6 +395,7 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
     IngestPipe pipe;
     st = pipe.init(ctx, cell_size, n_cells);
     LayerScheduler sched{t.get(), group, done};
+    if (st == CP2_OK) st = sched.init();
     for (size_t s = 0; st == CP2_OK && s < n_slots; ++s) {
       std::string fname = slot_file_name(base, first_slot + s);
       int fd = open(fname.c_str(), O_RDONLY);
@@ -392,7 +421,8 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
       close(fd);
       if (st == CP2_OK) st = sched.advance((s + 1) * n_cells, s + 1 == n_slots);
     }
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess && st == CP2_OK) st = CP2_ERR_HIP;
+    int fin = sched.finish();
+    if (st == CP2_OK) st = fin;
   }
   if (st != CP2_OK) return st;
   *out = t.release();

@@ -27,10 +27,10 @@ namespace cp2i {
 
 constexpr uint64_t NO_ROW = ~0ULL;
 
-// Called by the builders each time the trees of slots [s0, s1) (indices inside the batch) are complete ON THE
-// CONTEXT'S STREAM (everything enqueued, nothing synchronised): the streamed proof-input path hangs its
-// sampling / gather / download of those slots on it while later slots are still hashing.
-using SlotsDone = std::function<int(cp2_slot_trees* t, size_t s0, size_t s1)>;
+// Called by the builders each time the trees of slots [s0, s1) (indices inside the batch) are complete ON STREAM `st`
+// (everything enqueued, nothing synchronised): the streamed proof-input path hangs its sampling / gather / download
+// of those slots on that stream while later slots are still hashing on the context's stream.
+using SlotsDone = std::function<int(cp2_slot_trees* t, size_t s0, size_t s1, hipStream_t st)>;
 
 int trees_check_geometry(size_t cell_size, size_t block_size, size_t n_cells, size_t n_slots);
 // fake-data or slot-file trees; `group` = how many finished slots to batch per layer pass / callback (0: all at the end)

@@ -286,3 +286,27 @@ def test_repeated_host_calls_reuse_scratch(pkg, ctx, oracle):
         want = np.stack([C.compress(xy[i, :32], xy[i, 32:], key) for i in range(200)])
         got = np.stack([ctx.compress_batch(xy[i:i + 1], key)[0] for i in range(200)])
         assert np.array_equal(got, want)
+
+
+def test_host_pointer_batches_are_streamed_in_chunks(ctx, oracle):
+    """cp2_permute_batch / cp2_compress_batch on host arrays larger than the 2^20-item chunk: upload, kernel and
+    download of neighbouring chunks overlap through the pinned ring; results against the oracle on a strided sample
+    that covers every chunk edge."""
+    C, _ = oracle
+    rng = np.random.default_rng(2)
+    n = (1 << 21) + (1 << 20) + 12345                                    # 3 full chunks + a ragged one
+    x = rng.integers(0, 256, size=(n, 96), dtype=np.uint8)
+    x[:, 31] &= 0x1F
+    x[:, 63] &= 0x1F
+    x[:, 95] &= 0x1F
+    y = ctx.permute_batch(x)
+    edges = [k * (1 << 20) + d for k in range(4) for d in (-1, 0, 1) if 0 <= k * (1 << 20) + d < n]
+    idx = np.unique(np.concatenate([np.arange(0, n, 4099), np.array(edges), [n - 1]]))
+    assert np.array_equal(y[idx], C.permute_batch(x[idx], threads=8))
+    m = (1 << 20) + 777
+    xy = np.ascontiguousarray(x[:m, :64])
+    for key in (0, 3):
+        got = ctx.compress_batch(xy, key)
+        ids = np.unique(np.concatenate([np.arange(0, m, 9973), [(1 << 20) - 1, 1 << 20, m - 1]]))
+        want = np.stack([C.compress(xy[i, :32], xy[i, 32:], key) for i in ids])
+        assert np.array_equal(got[ids], want)
