@@ -299,13 +299,17 @@ extern "C" size_t cp2_felts_per_bytes(size_t len) { return (len + 1 + 30) / 31; 
 extern "C" int cp2_bytes_to_felts(const uint8_t* data, size_t len, uint8_t* out) try {
   if ((len && !data) || !out) return CP2_ERR_INVALID;
   size_t n = cp2_felts_per_bytes(len);
-  std::memset(out, 0, n * 32);
-  for (size_t k = 0; k < n; ++k) {
-    for (size_t i = 0; i < 31; ++i) {
-      size_t pos = 31 * k + i;
-      if (pos < len) out[32 * k + i] = data[pos];
-      else if (pos == len) out[32 * k + i] = 0x01;
-    }
+  const size_t full = len / 31;                         // chunks made of data bytes only
+  for (size_t k = 0; k < full; ++k) {
+    std::memcpy(out + 32 * k, data + 31 * k, 31);
+    out[32 * k + 31] = 0;
+  }
+  if (full < n) {                                       // the chunk holding the 0x01 marker (and, before it, the data tail)
+    uint8_t* last = out + 32 * full;
+    std::memset(last, 0, 32);
+    const size_t tail = len - 31 * full;
+    if (tail) std::memcpy(last, data + 31 * full, tail);
+    last[tail] = 0x01;
   }
   return CP2_OK;
 } catch (const std::bad_alloc&) {
