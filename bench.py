@@ -451,17 +451,6 @@ def ingest_leg(torch, ctx, pkg, dev):
                       "roots_match_device_build": ok_h and ok_f})
     ctx.set_ingest(0, 0, 0)
     os.remove(path_base + "0.dat")
-    # the host-pointer permutation entry point (pageable arrays in and out, PCIe both ways): never bench.py's `value`
-    hp = np.ascontiguousarray(cells.reshape(-1)[:(1 << 22) * 96].reshape(1 << 22, 96))
-    hp[:, 31] &= 0x1F
-    hp[:, 63] &= 0x1F
-    hp[:, 95] &= 0x1F
-    hout = np.zeros_like(hp)                                                   # touched: no first-use page faults in the timing
-    ctx.permute_batch(hp[:1 << 21], out=hout[:1 << 21])                        # rings allocated outside the timing
-    t = time.perf_counter()
-    ctx.permute_batch(hp, out=hout)
-    host_perm = (1 << 22) / (time.perf_counter() - t)
-    del hp, hout
     bh = max(r["host_pointer_GBps"] for r in table)
     bf = max(r["page_cache_file_GBps"] for r in table)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -469,8 +458,7 @@ def ingest_leg(torch, ctx, pkg, dev):
                        "pinned_h2d_peak_GBps": round(best, 2), "hash_from_hbm_GBps": round(kernel_gbps, 2), "by_fill_threads": table,
                        "best_host_pointer_GBps": bh, "best_page_cache_file_GBps": bf,
                        "host_pointer_frac_of_h2d_peak": round(bh / best, 3), "file_frac_of_h2d_peak": round(bf / best, 3),
-                       "host_pointer_frac_of_kernel_rate": round(bh / kernel_gbps, 3),
-                       "cp2_permute_batch_host_arrays_perms_per_s": host_perm}}
+                       "host_pointer_frac_of_kernel_rate": round(bh / kernel_gbps, 3)}}
 
 
 def dataset_leg(torch, dist, ctx, pkg, dev, rank, world):

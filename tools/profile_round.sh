@@ -1,17 +1,27 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence bench.py's roofline refers to.  Run ON THE GPU BOX from the repo root:
-#   bash tools/profile_round.sh r01
+#   bash tools/profile_round.sh r02
 # kernel-trace/stats and every --pmc group are separate runs (gpurun refuses --pmc combined with trace domains).
+# The program after `--` is python3 itself (no env / bash -c hop: the profiler's preload initialises the GPU first).
 set -e
-R=${1:-r01}
+R=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/prof_$R
 cd $GRAFT_REPO_ROOT
-rm -rf $O && mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/kt.log 2>&1
-B="python3 bench.py --steps 2 --warmup 1 --no-extra --no-cpu-baseline"
+if [ "$2" = "kt" ]; then rm -rf $O/kt; else rm -rf $O; fi
+mkdir -p $O
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/kt.log 2>&1
+echo "kernel trace done" > $O/progress.txt
+if [ "$2" = "kt" ]; then exit 0; fi
+B="python3 bench.py --steps 3 --warmup 1 --no-extra --no-cpu-baseline"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $B > $O/write.log 2>&1
+echo "traffic done" >> $O/progress.txt
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/sq -- $B > $O/sq.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/sq2 -- $B > $O/sq2.log 2>&1 || true
+# config 3's kernel (k_hash_cells over the 8 GiB slot): HBM bytes against the algorithmic 8 GiB + leaves
+H="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/hfetch -- $H > $O/hfetch.log 2>&1 || true
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/hwrite -- $H > $O/hwrite.log 2>&1 || true
+echo "all done" >> $O/progress.txt
 echo "now run locally: python3 tools/profile_summarize.py $R   (gpurun merges only gpurun_out/ back)"
