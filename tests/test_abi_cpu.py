@@ -102,3 +102,55 @@ def test_header_is_plain_c99_and_links(pkg, tmp_path):
                            "-Wl,-rpath," + libdir])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "c abi ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def _make_pi(pkg, cfg, slot, droot, ent, sroot, proof, cells, paths):
+    L = pkg.load_library()
+    p = lambda a: ctypes.c_void_p(np.ascontiguousarray(a).ctypes.data)   # noqa: E731
+    keep = [np.ascontiguousarray(a) for a in (droot, ent, sroot, proof, cells, paths)]
+    h = ctypes.c_void_p()
+    st = L.cp2_proof_input_create(ctypes.byref(cfg), slot, *(ctypes.c_void_p(a.ctypes.data) for a in keep[:4]), cells.shape[0], None,
+                                  ctypes.c_void_p(keep[4].ctypes.data), ctypes.c_void_p(keep[5].ctypes.data), None, ctypes.byref(h))
+    assert st == 0
+    text, ln = ctypes.c_void_p(), ctypes.c_size_t()
+    assert L.cp2_proof_input_json(h, ctypes.byref(text), ctypes.byref(ln)) == 0
+    s = ctypes.string_at(text, ln.value).decode()
+    L.cp2_free_buffer(text)
+    L.cp2_proof_input_free(h)
+    return s
+
+
+def test_json_writer_host_only_vs_oracle_edge_values(pkg, oracle):
+    """The byte-exact writer (json/bn254.nim:57-74) needs no GPU: cp2_proof_input_create + cp2_proof_input_json against
+    the Python restatement, on values that sit on every edge of the decimal conversion (base-10^19 chunks, reciprocal
+    division, four numbers converted side by side): 0, 1, 9, 10, 10^19 - 1, 10^19, 10^19 + 1, 10^38, 10^57, 10^76,
+    r - 1, 2^256 - 1, chunks that are all zeros or all nines, and random ones."""
+    C, P = oracle
+    rng = np.random.default_rng(123)
+    edge = [0, 1, 9, 10, 99, 100, 10**19 - 1, 10**19, 10**19 + 1, 2 * 10**19 - 1, 10**38 - 1, 10**38, 10**38 + 10**19, 10**57, 10**57 - 1,
+            10**76, 10**76 - 1, 10**76 + 10**57 + 10**38 + 10**19 + 1, P.R_MOD - 1, P.R_MOD, 2**256 - 1, 2**255, 2**64 - 1, 2**64, 2**128 - 1,
+            2**128, 2**192, 12345678901234567890123456789012345678901234567890123456789012345678901234567,
+            99999999999999999990000000000000000000, 10**19 * (10**19 - 1), 7 * 10**76]
+    edge += [int.from_bytes(rng.bytes(32), "little") >> int(s) for s in rng.integers(0, 250, size=64)]
+    felt = lambda v: np.frombuffer(int(v).to_bytes(32, "little"), dtype=np.uint8)   # noqa: E731
+    md, ml, cs, ns = 7, 3, 62, (len(edge) + 6) // 7
+    vals = edge + [0] * (ns * md - len(edge))
+    paths = np.stack([felt(v) for v in vals]).reshape(ns, md, 32)
+    cells = rng.integers(0, 256, size=(ns, cs), dtype=np.uint8)
+    cells[0, :] = 0                      # all-zero cell: elements 0, 0 and the lone 0x01 marker chunk
+    cells[1, :] = 255
+    droot, ent, sroot = felt(edge[5]), felt(edge[7]), felt(edge[18])
+    proof = np.stack([felt(v) for v in (0, 10**38, 2**256 - 1)])
+    cfg = pkg.make_config(maxDepth=md, maxLog2NSlots=ml, cellSize=cs, blockSize=cs * 2, nSlots=5, nCells=64, nSamples=ns)
+    got = _make_pi(pkg, cfg, 4, droot, ent, sroot, proof, cells, paths)
+    want = P.export_json({"dataSetRoot": edge[5], "entropy": edge[7], "nCells": 64, "nSlots": 5, "slotIndex": 4, "slotRoot": edge[18],
+                          "slotProof": {"merklePath": [0, 10**38, 2**256 - 1]},
+                          "proofInputs": [{"cellData": cells[i].tobytes(), "merkleProof": {"merklePath": vals[i * md:(i + 1) * md]}}
+                                          for i in range(ns)]})
+    assert got == want
+    # zero samples, zero-length slot proof
+    cfg0 = pkg.make_config(maxDepth=0, maxLog2NSlots=0, cellSize=31, blockSize=62, nSlots=1, nCells=2, nSamples=0)
+    got0 = _make_pi(pkg, cfg0, 0, felt(1), felt(2), felt(3), np.zeros((1, 32), np.uint8), np.zeros((0, 31), np.uint8), np.zeros((0, 32), np.uint8))
+    want0 = P.export_json({"dataSetRoot": 1, "entropy": 2, "nCells": 2, "nSlots": 1, "slotIndex": 0, "slotRoot": 3,
+                           "slotProof": {"merklePath": []}, "proofInputs": []})
+    assert got0 == want0
