@@ -310,3 +310,22 @@ def test_host_pointer_batches_are_streamed_in_chunks(ctx, oracle):
         ids = np.unique(np.concatenate([np.arange(0, m, 9973), [(1 << 20) - 1, 1 << 20, m - 1]]))
         want = np.stack([C.compress(xy[i, :32], xy[i, 32:], key) for i in ids])
         assert np.array_equal(got[ids], want)
+
+
+def test_degenerate_shapes_streamed_and_classic(pkg, ctx, oracle):
+    """Zero samples, one cell per block, a single block per slot, a single slot, cell sizes that are not a multiple
+    of 4: both pipelines against the Python restatement."""
+    C, P = oracle
+    shapes = [dict(maxDepth=6, maxLog2NSlots=2, cellSize=64, blockSize=256, nSlots=3, nCells=8, nSamples=0, seed=1),
+              dict(maxDepth=9, maxLog2NSlots=1, cellSize=31, blockSize=31, nSlots=1, nCells=4, nSamples=3, seed=2),        # cpb = 1
+              dict(maxDepth=5, maxLog2NSlots=3, cellSize=100, blockSize=800, nSlots=6, nCells=8, nSamples=5, seed=3),      # one block
+              dict(maxDepth=32, maxLog2NSlots=1, cellSize=62, blockSize=124, nSlots=1, nCells=2, nSamples=2, seed=4)]     # 1-slot dataset tree: one compression, key 3
+    for c in shapes:
+        cfg = pkg.make_config(**c)
+        ds = ctx.dataset(cfg)
+        sd = ctx.dataset_streamed(cfg, 99, threads=2, group_slots=1)
+        sd.export_streamed(None, threads=2)
+        for slot in range(c["nSlots"]):
+            want = P.export_json(P.generate_proof_input(dict(c), slot, 99))
+            assert ds.proof_input(slot, 99).json() == want, (c, slot)
+            assert sd.streamed_json(slot) == want, (c, slot)
