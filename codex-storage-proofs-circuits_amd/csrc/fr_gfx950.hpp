@@ -259,44 +259,81 @@ __device__ __forceinline__ Fe sbox(const Fe& x) {
   return mont_mul(x4, x);
 }
 
-// ---- lazy modular reduction -----------------------------------------------------------------
-// Table of (bias - q*N) rows lives in LDS (filled by qtab_fill); row q, 9 dwords, stride 9 (odd, so
-// lanes with different q hit different banks and equal q broadcasts).
-constexpr int QTAB_ROWS = 32;
-constexpr int QTAB_WORDS = QTAB_ROWS * NL;
+// ---- y and z of the internal rounds: five 58-bit limbs in 64-bit registers ----------------------------------
+// Only x passes through an S-box in the 56 internal rounds; y and z follow a linear recurrence (Permutation.hs:19-26).
+// In 9 x 29-bit limbs every round needs a carry step on each of them (3 spare bits, values grow 4x per round): 3
+// instructions per limb per value per round.  In 58-bit limbs there are 6 spare bits, so two rounds go by without any
+// carry step, a 64-bit add is one instruction (v_lshl_add_u64) for two 29-bit limbs, and x's next S-box input is cut
+// straight out of the 64-bit sums (its limbs stay below 2U + 64, inside mont_sqr's bound): 158 instead of 237
+// instructions per pair of rounds.  Every VALU instruction costs one issue slot in this kernel.
+constexpr int NW = 5;
+constexpr uint64_t MASK58 = ((uint64_t)1 << 58) - 1;
+struct Wide {
+  uint64_t w[NW];
+};
 
-// Fill the LDS table: row q holds U_i = bias_i - (q*N)_i with bias = {U, U-1, ..., U-1, -1}
-// (the bias sums to zero as a number, so  v + row(q)  ==  v - q*N  with every limb 0..7 non-negative).
-__device__ __forceinline__ void qtab_fill(uint32_t* tab, int tid, int nthreads) {
+// limbs (< 2^32 each, lazy) -> wide limbs w[j] = l[2j] + l[2j+1] * 2^29 (value unchanged)
+__device__ __forceinline__ Wide to_wide(const Fe& a) {
+  Wide r;
+#pragma unroll
+  for (int j = 0; j < NW - 1; ++j) r.w[j] = (uint64_t)a.l[2 * j] + ((uint64_t)a.l[2 * j + 1] << 29);
+  r.w[NW - 1] = a.l[NL - 1];
+  return r;
+}
+
+// wide limbs 0..3 < 2^58 exactly (after reduce_wide) -> limbs 0..7 < U exactly
+__device__ __forceinline__ Fe from_wide(const Wide& a) {
+  Fe r;
+#pragma unroll
+  for (int j = 0; j < NW - 1; ++j) {
+    CP2_BOUND(a.w[j] <= MASK58, "from_wide: limb not normalised");
+    r.l[2 * j] = (uint32_t)a.w[j] & MASK;
+    r.l[2 * j + 1] = (uint32_t)(a.w[j] >> 29);
+  }
+  r.l[NL - 1] = (uint32_t)a.w[NW - 1];
+  return r;
+}
+
+// ---- lazy modular reduction (wide) -----------------------------------------------------------------
+// Table of (bias - q*N) rows lives in LDS (filled by qtab_fill): row q, 5 x 64 bits, bias = {2^58, 2^58-1, 2^58-1,
+// 2^58-1, -1} (sums to zero as a number, so  v + row(q) == v - q*N  with every limb 0..3 non-negative; the last
+// limb wraps modulo 2^64 and comes out right because the true result is non-negative).
+constexpr int QTAB_ROWS = 64;                // q <= 35 in the worst case of the internal rounds (poseidon2_dev.hpp)
+constexpr int QTAB_WORDS = QTAB_ROWS * NW;   // 64-bit words
+struct alignas(8) QTab {
+  uint64_t row[QTAB_ROWS][NW];
+};
+
+__device__ __forceinline__ void qtab_fill(QTab& tab, int tid, int nthreads) {
   for (int idx = tid; idx < QTAB_WORDS; idx += nthreads) {
-    int q = idx / NL, i = idx % NL;
-    uint32_t t = FR_QN_TAB[q][i];
-    uint32_t bias = (i == 0) ? U29 : (i == NL - 1 ? 0xffffffffu : U29 - 1);
-    tab[idx] = bias - t;
+    int q = idx / NW, j = idx % NW;
+    uint64_t bias = (j == 0) ? ((uint64_t)1 << 58) : (j == NW - 1 ? ~(uint64_t)0 : MASK58);
+    tab.row[q][j] = bias - FR_QN_TABW[q][j];
   }
 }
 
-// Reduce a lazily-accumulated value: input limbs < 6 U (so limb + row < 2^32), value < 30 N;
-// output limbs 0..7 < U exactly, top limb small, value < 2 N (q is floor(v/N) or one less).
-__device__ __forceinline__ Fe reduce_lazy(const Fe& a, const uint32_t* tab) {
+// Reduce a lazily-accumulated wide value: input limbs < 2^63, value < 64 N; output limbs 0..3 < 2^58 exactly, top limb
+// small, value < 2 N (q is floor(v/N) or one less).
+__device__ __forceinline__ Wide reduce_wide(const Wide& a, const QTab& tab) {
   // t ~ floor(v / 2^232), never an over-estimate; N / 2^232 = 0x30644e.72e1...
-  uint32_t t = a.l[NL - 1] + (a.l[NL - 2] >> 29);
+  uint32_t t = (uint32_t)a.w[NW - 1] + (uint32_t)(a.w[NW - 2] >> 58);
+  CP2_BOUND(a.w[NW - 1] < ((uint64_t)1 << 31), "reduce_wide: top limb too large");
   // q = floor(t / (0x30644e + 1)) via 2^32 / 3171407 = 1354.27...; under-estimates only
   uint32_t q = __umulhi(t, 1354u);
-  CP2_BOUND(q < (uint32_t)QTAB_ROWS, "reduce_lazy: q outside the table (value >= 32N)");
+  CP2_BOUND(q < (uint32_t)QTAB_ROWS, "reduce_wide: q outside the table (value >= 64N)");
 #pragma unroll
-  for (int i = 0; i < NL - 1; ++i) CP2_BOUND((uint64_t)a.l[i] < ((uint64_t)6 << 29), "reduce_lazy input limb >= 6U");
-  const uint32_t* row = tab + q * NL;
-  Fe r;
-  uint32_t c = 0;
+  for (int j = 0; j < NW - 1; ++j) CP2_BOUND(a.w[j] < ((uint64_t)1 << 63), "reduce_wide input limb >= 2^63");
+  const uint64_t* row = tab.row[q];
+  Wide r;
+  uint64_t c = 0;
 #pragma unroll
-  for (int i = 0; i < NL - 1; ++i) {
-    uint32_t d = a.l[i] + row[i] + c;
-    r.l[i] = d & MASK;
-    c = d >> 29;
+  for (int j = 0; j < NW - 1; ++j) {
+    uint64_t d = a.w[j] + row[j] + c;
+    r.w[j] = d & MASK58;
+    c = d >> 58;
   }
-  r.l[NL - 1] = a.l[NL - 1] + row[NL - 1] + c;
-  CP2_BOUND(r.l[NL - 1] < (1u << 24), "reduce_lazy: result not below 2N (top limb)");
+  r.w[NW - 1] = a.w[NW - 1] + row[NW - 1] + c;
+  CP2_BOUND(r.w[NW - 1] < (1u << 24), "reduce_wide: result not below 2N (top limb)");
   return r;
 }
 

@@ -51,7 +51,7 @@ __device__ __forceinline__ Fe key_fe(uint32_t key) {
 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(TPB, CP2_PERM_WAVES) k_permute_batch(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n) {
-  __shared__ uint32_t qtab[fr::QTAB_WORDS];
+  __shared__ fr::QTab qtab;
   fr::qtab_fill(qtab, threadIdx.x, TPB);
   __syncthreads();
   size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(TPB, CP2_PERM_WAVES) k_permute_batch(const uin
 __global__ void __launch_bounds__(TPB) k_compress_layer(const uint4* __restrict__ in, uint4* __restrict__ out,
                                                           size_t m_in, size_t m_out, size_t nseg, uint32_t bottom,
                                                           size_t in_seg_stride, size_t out_seg_stride) {
-  __shared__ uint32_t qtab[fr::QTAB_WORDS];
+  __shared__ fr::QTab qtab;
   fr::qtab_fill(qtab, threadIdx.x, TPB);
   __syncthreads();
   size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(TPB) k_compress_layer(const uint4* __restrict_
 // ------------------------------------------------------------------------------------------------
 // compress(x, y, key) for n independent pairs (merkle/bn254.nim:18): the seam call `compressWithKey`, batched.
 __global__ void __launch_bounds__(TPB) k_compress_pairs(const uint4* __restrict__ xy, uint32_t key, uint4* __restrict__ out, size_t n) {
-  __shared__ uint32_t qtab[fr::QTAB_WORDS];
+  __shared__ fr::QTab qtab;
   fr::qtab_fill(qtab, threadIdx.x, TPB);
   __syncthreads();
   size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(TPB) k_compress_pairs(const uint4* __restrict_
 // Batched rate-2 sponge over field elements (Sponge.hs:30-43): item i hashes felts[i*nf .. i*nf+nf).
 __global__ void __launch_bounds__(TPB) k_sponge2_felts(const uint4* __restrict__ felts, size_t nf, size_t nitems,
                                                          uint4* __restrict__ out) {
-  __shared__ uint32_t qtab[fr::QTAB_WORDS];
+  __shared__ fr::QTab qtab;
   fr::qtab_fill(qtab, threadIdx.x, TPB);
   __syncthreads();
   size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;
@@ -173,7 +173,7 @@ __device__ __forceinline__ void chunk_pair(const uint32_t (&w)[17], Fe& a, Fe& b
 
 __global__ void __launch_bounds__(TPB, CP2_HASH_WAVES) k_hash_cells(const uint8_t* __restrict__ cells, size_t cell_size,
                                                                       size_t n_cells, uint4* __restrict__ out) {
-  __shared__ uint32_t qtab[fr::QTAB_WORDS];
+  __shared__ fr::QTab qtab;
   __shared__ uint32_t ring[TPB / 64][64 * RING_STRIDE];
   fr::qtab_fill(qtab, threadIdx.x, TPB);
 
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(TPB) k_sample_paths(TreeGeom g, const uint4* _
                                                         const uint64_t* __restrict__ slots, uint64_t slot0, size_t n_items,
                                                         uint32_t ns, uint32_t md, uint64_t* __restrict__ indices,
                                                         uint64_t* __restrict__ gcell, uint64_t* __restrict__ rows) {
-  __shared__ uint32_t qtab[fr::QTAB_WORDS];
+  __shared__ fr::QTab qtab;
   fr::qtab_fill(qtab, threadIdx.x, TPB);
   __syncthreads();
   size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;

@@ -16,7 +16,7 @@ extern "C" {
 
 using fr::Fe;
 
-static uint32_t g_qtab[fr::QTAB_WORDS];
+static fr::QTab g_qtab;
 
 static Fe load_canonical(const uint8_t* p) {
   uint32_t w[8];
