@@ -153,13 +153,20 @@ __device__ __forceinline__ void tie_cols(acc_t& acc, uint32_t (&a)[NL], uint32_t
 }
 
 // Montgomery product a*b/R (finely integrated product scanning, 17 columns).
+// MASKM = false: the quotient digits m_k are used as the full 32-bit products t_k * N' instead of their low 29 bits.
+// They are still correct modulo 2^29 (the column still clears), the extra bits only add multiples of N further up, so
+// the result is congruent and every output limb is still exact; what changes is its SIZE, out < A*B/R + 8.01 N instead of
+// + N, and the column budget: sum_j m_k N_j < 2^32 * (N_0 + .. + N_8) = 2^32 * 3.4005 U = 2^62.77, which leaves
+// 2^63.2 for the a*b products: limbs up to 2.02 U on a squaring, La * Lb < 4.09 U^2 on a product.  One v_and_b32 less
+// per low column: 27 instructions per S-box, the only user (its values are re-bounded in poseidon2_dev.hpp).
+template <bool MASKM = true>
 __device__ __forceinline__ Fe mont_mul(const Fe& a_in, const Fe& b) {
   Fe r;
   uint32_t a[NL], m[NL];
 #pragma unroll
   for (int i = 0; i < NL; ++i) a[i] = a_in.l[i];
 #pragma unroll
-  for (int i = 0; i < NL; ++i)   // La * Lb < 6.1 U^2 (column sum < 2^64); checked limb by limb against the worst partner
+  for (int i = 0; i < NL; ++i)   // La * Lb < 6.1 U^2 (column sum < 2^64); the 128-bit shadow accumulator of the host check is the real guard
     CP2_BOUND((uint64_t)a_in.l[i] < ((uint64_t)5 << 29) && (uint64_t)b.l[i] < ((uint64_t)5 << 29), "mont_mul operand limb >= 5U");
   acc_t acc = 0;
   CP2_PAD_DECL
@@ -170,7 +177,7 @@ __device__ __forceinline__ Fe mont_mul(const Fe& a_in, const Fe& b) {
     for (int i = 0; i <= k; ++i) acc += (uint64_t)a[i] * b.l[k - i];
 #pragma unroll
     for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * FR_N[k - i];
-    m[k] = ((uint32_t)acc * FR_NPRIME) & MASK;
+    m[k] = MASKM ? (((uint32_t)acc * FR_NPRIME) & MASK) : ((uint32_t)acc * FR_NPRIME);
     acc += (uint64_t)m[k] * FR_N[0];
     acc >>= 29;
     CP2_PAD();
@@ -204,6 +211,7 @@ __device__ __forceinline__ void tie_sq(acc_t& acc, uint32_t (&a)[NL], uint32_t (
 }
 
 // Montgomery square a*a/R: 45 products instead of 81 (cross terms against the doubled operand).
+template <bool MASKM = true>
 __device__ __forceinline__ Fe mont_sqr(const Fe& a_in) {
   Fe r;
   uint32_t a[NL], m[NL], d[NL];
@@ -211,7 +219,7 @@ __device__ __forceinline__ Fe mont_sqr(const Fe& a_in) {
   for (int i = 0; i < NL; ++i) a[i] = a_in.l[i];
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
-    CP2_BOUND((uint64_t)a[i] * 100 < (uint64_t)247 << 29, "mont_sqr operand limb >= 2.47U");
+    CP2_BOUND((uint64_t)a[i] * 100 < (uint64_t)(MASKM ? 247 : 202) << 29, "mont_sqr operand limb >= 2.47U (2.02U with unmasked quotient digits)");
     d[i] = a[i] << 1;   // limbs < 2.47 U  =>  doubled < 2^32
   }
   acc_t acc = 0;
@@ -224,7 +232,7 @@ __device__ __forceinline__ Fe mont_sqr(const Fe& a_in) {
     if constexpr ((k & 1) == 0) acc += (uint64_t)a[k / 2] * a[k / 2];
 #pragma unroll
     for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * FR_N[k - i];
-    m[k] = ((uint32_t)acc * FR_NPRIME) & MASK;
+    m[k] = MASKM ? (((uint32_t)acc * FR_NPRIME) & MASK) : ((uint32_t)acc * FR_NPRIME);
     acc += (uint64_t)m[k] * FR_N[0];
     acc >>= 29;
     CP2_PAD();
@@ -252,11 +260,16 @@ __device__ __forceinline__ Fe mont_sqr(const Fe& a_in) {
   return r;
 }
 
-// x^5 (Permutation.hs:14-17).  Input limbs < 2.47 U, value < 13 N; output normalized, value < 1.1 N.
+// x^5 (Permutation.hs:14-17).  Each product is below A*B/R + c N with R = 169.3 N and c = 8.01 (unmasked quotient
+// digits, MASKM = false: the default everywhere) or c = 1 (masked: used where the state is handed on, so that values
+// do not pile up across permutations).  Input limbs < 2.02 U, value A < 60 N; output limbs 0..7 < U and
+//   unmasked:  x^2 < 29.3 N,  x^4 < 13.1 N,  x^5 < 13.1 * 60 / 169.3 + 8.01 < 12.7 N
+//   masked:    x^2 < 22.3 N,  x^4 <  3.94 N, x^5 <  3.94 * 60 / 169.3 + 1   <  2.4 N
+template <bool MASKM = false>
 __device__ __forceinline__ Fe sbox(const Fe& x) {
-  Fe x2 = mont_sqr(x);
-  Fe x4 = mont_sqr(x2);
-  return mont_mul(x4, x);
+  Fe x2 = mont_sqr<MASKM>(x);
+  Fe x4 = mont_sqr<MASKM>(x2);
+  return mont_mul<MASKM>(x4, x);
 }
 
 // ---- y and z of the internal rounds: five 58-bit limbs in 64-bit registers ----------------------------------
@@ -298,7 +311,8 @@ __device__ __forceinline__ Fe from_wide(const Wide& a) {
 // Table of (bias - q*N) rows lives in LDS (filled by qtab_fill): row q, 5 x 64 bits, bias = {2^58, 2^58-1, 2^58-1,
 // 2^58-1, -1} (sums to zero as a number, so  v + row(q) == v - q*N  with every limb 0..3 non-negative; the last
 // limb wraps modulo 2^64 and comes out right because the true result is non-negative).
-constexpr int QTAB_ROWS = 64;                // q <= 35 in the worst case of the internal rounds (poseidon2_dev.hpp)
+constexpr int QTAB_ROWS = 96;                // q <= 90 in the worst case of the internal rounds (poseidon2_dev.hpp); 96 rows keep
+                                             // k_hash_cells at 54 016 B of LDS per block, three blocks per CU
 constexpr int QTAB_WORDS = QTAB_ROWS * NW;   // 64-bit words
 struct alignas(8) QTab {
   uint64_t row[QTAB_ROWS][NW];
@@ -312,7 +326,7 @@ __device__ __forceinline__ void qtab_fill(QTab& tab, int tid, int nthreads) {
   }
 }
 
-// Reduce a lazily-accumulated wide value: input limbs < 2^63, value < 64 N; output limbs 0..3 < 2^58 exactly, top limb
+// Reduce a lazily-accumulated wide value: input limbs < 2^63, value < 96 N; output limbs 0..3 < 2^58 exactly, top limb
 // small, value < 2 N (q is floor(v/N) or one less).
 __device__ __forceinline__ Wide reduce_wide(const Wide& a, const QTab& tab) {
   // t ~ floor(v / 2^232), never an over-estimate; N / 2^232 = 0x30644e.72e1...
@@ -320,7 +334,7 @@ __device__ __forceinline__ Wide reduce_wide(const Wide& a, const QTab& tab) {
   CP2_BOUND(a.w[NW - 1] < ((uint64_t)1 << 31), "reduce_wide: top limb too large");
   // q = floor(t / (0x30644e + 1)) via 2^32 / 3171407 = 1354.27...; under-estimates only
   uint32_t q = __umulhi(t, 1354u);
-  CP2_BOUND(q < (uint32_t)QTAB_ROWS, "reduce_wide: q outside the table (value >= 64N)");
+  CP2_BOUND(q < (uint32_t)QTAB_ROWS, "reduce_wide: q outside the table (value >= 96N)");
 #pragma unroll
   for (int j = 0; j < NW - 1; ++j) CP2_BOUND(a.w[j] < ((uint64_t)1 << 63), "reduce_wide input limb >= 2^63");
   const uint64_t* row = tab.row[q];
@@ -352,13 +366,13 @@ __device__ __forceinline__ Fe from_words(const uint32_t (&w)[8]) {
 }
 
 // raw 256-bit integer -> Montgomery form (value < 2N, normalized): a * R^2 / R
-__device__ __forceinline__ Fe to_mont(const Fe& raw) { return mont_mul(raw, fe_const(FR_R2)); }
+__device__ __forceinline__ Fe to_mont(const Fe& raw) { return mont_mul<true>(raw, fe_const(FR_R2)); }
 
 // Montgomery form (limbs < 2.47 U, value < R) -> canonical integer in [0, N) as 8 dwords
 __device__ __forceinline__ void to_canonical_words(const Fe& a, uint32_t (&w)[8]) {
   Fe one = fe_zero();
   one.l[0] = 1;
-  Fe c = mont_mul(a, one);            // (a + m N)/R <= N, limbs 0..7 < U
+  Fe c = mont_mul<true>(a, one);      // masked quotient digits: (a + m N)/R <= N, limbs 0..7 < U
   uint32_t diff = 0;                  // c == N  <=>  every limb equal (limbs 0..7 < U, so the form is unique)
 #pragma unroll
   for (int i = 0; i < NL; ++i) diff |= c.l[i] ^ FR_N[i];

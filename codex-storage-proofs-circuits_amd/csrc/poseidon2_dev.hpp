@@ -17,12 +17,13 @@ struct State {
   Fe x, y, z;
 };
 
-// the S-box keeps its output below 1.3 N for inputs below 30 N (top limb < 1.3 * 0x30644f): asserted in the
-// host check build.  (Inputs reach ~24 N in the first external round of a sponge step: state < 4.3 N plus an
-// absorbed element < 2 N per lane, times 4 in the linear layer, plus the round constant.)
+// The S-box (fr_gfx950.hpp) keeps its output below 12.7 N (unmasked quotient digits) or 2.4 N (masked) for inputs
+// below 60 N (top limbs against multiples of N >> 232 = 0x30644e.7): asserted in the host check build.
+template <bool MASKM = false>
 __device__ __forceinline__ Fe sbox_checked(const Fe& x) {
-  Fe r = fr::sbox(x);
-  CP2_BOUND(r.l[fr::NL - 1] < 4122830u, "sbox output >= 1.3N");
+  CP2_BOUND(x.l[fr::NL - 1] < 60u * 3171407u, "sbox input >= 60N");
+  Fe r = fr::sbox<MASKM>(x);
+  CP2_BOUND(r.l[fr::NL - 1] < (MASKM ? 7611377u : 40276869u), "sbox output >= 2.4N / 12.7N");
   return r;
 }
 
@@ -33,11 +34,14 @@ __device__ __forceinline__ Fe rc(int idx) {
   return r;
 }
 
-// Permutation.hs:28-33.  in: limbs < U+8;  out: limbs < U+8, values < 4.3 N
+// Permutation.hs:28-33.  in: limbs < U+8, values < 51 N;  out: limbs < U+8, values < 4 * 12.7 N = 51 N, or
+// < 4 * 2.4 N = 9.6 N when MASKM (the last round of each group of four: what it hands to the internal rounds and to the
+// caller must be small, because the next step multiplies it by up to 4 again before any S-box sees it).
+template <bool MASKM>
 __device__ __forceinline__ void external_round(State& s, int rc_base) {
-  Fe x = sbox_checked(fr::add_lazy(s.x, rc(rc_base + 0)));
-  Fe y = sbox_checked(fr::add_lazy(s.y, rc(rc_base + 1)));
-  Fe z = sbox_checked(fr::add_lazy(s.z, rc(rc_base + 2)));
+  Fe x = sbox_checked<MASKM>(fr::add_lazy(s.x, rc(rc_base + 0)));
+  Fe y = sbox_checked<MASKM>(fr::add_lazy(s.y, rc(rc_base + 1)));
+  Fe z = sbox_checked<MASKM>(fr::add_lazy(s.z, rc(rc_base + 2)));
   Fe sum = fr::add_lazy(fr::add_lazy(x, y), z);
   s.x = fr::norm(fr::add_lazy(x, sum));
   s.y = fr::norm(fr::add_lazy(y, sum));
@@ -50,11 +54,13 @@ __device__ __forceinline__ void external_round(State& s, int rc_base) {
 //   reduce:  Y1, Z1 -> below 2N, limbs below W = 2^58
 //   half B:  the same on (xin, Y1r, Z1r), no reduction after it
 // in : xin = S-box input INCLUDING its round constant, limbs < 2U + 64 (inside mont_sqr's 2.47U)
-// Worst-case bounds (reduce_wide leaves < 2N; q is the exact quotient or one less):
-//   entering a pair  Y < 7.1N (limbs < 4W),  Z < 9.1N (< 5W)   [first pair: < 4.3N, limbs < W, from the external rounds]
-//   half A:  S < 17.3N (< 10W),  Y1 < 24.4N (< 14W),  Z1 < 35.5N (< 20W < 2^63),  xin < 19.4N,  T = S + c < 11W
-//   half B:  S < 5.1N (< 3W),   Y2 < 7.1N (< 4W),   Z2 < 9.1N (< 5W),   xin < 7.2N
-//   S-box inputs stay below 30N, where its output is below 1.3N (asserted); q <= 35 < 64 table rows; 35.5N < R = 169N.
+// Worst-case bounds (reduce_wide leaves < 2N; q is the exact quotient or one less; S-box output < f(input) with
+// f(I) = ((I^2/R + 8.01N)^2/R + 8.01N) * I/R + 8.01N, R = 169.3 N; W = 2^58).  Write a, b for the S-box outputs of halves A, B:
+//   half B:  S = b + Y1r + Z1r < b + 4N,  Y2 < b + 6N (limbs < 4W),  Z2 < b + 8N (< 5W),  xin_A = 2b + 5N
+//   half A:  S < a + 2b + 14N (< 10W),  Y1 < a + 3b + 20N (< 14W),  Z1 < a + 4b + 30N (< 20W < 2^63),  xin_B = 2a + 2b + 15N,  T < 11W
+//   fixed point of (a, b) = (f(2b + 5N), f(2a + 2b + 15N)):  a < 9.7N, b < 12.6N, so xin_A < 30.2N, xin_B < 59.6N (< 60N),
+//   Y1 < 67.5N, Z1 < 90.1N: q <= 90 < 96 table rows and every value stays below R = 169N (nine limbs).
+//   First pair: x, Y, Z < 9.6N from the masked fourth external round (xin < 10.6N), inside the figures above (b + 8N with b = 12.6N).
 __device__ __forceinline__ void wide_half_round(fr::Fe& xin, fr::Wide& Y, fr::Wide& Z, const uint64_t (&rc_next)[fr::NW]) {
   using namespace fr;
   const Fe x = sbox_checked(xin);                                   // x' (normalised: limbs 0..7 < U)
@@ -99,7 +105,8 @@ __device__ __forceinline__ void internal_round_pair(fr::Fe& xin, fr::Wide& Y, fr
   wide_half_round(xin, Y, Z, fr::P2_RCW_MONT[r + 2]);
 }
 
-// Permutation.hs:40-45.  in: limbs < U+16, values < 8N;  out: limbs < U+8, values < 4.3 N
+// Permutation.hs:40-45.  in: limbs < U+16, values < 12N (a state this function returned, plus an absorbed element < 2N);
+// out: limbs < U+8, values < 9.6 N.  The linear layer below then feeds the first S-boxes at most 4 * 12 + 1 = 49 N.
 __device__ __forceinline__ void permute(State& s, const fr::QTab& qtab) {
   {  // linearLayer, Permutation.hs:35-36
     Fe sum = fr::add_lazy(fr::add_lazy(s.x, s.y), s.z);
@@ -110,7 +117,8 @@ __device__ __forceinline__ void permute(State& s, const fr::QTab& qtab) {
 #pragma unroll 1
   for (int half = 0; half < 2; ++half) {
 #pragma unroll 1
-    for (int r = 0; r < 4; ++r) external_round(s, (half ? 68 : 0) + 3 * r);
+    for (int r = 0; r < 3; ++r) external_round<false>(s, (half ? 68 : 0) + 3 * r);
+    external_round<true>(s, (half ? 68 : 0) + 9);
     if (half == 0) {
       fr::Wide Y = fr::to_wide(s.y), Z = fr::to_wide(s.z);
       Fe xin = fr::add_lazy(s.x, rc(12));                           // limbs < 2U + 8
