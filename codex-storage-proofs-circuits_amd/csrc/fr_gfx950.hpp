@@ -10,10 +10,13 @@
 //
 // Bounds (U = 2^29, N = field modulus, R = 2^261 ~ 169.3 N):
 //   * a limb vector is "normalized" when limbs 0..7 < U + 8 (and the top limb is small);
-//   * mont_mul / mont_sqr accept limbs up to 2.47 U on either operand (column sum
-//       2^35 + 9*La*Lb + 9*U*U < 2^64 needs La*Lb < 6.1 U^2) and produce limbs 0..7 < U;
-//   * value bound: out < A*B/R + N, so inputs below 13 N give outputs below 2 N and no
-//     conditional subtraction is ever needed inside a chain (lazy Montgomery).
+//   * mont_mul / mont_sqr with masked quotient digits accept limbs up to 2.47 U on either operand (column sum
+//       2^35 + 9*La*Lb + 9*U*U < 2^64 needs La*Lb < 6.1 U^2) and produce limbs 0..7 < U; value bound out < A*B/R + N;
+//   * with UNMASKED quotient digits (the S-box): the m*N part of a column is below 2^32 * 3.4005 U, operands up to
+//       2.02 U on a squaring, La*Lb < 4.09 U^2 on a product; value bound out < A*B/R + 8.01 N;
+//   * either way no conditional subtraction is ever needed inside a chain (lazy Montgomery): R = 169 N contracts
+//     x -> x^2/R + 8 N for everything below 160 N, and the S-box sees inputs below 60 N (poseidon2_dev.hpp);
+//   * y and z of the internal rounds are held in five 58-bit limbs (struct Wide) with 6 spare bits each.
 //
 // What the reference computes with this arithmetic: Permutation.hs:14-45 (field ops of
 // zikkurat-algebra / constantine there).  Nothing here is derived from those libraries' code.
