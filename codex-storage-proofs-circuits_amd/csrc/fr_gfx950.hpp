@@ -207,10 +207,12 @@ __device__ __forceinline__ Fe mont_mul(const Fe& a_in, const Fe& b) {
   return r;
 }
 
-template <int LO, int... I, int... J>
+// d[0] takes no part in any product (cross terms are a[i] * d[j] with i < j), so it is never tied and never computed
+template <int LO, int DLO, int... I, int... D, int... J>
 __device__ __forceinline__ void tie_sq(acc_t& acc, uint32_t (&a)[NL], uint32_t (&d)[NL], uint32_t (&m)[NL],
-                                       std::integer_sequence<int, I...>, std::integer_sequence<int, J...>) {
-  tie(acc, a[LO + I]..., d[LO + I]..., m[LO + J]...);
+                                       std::integer_sequence<int, I...>, std::integer_sequence<int, D...>,
+                                       std::integer_sequence<int, J...>) {
+  tie(acc, a[LO + I]..., d[DLO + D]..., m[LO + J]...);
 }
 
 // Montgomery square a*a/R: 45 products instead of 81 (cross terms against the doubled operand).
@@ -223,13 +225,15 @@ __device__ __forceinline__ Fe mont_sqr(const Fe& a_in) {
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     CP2_BOUND((uint64_t)a[i] * 100 < (uint64_t)(MASKM ? 247 : 202) << 29, "mont_sqr operand limb >= 2.47U (2.02U with unmasked quotient digits)");
-    d[i] = a[i] << 1;   // limbs < 2.47 U  =>  doubled < 2^32
+    d[i] = i ? a[i] << 1 : 0;   // limbs < 2.47 U  =>  doubled < 2^32
   }
   acc_t acc = 0;
   CP2_PAD_DECL
   auto lo_col = [&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    if constexpr (k > 0) tie_sq<0>(acc, a, d, m, std::make_integer_sequence<int, k + 1>{}, std::make_integer_sequence<int, k>{});
+    if constexpr (k > 0)
+      tie_sq<0, 1>(acc, a, d, m, std::make_integer_sequence<int, k + 1>{}, std::make_integer_sequence<int, k>{},
+                   std::make_integer_sequence<int, k>{});
 #pragma unroll
     for (int i = 0; 2 * i < k; ++i) acc += (uint64_t)a[i] * d[k - i];
     if constexpr ((k & 1) == 0) acc += (uint64_t)a[k / 2] * a[k / 2];
@@ -243,7 +247,8 @@ __device__ __forceinline__ Fe mont_sqr(const Fe& a_in) {
   auto hi_col = [&](auto kc) {
     constexpr int k = decltype(kc)::value;
     constexpr int lo = k - NL + 1, cnt = NL - lo;
-    tie_sq<lo>(acc, a, d, m, std::make_integer_sequence<int, cnt>{}, std::make_integer_sequence<int, cnt>{});
+    tie_sq<lo, lo>(acc, a, d, m, std::make_integer_sequence<int, cnt>{}, std::make_integer_sequence<int, cnt>{},
+                   std::make_integer_sequence<int, cnt>{});
 #pragma unroll
     for (int i = lo; 2 * i < k; ++i) acc += (uint64_t)a[i] * d[k - i];
     if constexpr ((k & 1) == 0) acc += (uint64_t)a[k / 2] * a[k / 2];
