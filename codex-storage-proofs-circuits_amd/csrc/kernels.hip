@@ -171,7 +171,9 @@ __device__ __forceinline__ void chunk_pair(const uint32_t (&w)[17], Fe& a, Fe& b
   }
 }
 
-__global__ void __launch_bounds__(TPB, CP2_HASH_WAVES) k_hash_cells(const uint8_t* __restrict__ cells, size_t cell_size,
+// LDS allows three workgroups per CU = three waves per SIMD: tell the register allocator that is also the MOST it will
+// ever get, so that it uses the registers (up to 168) instead of squeezing the staging loops for an occupancy it cannot have
+__global__ void __launch_bounds__(TPB, CP2_HASH_WAVES) __attribute__((amdgpu_waves_per_eu(CP2_HASH_WAVES, CP2_HASH_WAVES))) k_hash_cells(const uint8_t* __restrict__ cells, size_t cell_size,
                                                                       size_t n_cells, uint4* __restrict__ out) {
   __shared__ fr::QTab qtab;
   __shared__ uint32_t ring[TPB / 64][64 * RING_STRIDE];
@@ -199,30 +201,47 @@ __global__ void __launch_bounds__(TPB, CP2_HASH_WAVES) k_hash_cells(const uint8_
   for (size_t line = 0; line < nlines; ++line) {
     __syncthreads();   // every lane is done reading what this stage overwrites (and, first pass, the qtab fill)
     const int ring_base = (int)((line * LINE_WORDS) % RING_WORDS);
-#pragma unroll 4
-    for (int k = 0; k < LINE_WORDS; ++k) {
-      const int idx = k * 64 + lane;
-      const int c = idx >> 5, w = idx & 31;                 // 32 consecutive lanes = one 128-byte line
-      const size_t cell = cell0 + c;
+    // Word w of line `line` of 32 cells per lane: lane = (cell parity, w), cell = cell0 + 2k + (lane >> 5) for k = 0..31.
+    // Everything but the cell is the same for all 32 loads of a lane, so it is worked out once per line: the byte offset
+    // p0, whether the dword lies inside the cell, the padding bit it may carry, its slot in the ring.
+    {
+      const int w = lane & 31, half = lane >> 5;
       const size_t p0 = line * 128 + (size_t)w * 4;
-      uint32_t val = 0;
-      if (cell < n_cells) {
-        const uint8_t* base = cells + cell * cell_size;
-        if (aligned4 && p0 + 4 <= cell_size) {
-          val = *reinterpret_cast<const uint32_t*>(base + p0);
-        } else if (p0 <= cell_size) {
-#pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            size_t p = p0 + b;
-            uint32_t byte = (p < cell_size) ? base[p] : (p == cell_size ? 1u : 0u);
-            val |= byte << (8 * b);
-          }
-        }
-        if (sponge_pad_pos >= p0 && sponge_pad_pos < p0 + 4) val |= 1u << (8 * (sponge_pad_pos - p0));
-      }
+      const uint32_t padmask = (sponge_pad_pos >= p0 && sponge_pad_pos < p0 + 4) ? 1u << (8 * (sponge_pad_pos - p0)) : 0u;
       int slot = ring_base + w;
       if (slot >= RING_WORDS) slot -= RING_WORDS;
-      my_ring[c * RING_STRIDE + slot] = val;
+      uint32_t* dst = my_ring + half * RING_STRIDE + slot;                     // + 2 * RING_STRIDE per k
+      const size_t first = cell0 + (size_t)half;
+      const int kmax = first < n_cells ? (int)((n_cells - first + 1) / 2 < 32 ? (n_cells - first + 1) / 2 : 32) : 0;   // cells that exist
+      const uint8_t* ptr = cells + first * cell_size + p0;
+      const size_t step = 2 * cell_size;
+      if (aligned4 && p0 + 4 <= cell_size) {            // a whole dword of cell data: the common case
+#pragma unroll 8
+        for (int k = 0; k < LINE_WORDS; ++k) {
+          uint32_t val = padmask;
+          if (k < kmax) val |= *reinterpret_cast<const uint32_t*>(ptr);
+          dst[k * 2 * RING_STRIDE] = val;
+          ptr += step;
+        }
+      } else if (p0 <= cell_size) {                      // the dword straddles the end of the cell (or cells are not 4-byte aligned)
+#pragma unroll 1
+        for (int k = 0; k < LINE_WORDS; ++k) {
+          uint32_t val = padmask;
+          if (k < kmax) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              const size_t p = p0 + b;
+              const uint32_t byte = (p < cell_size) ? ptr[b] : (p == cell_size ? 1u : 0u);   // 0x01 ends the data (Slot.hs:243-250)
+              val |= byte << (8 * b);
+            }
+          }
+          dst[k * 2 * RING_STRIDE] = val;
+          ptr += step;
+        }
+      } else {                                           // past the data: zero padding, possibly the sponge's own "1"
+#pragma unroll 8
+        for (int k = 0; k < LINE_WORDS; ++k) dst[k * 2 * RING_STRIDE] = padmask;
+      }
     }
     __syncthreads();
     const size_t avail = (line + 1) * 128 < stream_len ? (line + 1) * 128 : stream_len;
