@@ -329,3 +329,31 @@ def test_degenerate_shapes_streamed_and_classic(pkg, ctx, oracle):
             want = P.export_json(P.generate_proof_input(dict(c), slot, 99))
             assert ds.proof_input(slot, 99).json() == want, (c, slot)
             assert sd.streamed_json(slot) == want, (c, slot)
+
+
+def test_streamed_slots_larger_than_the_staging_chunk(pkg, ctx, oracle):
+    """Three 4 GiB slots (2^21 cells): every slot spans two 2 GiB staging chunks, so slots complete in the middle of the
+    chunk loop and the sampling of slot i overlaps the hashing of slot i+1.  Streamed == classic on roots and text, and
+    the sampled paths of one slot re-derive its root through the oracle's reconstructRoot (the circuit's check)."""
+    C, P = oracle
+    c = dict(maxDepth=32, maxLog2NSlots=2, cellSize=2048, blockSize=65536, nSlots=3, nCells=1 << 21, nSamples=20, seed=99)
+    cfg = pkg.make_config(**c)
+    sd = ctx.dataset_streamed(cfg, 777, threads=4)
+    ref = ctx.dataset(cfg)
+    assert np.array_equal(sd.local_roots(), ref.local_roots())
+    sd.export_streamed(None, threads=4)
+    pi = ref.proof_input(2, 777)
+    assert sd.streamed_json(2) == pi.json()
+    root = pkg.array_to_felts(pi.roots()[1])[0]
+    idx, paths, leaves, cells = pi.cell_indices(), pi.merkle_paths(), pi.leaf_hashes(), pi.cell_data()
+    for k in range(4):
+        ci = int(idx[k])
+        leaf = pkg.array_to_felts(leaves[k:k + 1])[0]
+        assert leaf == C.array_to_felts(C.hash_bytes(cells[k]))[0]
+        assert cells[k].tobytes() == P.gen_fake_cell(P.slot_seed(99, 2), ci, 2048)
+        path = pkg.array_to_felts(paths[k])
+        bot = P.reconstruct_root({"numberOfLeaves": 32, "leafIndex": ci % 32, "leafValue": leaf, "merklePath": path[:5]})
+        top = P.reconstruct_root({"numberOfLeaves": (1 << 21) // 32, "leafIndex": ci // 32, "leafValue": bot, "merklePath": path[5:21]})
+        assert top == root and path[21:] == [0] * 11
+    sd.free()
+    ref.free()
