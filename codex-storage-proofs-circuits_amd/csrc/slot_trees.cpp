@@ -320,6 +320,12 @@ struct IngestPipe {
     f(0, n / nt);
     pool->wait_idle();
   }
+  // cells of the next chunk: the first one is a quarter of the ring slot, so that the GPU starts hashing after a quarter
+  // of the fill + upload latency (its short kernel hides under the second chunk's upload)
+  size_t next_cells(size_t remaining) const {
+    size_t m = turn == 0 ? std::max<size_t>(chunk / 4, std::min<size_t>(chunk, 32768)) : chunk;
+    return std::min(m, remaining);
+  }
   // the pinned buffer the host may fill next (blocks until the kernel that last used this ring slot is done)
   int acquire(uint8_t** buf) {
     int b = (int)(turn % depth);
@@ -344,8 +350,8 @@ struct IngestPipe {
 int cp2i::hash_host_cells_pipelined(cp2_ctx* ctx, const uint8_t* cells, size_t cell_size, size_t n, uint8_t* d_leaves) {
   IngestPipe pipe;
   CP2_TRY(pipe.init(ctx, cell_size, n));
-  for (size_t c0 = 0; c0 < n; c0 += pipe.chunk) {
-    size_t m = std::min(pipe.chunk, n - c0);
+  for (size_t c0 = 0, m = 0; c0 < n; c0 += m) {
+    m = pipe.next_cells(n - c0);
     uint8_t* buf = nullptr;
     CP2_TRY(pipe.acquire(&buf));
     const uint8_t* src = cells + c0 * cell_size;
@@ -400,8 +406,8 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
       std::string fname = slot_file_name(base, first_slot + s);
       int fd = open(fname.c_str(), O_RDONLY);
       if (fd < 0) { ctx->err = "cannot open " + fname; st = CP2_ERR_IO; break; }
-      for (size_t c0 = 0; st == CP2_OK && c0 < n_cells; c0 += pipe.chunk) {
-        size_t m = std::min(pipe.chunk, n_cells - c0);
+      for (size_t c0 = 0, m = 0; st == CP2_OK && c0 < n_cells; c0 += m) {
+        m = pipe.next_cells(n_cells - c0);
         uint8_t* buf = nullptr;
         st = pipe.acquire(&buf);
         if (st != CP2_OK) break;
