@@ -54,10 +54,11 @@ extern "C" void cp2_free(cp2_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->aux_stream) {
-    (void)hipStreamSynchronize(ctx->aux_stream);
-    (void)hipStreamDestroy(ctx->aux_stream);
-  }
+  for (hipStream_t st : {ctx->aux_stream, ctx->aux2_stream})
+    if (st) {
+      (void)hipStreamSynchronize(st);
+      (void)hipStreamDestroy(st);
+    }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   ctx->pool->trim();   // cached scratch goes now; pinned blocks still held by live proof inputs return to the pool later
   delete ctx;

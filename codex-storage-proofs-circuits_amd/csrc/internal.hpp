@@ -98,7 +98,8 @@ struct cp2_ctx {
   bool native = false;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
-  hipStream_t aux_stream = nullptr;   // gathers / downloads that overlap hashing on `stream` (created on first use)
+  hipStream_t aux_stream = nullptr;   // second hashing stream: chunks alternate between `stream` and this one (created on first use)
+  hipStream_t aux2_stream = nullptr;  // sampling, gathers and downloads of the streamed proof-input path (created on first use)
   std::shared_ptr<cp2i::BlockPool> pool = std::make_shared<cp2i::BlockPool>();
   size_t stage_bytes = (size_t)1 << 31;   // device staging chunk of the fake-data builder
   int ingest_threads = 0, ingest_ring = 0;   // 0: CP2_INGEST_* environment or the built-in default (cp2_set_ingest)
@@ -138,6 +139,7 @@ struct DevBuf {
       if (owner) {
         (void)hipStreamSynchronize(owner->stream);
         if (owner->aux_stream) (void)hipStreamSynchronize(owner->aux_stream);
+        if (owner->aux2_stream) (void)hipStreamSynchronize(owner->aux2_stream);
         owner->pool->put(false, p, bytes);
       } else {
         (void)hipFree(p);
@@ -290,7 +292,7 @@ inline std::vector<size_t> layer_sizes_of(size_t n) {
 int merkle_trees_dev(cp2_ctx* ctx, const void* d_leaves, size_t n, size_t nseg, void* d_layers_out, bool leaves_in_place);
 // hash n host-resident cells into d_leaves (device, n x 32 bytes) through the pinned ingestion pipe
 int hash_host_cells_pipelined(cp2_ctx* ctx, const uint8_t* cells, size_t cell_size, size_t n, uint8_t* d_leaves);
-// the context's second stream (created on first use)
-int aux_stream(cp2_ctx* ctx, hipStream_t* out);
+// the context's second (which = 1) or third (which = 2) stream, created on first use
+int aux_stream(cp2_ctx* ctx, hipStream_t* out, int which = 1);
 
 }  // namespace cp2i

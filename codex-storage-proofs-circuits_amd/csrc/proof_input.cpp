@@ -818,8 +818,8 @@ extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, u
   const cp2_config cfgv = ds->cfg;
   const std::string file_base = ds->file_base;
 
-  hipStream_t aux = nullptr;
-  CP2_TRY(aux_stream(ctx, &aux));
+  hipStream_t aux = nullptr;                                   // the sampling / download stream (the context's third)
+  CP2_TRY(aux_stream(ctx, &aux, 2));
   SampleDev dev;
   StreamRing ring;
   CP2_TRY(dev.init(ctx, group_slots, ns, md, cs, !from_file));
@@ -885,10 +885,8 @@ extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, u
         // ring slot r was last used by pass k - DEPTH: its tasks must have been handed out and finished
         while (consumed + StreamRing::DEPTH <= k) { CP2_TRY(consume(consumed)); ++consumed; }
         while (ring.pending[r].load() != 0) std::this_thread::yield();
-        if (tree_stream != aux) {   // the builders run a group's layers on the second stream already; otherwise order after them
-          CP2_HIP(ctx, hipEventRecord(trees_ready, tree_stream));
-          CP2_HIP(ctx, hipStreamWaitEvent(aux, trees_ready, 0));
-        }
+        CP2_HIP(ctx, hipEventRecord(trees_ready, tree_stream));   // the group's layer passes end on one of the two hashing streams
+        CP2_HIP(ctx, hipStreamWaitEvent(aux, trees_ready, 0));
         CP2_TRY(enqueue_sampling(t, geom, dev, ring.host[r], nullptr, g0, g1 - g0, ns, md, !from_file, aux));
         CP2_HIP(ctx, hipEventRecord(ring.landed[r], aux));
         ring.s0[r] = g0;

@@ -38,9 +38,10 @@ void StageTimer::lap(const char* what) {
   t0 = t1;
 }
 
-int aux_stream(cp2_ctx* ctx, hipStream_t* out) {
-  if (!ctx->aux_stream) CP2_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-  *out = ctx->aux_stream;
+int aux_stream(cp2_ctx* ctx, hipStream_t* out, int which) {
+  hipStream_t& st = which == 2 ? ctx->aux2_stream : ctx->aux_stream;
+  if (!st) CP2_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  *out = st;
   return CP2_OK;
 }
 
@@ -129,30 +130,44 @@ static int trees_build_layers(cp2_slot_trees* t, size_t s0, size_t s1, hipStream
 }
 
 // Tracks which slots have all their cells hashed and runs the layer passes (and the caller's hook) group by group.
-// With groups, the layer passes go to the context's SECOND stream: the upper layers of a group are small launches
-// whose duration is the latency of one permutation chain each (~0.1 ms), and on their own stream that latency hides
-// behind the next group's cell hashing instead of idling the GPU between two big kernels.
+// Cell hashing alternates between the context's two streams, chunk by chunk (hs[0] = ctx->stream, hs[1] = the second
+// stream): consecutive kernels of one stream leave the GPU half empty while the last workgroups of one retire and the
+// next has not started, and with two streams the next chunk's workgroups take the freed CUs at once (ingestion: +7...15 %,
+// profiles/r02_ingest_scaling.txt; fake-data build of 4096 slots: -0.9 %).  With GROUPS (the streamed proof-input path) the
+// fake builder hashes on the context's stream only and the group's layer passes go to the second stream: those small
+// launches, each as long as one permutation chain (~0.1 ms), hide behind the next group's hashing, and groups complete one
+// after the other (two chunks in flight finish together and leave twice the formatting work for the end: +1.8 % measured).
 namespace {
 struct LayerScheduler {
   cp2_slot_trees* t;
   size_t group;
   const SlotsDone& done;
   size_t built = 0;
-  hipStream_t tree_stream = nullptr;
-  hipEvent_t hashed = nullptr;
+  hipStream_t hs[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};     // the latest hashing enqueued on each stream
   ~LayerScheduler() {
-    if (tree_stream && tree_stream != t->ctx->stream) (void)hipStreamSynchronize(tree_stream);
-    if (hashed) (void)hipEventDestroy(hashed);
+    for (int i = 0; i < 2; ++i) {
+      if (hs[i]) (void)hipStreamSynchronize(hs[i]);
+      if (ev[i]) (void)hipEventDestroy(ev[i]);
+    }
   }
   int init() {
     cp2_ctx* ctx = t->ctx;
-    if (group == 0) { tree_stream = ctx->stream; return CP2_OK; }
-    CP2_TRY(aux_stream(ctx, &tree_stream));
-    CP2_HIP(ctx, hipEventCreateWithFlags(&hashed, hipEventDisableTiming));
+    hs[0] = ctx->stream;
+    CP2_TRY(aux_stream(ctx, &hs[1]));
+    for (int i = 0; i < 2; ++i) {
+      CP2_HIP(ctx, hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+      CP2_HIP(ctx, hipEventRecord(ev[i], hs[i]));
+    }
     return CP2_OK;
   }
-  // cells [0, cells_hashed) of the batch are enqueued for hashing on the context's stream
-  int advance(size_t cells_hashed, bool final) {
+  // a chunk's hashing has just been enqueued on hs[s]
+  int hashed_on(int s) {
+    CP2_HIP(t->ctx, hipEventRecord(ev[s], hs[s]));
+    return CP2_OK;
+  }
+  // cells [0, cells_hashed) of the batch are enqueued for hashing, the last chunk on hs[s]
+  int advance(size_t cells_hashed, bool final, int s) {
     cp2_ctx* ctx = t->ctx;
     const size_t complete = cells_hashed / t->n_cells;
     for (;;) {
@@ -161,19 +176,18 @@ struct LayerScheduler {
       if (group && avail >= group) take = group;
       else if (final && avail) take = avail;
       if (!take) return CP2_OK;
-      if (tree_stream != ctx->stream) {
-        CP2_HIP(ctx, hipEventRecord(hashed, ctx->stream));
-        CP2_HIP(ctx, hipStreamWaitEvent(tree_stream, hashed, 0));
-      }
-      CP2_TRY(trees_build_layers(t, built, built + take, tree_stream));
-      if (done) CP2_TRY(done(t, built, built + take, tree_stream));
+      (void)s;
+      const int ts = group ? 1 : 0;             // groups: layer passes on the second stream; otherwise everything ends on the context's
+      CP2_HIP(ctx, hipStreamWaitEvent(hs[ts], ev[1 - ts], 0));   // cells of these slots were (also) hashed on the other stream
+      CP2_TRY(trees_build_layers(t, built, built + take, hs[ts]));
+      if (done) CP2_TRY(done(t, built, built + take, hs[ts]));
       built += take;
     }
   }
   int finish() {   // everything of both streams done
     cp2_ctx* ctx = t->ctx;
-    CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (tree_stream && tree_stream != ctx->stream) CP2_HIP(ctx, hipStreamSynchronize(tree_stream));
+    CP2_HIP(ctx, hipStreamSynchronize(hs[0]));
+    CP2_HIP(ctx, hipStreamSynchronize(hs[1]));
     return CP2_OK;
   }
 };
@@ -195,17 +209,22 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
   size_t chunk = std::max<size_t>(1, std::min(total_cells, ctx->stage_bytes / cell_size));
   if (chunk > n_cells) chunk -= chunk % n_cells;
   if (group && chunk > group * n_cells) chunk = group * n_cells;
-  DevBuf stage;
-  CP2_TRY(stage.scratch(ctx, chunk * cell_size));
+  const bool two = total_cells > chunk && group == 0;          // a second staging buffer only when chunks alternate between the streams
+  DevBuf stage[2];
+  CP2_TRY(stage[0].scratch(ctx, chunk * cell_size));
+  if (two) CP2_TRY(stage[1].scratch(ctx, chunk * cell_size));
   const uint64_t seed0 = cp2_slot_seed(dataset_seed, first_slot);
   LayerScheduler sched{t.get(), group, done};
   int st = sched.init();
-  for (size_t c0 = 0; st == CP2_OK && c0 < total_cells; c0 += chunk) {
+  size_t turn = 0;
+  for (size_t c0 = 0; st == CP2_OK && c0 < total_cells; c0 += chunk, ++turn) {
     size_t n = std::min(chunk, total_cells - c0);
-    hipError_t e = cp2k::launch_gen_fake_cells(seed0, n_cells, c0, nullptr, n, cell_size, stage.p, ctx->stream);
-    if (e == hipSuccess) e = cp2k::launch_hash_cells(stage.p, cell_size, n, t->nodes.u8() + c0 * 32, ctx->stream);
+    const int s = group ? 0 : (int)(turn & 1);                 // generation + hashing of this chunk on stream s, in its own staging buffer
+    hipError_t e = cp2k::launch_gen_fake_cells(seed0, n_cells, c0, nullptr, n, cell_size, stage[s].p, sched.hs[s]);
+    if (e == hipSuccess) e = cp2k::launch_hash_cells(stage[s].p, cell_size, n, t->nodes.u8() + c0 * 32, sched.hs[s]);
     if (e != hipSuccess) { ctx->err = hipGetErrorString(e); st = CP2_ERR_HIP; break; }
-    st = sched.advance(c0 + n, c0 + n == total_cells);
+    st = sched.hashed_on(s);
+    if (st == CP2_OK) st = sched.advance(c0 + n, c0 + n == total_cells, s);
   }
   int fin = sched.finish();
   if (st == CP2_OK) st = fin;
@@ -280,9 +299,12 @@ struct IngestPipe {
   size_t chunk = 0, turn = 0;
   int threads = 1;
   std::unique_ptr<Workers> pool;
+  hipStream_t hash_stream[2] = {nullptr, nullptr};   // chunks alternate between the context's two streams: the next chunk's
+                                                     // workgroups fill the CUs as the previous kernel's last ones retire
 
   ~IngestPipe() {
     if (!ctx) return;
+    (void)finish();
     (void)hipStreamSynchronize(ctx->stream);
     if (copy) (void)hipStreamSynchronize(copy);
     for (int b = 0; b < depth; ++b) {
@@ -301,6 +323,8 @@ struct IngestPipe {
     threads = std::max(1, std::min(threads, 64));
     chunk = std::max<size_t>(1, std::min(max_cells, chunk_bytes / cell_size));
     CP2_HIP(ctx, hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+    hash_stream[0] = ctx->stream;
+    CP2_TRY(aux_stream(ctx, &hash_stream[1]));
     for (int b = 0; b < want_depth; ++b) {
       CP2_TRY(pinned[b].alloc(ctx, chunk * cell_size));
       CP2_TRY(dev[b].scratch(ctx, chunk * cell_size));
@@ -320,10 +344,11 @@ struct IngestPipe {
     f(0, n / nt);
     pool->wait_idle();
   }
-  // cells of the next chunk: the first one is a quarter of the ring slot, so that the GPU starts hashing after a quarter
-  // of the fill + upload latency (its short kernel hides under the second chunk's upload)
+  // cells of the next chunk: a quarter, a half, three quarters of the ring slot, then whole slots.  The GPU starts hashing
+  // after a quarter of the fill + upload latency, and each upload (57 GB/s) still lands before the previous, shorter
+  // kernel (43 GB/s, never under 3.75 ms) has finished, so the start-up bubble stays under a millisecond.
   size_t next_cells(size_t remaining) const {
-    size_t m = turn == 0 ? std::max<size_t>(chunk / 4, std::min<size_t>(chunk, 32768)) : chunk;
+    size_t m = turn < 3 ? std::max<size_t>(chunk * (turn + 1) / 4, std::min<size_t>(chunk, 32768)) : chunk;
     return std::min(m, remaining);
   }
   // the pinned buffer the host may fill next (blocks until the kernel that last used this ring slot is done)
@@ -338,10 +363,21 @@ struct IngestPipe {
     int b = (int)(turn % depth);
     CP2_HIP(ctx, hipMemcpyAsync(dev[b].p, pinned[b].p, m * cell_size, hipMemcpyHostToDevice, copy));
     CP2_HIP(ctx, hipEventRecord(copied[b], copy));
-    CP2_HIP(ctx, hipStreamWaitEvent(ctx->stream, copied[b], 0));
-    CP2_HIP(ctx, cp2k::launch_hash_cells(dev[b].p, cell_size, m, leaves_out, ctx->stream));
-    CP2_HIP(ctx, hipEventRecord(hashed[b], ctx->stream));
+    hipStream_t hs = hash_stream[turn & 1];
+    CP2_HIP(ctx, hipStreamWaitEvent(hs, copied[b], 0));
+    CP2_HIP(ctx, cp2k::launch_hash_cells(dev[b].p, cell_size, m, leaves_out, hs));
+    CP2_HIP(ctx, hipEventRecord(hashed[b], hs));
+    last_on_aux = (turn & 1) ? b : last_on_aux;
     ++turn;
+    return CP2_OK;
+  }
+  int last_on_aux = -1;
+  // everything hashed on the second stream is ordered before whatever the caller enqueues next on the context's stream
+  int finish() {
+    if (last_on_aux >= 0) {
+      CP2_HIP(ctx, hipStreamWaitEvent(ctx->stream, hashed[last_on_aux], 0));
+      last_on_aux = -1;
+    }
     return CP2_OK;
   }
 };
@@ -358,7 +394,7 @@ int cp2i::hash_host_cells_pipelined(cp2_ctx* ctx, const uint8_t* cells, size_t c
     pipe.parallel_ranges(m * cell_size, (size_t)2 << 20, [=](size_t a, size_t b) { std::memcpy(buf + a, src + a, b - a); });
     CP2_TRY(pipe.submit(m, cell_size, d_leaves + c0 * 32));
   }
-  return CP2_OK;   // the pipe's destructor waits for the streams
+  return pipe.finish();   // the pipe's destructor waits for the streams
 }
 
 extern "C" int cp2_slot_trees_build_host(cp2_ctx* ctx, const uint8_t* cells, size_t n_slots, size_t cell_size,
@@ -425,7 +461,9 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
         st = pipe.submit(m, cell_size, t->nodes.u8() + (s * n_cells + c0) * 32);
       }
       close(fd);
-      if (st == CP2_OK) st = sched.advance((s + 1) * n_cells, s + 1 == n_slots);
+      if (st == CP2_OK) st = pipe.finish();   // the context's stream now follows everything hashed on the second one
+      if (st == CP2_OK) st = sched.hashed_on(0);
+      if (st == CP2_OK) st = sched.advance((s + 1) * n_cells, s + 1 == n_slots, 0);
     }
     int fin = sched.finish();
     if (st == CP2_OK) st = fin;
@@ -594,6 +632,7 @@ extern "C" void cp2_slot_trees_free(cp2_slot_trees* t) {
   (void)hipSetDevice(t->ctx->device);
   (void)hipStreamSynchronize(t->ctx->stream);
   if (t->ctx->aux_stream) (void)hipStreamSynchronize(t->ctx->aux_stream);
+  if (t->ctx->aux2_stream) (void)hipStreamSynchronize(t->ctx->aux2_stream);
   delete t;
 }
 
