@@ -352,15 +352,21 @@ def witness_leg(torch, ctx, pkg):
     ctx.reset_stream()
     torch.cuda.synchronize()
     res = {}
-    # ---- classic
-    t0 = time.perf_counter()
-    ds = ctx.dataset(cfg)                 # every slot tree, built once (sync on return)
-    ds.set_roots(None)                    # dataset tree over the 4096 slot roots
-    t1 = time.perf_counter()
-    nbytes = ds.export_proof_inputs(list(range(n_slots)), 1234567, None, threads=threads, batch=512)
-    t2 = time.perf_counter()
-    root_hex = ds.root().tobytes()[::-1].hex()
-    ds.free()
+    # ---- classic, twice: the first pass of a context also allocates its device staging (two 2 GiB buffers), the node
+    # buffer and the pinned landing zones, which the context keeps
+    classic = []
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ds = ctx.dataset(cfg)                 # every slot tree, built once (sync on return)
+        ds.set_roots(None)                    # dataset tree over the 4096 slot roots
+        t1 = time.perf_counter()
+        nbytes = ds.export_proof_inputs(list(range(n_slots)), 1234567, None, threads=threads, batch=512)
+        t2 = time.perf_counter()
+        root_hex = ds.root().tobytes()[::-1].hex()
+        ds.free()
+        classic.append((t1 - t0, t2 - t1))
+    t0, t1, t2 = 0.0, min(c[0] for c in classic), min(c[0] + c[1] for c in classic)
     # ---- streamed, twice: the first pass also pays for the pinned staging (hipHostMalloc), which the context keeps
     runs = []
     for _ in range(2):
@@ -384,7 +390,8 @@ def witness_leg(torch, ctx, pkg):
     res["witnesses"] = {"workload": "configs[3]: nSamples=100, maxDepth=32, 4096 slots x 2^12 cells (32 GiB fake data) batched, 1 GPU",
                         "json_threads": threads, "json_bytes": nbytes,
                         "classic": {"build_trees_s": round(t1 - t0, 4), "pipelined_generate_and_json_s": round(t2 - t1, 4),
-                                    "witnesses_per_s_with_json": n_slots / (t2 - t0)},
+                                    "witnesses_per_s_with_json": n_slots / (t2 - t0),
+                                    "runs_trees_then_export_s": [[round(a, 4), round(b, 4)] for a, b in classic]},
                         "streamed_runs": runs,
                         "witnesses_per_s_with_json": n_slots / best,
                         "witnesses_per_s_with_json_first_run": n_slots / runs[0]["total_s"],
