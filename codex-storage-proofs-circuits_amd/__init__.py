@@ -85,6 +85,8 @@ def load_library():
         "cp2_last_error": (cp, [vp]),
         "cp2_device_is_native": (i32, [vp]),
         "cp2_set_ingest": (i32, [vp, i32, i32, sz]),
+        "cp2_trim": (i32, [vp]),
+        "cp2_set_body_budget": (i32, [vp, sz, cp]),
         "cp2_permute_batch": (i32, [vp, vp, vp, sz]),
         "cp2_permute_batch_dev": (i32, [vp, vp, vp, sz]),
         "cp2_compress_batch": (i32, [vp, vp, u32, vp, sz]),
@@ -225,6 +227,13 @@ class Context:
 
     def set_ingest(self, fill_threads=0, ring_depth=0, chunk_bytes=0):
         self._ck(self.L.cp2_set_ingest(self.h, fill_threads, ring_depth, chunk_bytes), "cp2_set_ingest")
+
+    def trim(self):
+        """Give the context's cached device / pinned scratch back to the system (cp2_trim)."""
+        self._ck(self.L.cp2_trim(self.h), "cp2_trim")
+
+    def set_body_budget(self, max_resident_bytes=0, spill_dir=None):
+        self._ck(self.L.cp2_set_body_budget(self.h, max_resident_bytes, spill_dir.encode() if spill_dir else None), "cp2_set_body_budget")
 
     # -- a1
     def permute_batch(self, states, out=None):

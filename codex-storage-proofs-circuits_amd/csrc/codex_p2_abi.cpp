@@ -94,6 +94,31 @@ extern "C" int cp2_sync(cp2_ctx* ctx) try {
   return CP2_ERR_INVALID;
 }
 
+extern "C" int cp2_trim(cp2_ctx* ctx) try {
+  if (!ctx) return CP2_ERR_INVALID;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));            // nothing in flight may still touch a cached block
+  if (ctx->aux_stream) CP2_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
+  if (ctx->aux2_stream) CP2_HIP(ctx, hipStreamSynchronize(ctx->aux2_stream));
+  ctx->pool->trim();
+  return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
+}
+
+extern "C" int cp2_set_body_budget(cp2_ctx* ctx, size_t max_resident_bytes, const char* spill_dir) try {
+  if (!ctx) return CP2_ERR_INVALID;
+  if (max_resident_bytes) ctx->body_budget = max_resident_bytes;
+  ctx->spill_dir = spill_dir ? spill_dir : "";
+  return CP2_OK;
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
+}
+
 extern "C" const char* cp2_strerror(int status) {
   switch (status) {
     case CP2_OK: return "ok";
@@ -478,7 +503,7 @@ extern "C" int cp2_gen_fake_cells(cp2_ctx* ctx, uint64_t seed, uint64_t first, s
 extern "C" int cp2_cell_indices(cp2_ctx* ctx, const uint8_t entropy[32], const uint8_t slot_root[32], uint64_t n_cells,
                                 size_t n_samples, uint64_t* out) try {
   if (!ctx || !entropy || !slot_root || (n_samples && !out)) return CP2_ERR_INVALID;
-  if (n_cells == 0 || (n_cells & (n_cells - 1)) != 0) return CP2_ERR_INVALID;   // sample/bn254.nim:19-20
+  if (n_cells < 2 || (n_cells & (n_cells - 1)) != 0) return CP2_ERR_INVALID;    // sample/bn254.nim:19-20; one cell: extractLowBits asserts k > 0 (types/bn254.nim:48)
   if (n_samples == 0) return CP2_OK;
   std::vector<uint8_t> felts(n_samples * 96, 0), dig(n_samples * 32);
   for (size_t i = 0; i < n_samples; ++i) {

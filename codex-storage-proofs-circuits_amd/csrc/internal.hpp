@@ -104,6 +104,8 @@ struct cp2_ctx {
   size_t stage_bytes = (size_t)1 << 31;   // device staging chunk of the fake-data builder
   int ingest_threads = 0, ingest_ring = 0;   // 0: CP2_INGEST_* environment or the built-in default (cp2_set_ingest)
   size_t ingest_chunk = 0;
+  size_t body_budget = 0;                    // streamed proof-input bodies kept in host memory; 0: CP2_BODY_BUDGET_MB or 4 GiB (cp2_set_body_budget)
+  std::string spill_dir;                     // where bodies beyond the budget go; empty: $TMPDIR or /tmp
   std::string err;
 };
 

@@ -9,6 +9,9 @@
 //
 // All global-memory field elements are 32-byte little-endian canonical integers (the ABI format).
 #include "kernels.hpp"
+
+#include <cstdlib>
+
 #include "poseidon2_dev.hpp"
 
 namespace cp2k {
@@ -173,14 +176,19 @@ __device__ __forceinline__ void chunk_pair(const uint32_t (&w)[17], Fe& a, Fe& b
 
 // LDS allows three workgroups per CU = three waves per SIMD: tell the register allocator that is also the MOST it will
 // ever get, so that it uses the registers (up to 168) instead of squeezing the staging loops for an occupancy it cannot have
-__global__ void __launch_bounds__(TPB, CP2_HASH_WAVES) __attribute__((amdgpu_waves_per_eu(CP2_HASH_WAVES, CP2_HASH_WAVES))) k_hash_cells(const uint8_t* __restrict__ cells, size_t cell_size,
+//
+// BT = threads per workgroup: 256 (four waves share one reduction table: 54 016 B of LDS, three workgroups per CU; what the
+// product launches) or 64 (one wave per workgroup: 16 384 B, ten per CU; kept for tools/hash_block_sweep.cpp, which showed
+// that the workgroup shape does not matter below 256 MiB and that 64 lanes lose above: profiles/r03_hash_block_sweep.txt).
+template <int BT>
+__global__ void __launch_bounds__(BT, CP2_HASH_WAVES) __attribute__((amdgpu_waves_per_eu(CP2_HASH_WAVES, CP2_HASH_WAVES))) k_hash_cells(const uint8_t* __restrict__ cells, size_t cell_size,
                                                                       size_t n_cells, uint4* __restrict__ out) {
   __shared__ fr::QTab qtab;
-  __shared__ uint32_t ring[TPB / 64][64 * RING_STRIDE];
-  fr::qtab_fill(qtab, threadIdx.x, TPB);
+  __shared__ uint32_t ring[BT / 64][64 * RING_STRIDE];
+  fr::qtab_fill(qtab, threadIdx.x, BT);
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const size_t cell0 = (size_t)blockIdx.x * TPB + (size_t)wave * 64;
+  const size_t cell0 = (size_t)blockIdx.x * BT + (size_t)wave * 64;
   const size_t my_cell = cell0 + lane;
   const size_t nfelts = (cell_size + 31) / 31;            // chunks of cell || 0x01
   const size_t total = (nfelts + 2) & ~(size_t)1;          // + sponge pad, even
@@ -406,44 +414,88 @@ __global__ void __launch_bounds__(TPB) k_gather_rows(const uint8_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-static inline unsigned grid_for(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
+// Workgroups for n work items.  A grid holds at most 2^31 - 1 workgroups in x; the per-item kernels are launched in slices of
+// at most MAX_ITEMS items (every item is independent and addressed from a base pointer), the layer / sampling kernels, whose
+// item index is decomposed inside the kernel, refuse what does not fit one grid (2^38 nodes: far beyond any HBM).
+constexpr size_t MAX_BLOCKS = (size_t)1 << 30;
+constexpr size_t MAX_ITEMS = MAX_BLOCKS * TPB;
+static inline bool fits_one_grid(size_t n) { return (n + TPB - 1) / TPB <= MAX_BLOCKS; }
+static inline unsigned grid_for(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }   // n <= MAX_ITEMS
 
 hipError_t launch_permute_batch(const void* in, void* out, size_t n, hipStream_t st) {
-  if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_permute_batch, dim3(grid_for(n)), dim3(TPB), 0, st, (const uint4*)in, (uint4*)out, n);
-  return hipGetLastError();
+  for (size_t i0 = 0; i0 < n; i0 += MAX_ITEMS) {
+    const size_t m = n - i0 < MAX_ITEMS ? n - i0 : MAX_ITEMS;
+    hipLaunchKernelGGL(k_permute_batch, dim3(grid_for(m)), dim3(TPB), 0, st, (const uint4*)in + 6 * i0, (uint4*)out + 6 * i0, m);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 hipError_t launch_compress_layer(const void* in, void* out, size_t m_in, size_t nseg, bool bottom,
                                  size_t in_seg_stride, size_t out_seg_stride, hipStream_t st) {
   size_t m_out = (m_in + 1) / 2;
   if (m_out * nseg == 0) return hipSuccess;
+  if (!fits_one_grid(m_out * nseg)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_compress_layer, dim3(grid_for(m_out * nseg)), dim3(TPB), 0, st, (const uint4*)in, (uint4*)out,
                      m_in, m_out, nseg, bottom ? 1u : 0u, in_seg_stride, out_seg_stride);
   return hipGetLastError();
 }
 
 hipError_t launch_compress_pairs(const void* xy, uint32_t key, void* out, size_t n, hipStream_t st) {
-  if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_compress_pairs, dim3(grid_for(n)), dim3(TPB), 0, st, (const uint4*)xy, key, (uint4*)out, n);
-  return hipGetLastError();
+  for (size_t i0 = 0; i0 < n; i0 += MAX_ITEMS) {
+    const size_t m = n - i0 < MAX_ITEMS ? n - i0 : MAX_ITEMS;
+    hipLaunchKernelGGL(k_compress_pairs, dim3(grid_for(m)), dim3(TPB), 0, st, (const uint4*)xy + 4 * i0, key, (uint4*)out + 2 * i0, m);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 hipError_t launch_sponge2_felts(const void* felts, size_t nf, size_t nitems, void* out, hipStream_t st) {
-  if (nitems == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_sponge2_felts, dim3(grid_for(nitems)), dim3(TPB), 0, st, (const uint4*)felts, nf, nitems, (uint4*)out);
-  return hipGetLastError();
+  for (size_t i0 = 0; i0 < nitems; i0 += MAX_ITEMS) {
+    const size_t m = nitems - i0 < MAX_ITEMS ? nitems - i0 : MAX_ITEMS;
+    hipLaunchKernelGGL(k_sponge2_felts, dim3(grid_for(m)), dim3(TPB), 0, st, (const uint4*)felts + 2 * nf * i0, nf, m, (uint4*)out + 2 * i0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+// Workgroup size of k_hash_cells: 256 unless CP2_HASH_BLOCK=64 is in the environment (A/B tooling only).
+static int hash_block_override() {
+  static const int v = [] {
+    const char* e = std::getenv("CP2_HASH_BLOCK");
+    const int x = e ? std::atoi(e) : 0;
+    return (x == 64 || x == 256) ? x : 0;
+  }();
+  return v;
+}
+
+hipError_t launch_hash_cells_block(int block, const void* cells, size_t cell_size, size_t n_cells, void* out, hipStream_t st) {
+  if (block != 64 && block != 256) return hipErrorInvalidValue;
+  const size_t max_items = MAX_BLOCKS * (size_t)block;
+  for (size_t i0 = 0; i0 < n_cells; i0 += max_items) {
+    const size_t m = n_cells - i0 < max_items ? n_cells - i0 : max_items;
+    const unsigned grid = (unsigned)((m + block - 1) / block);
+    const uint8_t* src = (const uint8_t*)cells + i0 * cell_size;
+    if (block == 64) hipLaunchKernelGGL(k_hash_cells<64>, dim3(grid), dim3(64), 0, st, src, cell_size, m, (uint4*)out + 2 * i0);
+    else hipLaunchKernelGGL(k_hash_cells<256>, dim3(grid), dim3(256), 0, st, src, cell_size, m, (uint4*)out + 2 * i0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 hipError_t launch_hash_cells(const void* cells, size_t cell_size, size_t n_cells, void* out, hipStream_t st) {
-  if (n_cells == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_hash_cells, dim3(grid_for(n_cells)), dim3(TPB), 0, st, (const uint8_t*)cells, cell_size, n_cells, (uint4*)out);
-  return hipGetLastError();
+  const int block = hash_block_override();
+  return launch_hash_cells_block(block ? block : 256, cells, cell_size, n_cells, out, st);
 }
 
 hipError_t launch_gen_fake_cells(uint64_t seed0, uint64_t cells_per_slot, uint64_t first, const uint64_t* list,
                                  size_t n_cells, size_t cell_size, void* out, hipStream_t st) {
   if (n_cells == 0 || cell_size == 0) return hipSuccess;
+  if (!fits_one_grid(n_cells)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_gen_fake_cells, dim3(grid_for(n_cells)), dim3(TPB), 0, st, seed0, cells_per_slot, first, list,
                      n_cells, cell_size, (uint8_t*)out);
   return hipGetLastError();
@@ -453,6 +505,7 @@ hipError_t launch_sample_paths(const TreeGeom& g, const void* nodes, const void*
                                size_t n_items, uint32_t ns, uint32_t md, uint64_t* indices, uint64_t* gcell, uint64_t* rows,
                                hipStream_t st) {
   if (n_items == 0 || ns == 0) return hipSuccess;
+  if (!fits_one_grid(n_items * ns)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_sample_paths, dim3(grid_for(n_items * ns)), dim3(TPB), 0, st, g, (const uint4*)nodes, (const uint4*)d_entropy,
                      slots, slot0, n_items, ns, md, indices, gcell, rows);
   return hipGetLastError();
@@ -461,8 +514,7 @@ hipError_t launch_sample_paths(const TreeGeom& g, const void* nodes, const void*
 hipError_t launch_gather_rows(const void* src, const uint64_t* index, size_t nrows, size_t row_bytes, void* out, hipStream_t st) {
   if (nrows == 0) return hipSuccess;
   size_t work = nrows * (row_bytes / 4);
-  unsigned grid = grid_for(work);
-  if (grid > 4096) grid = 4096;
+  unsigned grid = work > (size_t)4096 * TPB ? 4096u : grid_for(work);
   hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(TPB), 0, st, (const uint8_t*)src, index, nrows, row_bytes, (uint8_t*)out);
   return hipGetLastError();
 }

@@ -19,7 +19,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -31,6 +33,84 @@ using namespace cp2i;
 // ---------------------------------------------------------------------------------------------
 // dataset
 // ---------------------------------------------------------------------------------------------
+// JSON bodies (", \"cellData\": ... }") of the streamed build, one per local slot.  Bodies stay in host memory up to the
+// context's budget (cp2_set_body_budget; 0.7 MB each at nSamples = 100, cellSize = 2048: 23 GB for 32 768 local slots if
+// nothing bounded it); beyond it they go to "<dir>/cp2_body_<pid>_<dataset>_<slot>.part" and are read back at export.
+// put() is called from the formatting workers, everything else from the owning thread.
+struct BodyStore {
+  std::vector<std::string> mem;
+  std::vector<uint64_t> size;        // text length of every body, resident or spilled
+  std::vector<uint8_t> spilled;
+  std::string dir, tag;
+  size_t budget = 0;
+  std::atomic<size_t> resident{0};
+  std::atomic<size_t> n_spilled{0};
+  ~BodyStore() {
+    for (size_t s = 0; s < spilled.size(); ++s)
+      if (spilled[s]) std::remove(file_of(s).c_str());
+  }
+  void init(cp2_ctx* ctx, size_t n) {
+    static std::atomic<unsigned> serial{0};
+    mem.assign(n, std::string());
+    size.assign(n, 0);
+    spilled.assign(n, 0);
+    budget = ctx->body_budget;
+    if (!budget) {
+      const char* e = std::getenv("CP2_BODY_BUDGET_MB");
+      const unsigned long long mb = e ? std::strtoull(e, nullptr, 10) : 0;
+      budget = mb ? (size_t)mb << 20 : (size_t)4 << 30;
+    }
+    dir = ctx->spill_dir;
+    if (dir.empty()) { const char* t = std::getenv("TMPDIR"); dir = (t && *t) ? t : "/tmp"; }
+    tag = std::to_string((long)getpid()) + "_" + std::to_string(serial.fetch_add(1));
+  }
+  std::string file_of(size_t s) const { return dir + "/cp2_body_" + tag + "_" + std::to_string(s) + ".part"; }
+  // takes a copy of exactly text.size() bytes (the caller's buffer is sized for the worst case and reused)
+  int put(size_t s, const std::string& text) {
+    size[s] = text.size();
+    const size_t before = resident.fetch_add(text.size());
+    if (before + text.size() <= budget) {
+      mem[s].assign(text.data(), text.size());
+      return CP2_OK;
+    }
+    resident.fetch_sub(text.size());
+    FILE* f = std::fopen(file_of(s).c_str(), "wb");
+    if (!f) return CP2_ERR_IO;
+    const bool ok = std::fwrite(text.data(), 1, text.size(), f) == text.size();
+    if (std::fclose(f) != 0 || !ok) { std::remove(file_of(s).c_str()); return CP2_ERR_IO; }
+    spilled[s] = 1;
+    n_spilled.fetch_add(1);
+    return CP2_OK;
+  }
+  // appends the body of slot s to `out`
+  int append(size_t s, std::string& out) const {
+    if (!spilled[s]) { out.append(mem[s]); return CP2_OK; }
+    FILE* f = std::fopen(file_of(s).c_str(), "rb");
+    if (!f) return CP2_ERR_IO;
+    const size_t at = out.size();
+    out.resize(at + size[s]);
+    const bool ok = std::fread(&out[at], 1, size[s], f) == size[s];
+    std::fclose(f);
+    return ok ? CP2_OK : CP2_ERR_IO;
+  }
+  // writes the body of slot s to an open file (spilled bodies are copied through a bounded buffer)
+  int write_to(size_t s, FILE* dst) const {
+    if (!spilled[s]) return std::fwrite(mem[s].data(), 1, mem[s].size(), dst) == mem[s].size() ? CP2_OK : CP2_ERR_IO;
+    FILE* f = std::fopen(file_of(s).c_str(), "rb");
+    if (!f) return CP2_ERR_IO;
+    std::vector<char> buf((size_t)1 << 20);
+    uint64_t left = size[s];
+    bool ok = true;
+    while (ok && left) {
+      const size_t m = (size_t)std::min<uint64_t>(left, buf.size());
+      ok = std::fread(buf.data(), 1, m, f) == m && std::fwrite(buf.data(), 1, m, dst) == m;
+      left -= m;
+    }
+    std::fclose(f);
+    return ok ? CP2_OK : CP2_ERR_IO;
+  }
+};
+
 struct cp2_dataset {
   cp2_ctx* ctx = nullptr;
   cp2_config cfg{};
@@ -44,7 +124,7 @@ struct cp2_dataset {
   // streamed build: one JSON body (", \"cellData\": ... }") per local slot, made while later slots were hashing
   bool prepared = false;
   uint8_t prep_entropy[32] = {};
-  std::vector<std::string> bodies;
+  BodyStore bodies;
   ~cp2_dataset() { cp2_slot_trees_free(trees); }
 };
 
@@ -331,6 +411,7 @@ extern "C" int cp2_proof_inputs_generate_batch(cp2_dataset* ds, const uint64_t* 
   for (size_t i = 0; i < n; ++i)
     if (slot_idx[i] < ds->first_slot || slot_idx[i] >= ds->first_slot + ds->n_local) return CP2_ERR_INVALID;
   if (!is_pow2(cfg.n_cells)) return CP2_ERR_INVALID;                    // sample/bn254.nim:19-20
+  if (cfg.n_samples && cfg.n_cells < 2) return CP2_ERR_INVALID;         // extractLowBits asserts k > 0, types/bn254.nim:48
   if (!ds->have_roots) CP2_TRY(cp2_dataset_set_roots(ds, nullptr));
   if (ds->dsizes.size() - 1 > (size_t)cfg.max_log2_nslots) return CP2_ERR_INVALID;   // padMerkleProof assert
   if (cp2_slot_trees_depth(t) > (size_t)cfg.max_depth) return CP2_ERR_INVALID;        // padMerkleProof assert
@@ -652,6 +733,16 @@ int write_parts(const char* path, const std::string& a, const std::string& b) {
   return (w == a.size() + b.size() && rc == 0) ? CP2_OK : CP2_ERR_IO;
 }
 
+// head, then the stored body of local slot s (resident or spilled)
+int write_head_and_body(const char* path, const std::string& head, const BodyStore& bodies, size_t s) {
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return CP2_ERR_IO;
+  int st = std::fwrite(head.data(), 1, head.size(), f) == head.size() ? CP2_OK : CP2_ERR_IO;
+  if (st == CP2_OK) st = bodies.write_to(s, f);
+  if (std::fclose(f) != 0 && st == CP2_OK) st = CP2_ERR_IO;
+  return st;
+}
+
 }  // namespace
 
 static void proof_input_text(const cp2_proof_input* p, std::string& s) {
@@ -784,10 +875,23 @@ struct StreamRing {
   static constexpr int DEPTH = 3;
   SampleHost host[DEPTH];
   hipEvent_t landed[DEPTH] = {};
-  std::atomic<size_t> pending[DEPTH];     // body tasks still reading host[r]
   size_t s0[DEPTH] = {}, s1[DEPTH] = {};   // slot range parked in host[r]
-  StreamRing() { for (auto& p : pending) p.store(0); }
   ~StreamRing() { for (auto e : landed) if (e) (void)hipEventDestroy(e); }   // host[] drain their stream themselves
+  // body tasks still reading host[r]: the build thread sleeps on the condition variable until a ring slot is free
+  void begin(int r, size_t n) { std::lock_guard<std::mutex> lk(mu); pending[r] = n; }
+  void task_done(int r) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (--pending[r] == 0) cv.notify_all();
+  }
+  void wait_free(int r) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return pending[r] == 0; });
+  }
+
+ private:
+  std::mutex mu;
+  std::condition_variable cv;
+  size_t pending[DEPTH] = {};
 };
 
 }  // namespace
@@ -798,6 +902,7 @@ extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, u
   *out = nullptr;
   CP2_TRY(dataset_check(cfg, first_slot, n_local));
   if (!is_pow2(cfg->n_cells)) return CP2_ERR_INVALID;                    // sample/bn254.nim:19-20
+  if (cfg->n_samples && cfg->n_cells < 2) return CP2_ERR_INVALID;        // extractLowBits asserts k > 0, types/bn254.nim:48
   CP2_TRY(trees_check_geometry(cfg->cell_size, cfg->block_size, cfg->n_cells, n_local));
   {
     const size_t cpb = cfg->block_size / cfg->cell_size, depth = (layer_sizes_of(cpb).size() - 1) + (layer_sizes_of(cfg->n_cells / cpb).size() - 1);
@@ -812,7 +917,7 @@ extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, u
 
   std::unique_ptr<cp2_dataset> ds(dataset_new(ctx, cfg, first_slot, n_local));
   if (!ds) return CP2_ERR_ALLOC;
-  ds->bodies.resize(n_local);
+  ds->bodies.init(ctx, n_local);
   std::memcpy(ds->prep_entropy, entropy, 32);
   const bool from_file = ds->from_file;
   const cp2_config cfgv = ds->cfg;
@@ -833,6 +938,8 @@ extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, u
   struct EvGuard { hipEvent_t e; ~EvGuard() { (void)hipEventDestroy(e); } } ev_guard{trees_ready};
 
   std::atomic<int> task_status{CP2_OK};
+  std::mutex io_mu;
+  std::string io_error;         // first slot file a formatting worker could not open
   cp2_dataset* dsp = ds.get();
   size_t n_groups = 0;          // sampling passes enqueued so far
   size_t consumed = 0;          // passes whose body tasks have been handed to the workers
@@ -847,29 +954,42 @@ extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, u
       const int r = (int)(k % StreamRing::DEPTH);
       CP2_HIP(ctx, hipEventSynchronize(ring.landed[r]));
       const size_t a = ring.s0[r], b = ring.s1[r];
-      ring.pending[r].store(b - a);
+      ring.begin(r, b - a);
       for (size_t s = a; s < b; ++s) {
         pool.submit([&, s, a, r] {
           try {
             const uint8_t* paths = ring.host[r].paths.u8() + (s - a) * ns * md * 32;
             const uint64_t* idx = static_cast<const uint64_t*>(ring.host[r].idx.p) + (s - a) * ns;
-            std::string& body = dsp->bodies[s];
+            static thread_local std::string body;   // worst-case sized once per worker; the store keeps an exact-size copy
             body.clear();
             body.reserve(body_reserve(cfgv, ns));
+            bool have = true;
             if (from_file) {      // sampled cells straight from the slot file (slot.nim:57-68)
               std::vector<uint8_t> cells(ns * cs);
-              int fd = open(slot_file_name(file_base, first_slot + s).c_str(), O_RDONLY);
-              if (fd < 0) task_status.store(CP2_ERR_IO);
-              for (size_t c = 0; c < ns; ++c) read_file_cell(fd, cs, idx[c], &cells[c * cs]);
-              if (fd >= 0) close(fd);
-              text_body(body, cfgv, ns, cells.data(), paths);
+              const std::string fname = slot_file_name(file_base, first_slot + s);
+              int fd = open(fname.c_str(), O_RDONLY);
+              if (fd < 0) {       // reported like the classic path ("cannot open <file>"); no body for this slot
+                task_status.store(CP2_ERR_IO);
+                std::lock_guard<std::mutex> lk(io_mu);
+                if (io_error.empty()) io_error = "cannot open " + fname;
+                have = false;
+              } else {
+                for (size_t c = 0; c < ns; ++c) read_file_cell(fd, cs, idx[c], &cells[c * cs]);
+                close(fd);
+                text_body(body, cfgv, ns, cells.data(), paths);
+              }
             } else {
               text_body(body, cfgv, ns, ring.host[r].cells.u8() + (s - a) * ns * cs, paths);
+            }
+            if (have && dsp->bodies.put(s, body) != CP2_OK) {
+              task_status.store(CP2_ERR_IO);
+              std::lock_guard<std::mutex> lk(io_mu);
+              if (io_error.empty()) io_error = "cannot write " + dsp->bodies.file_of(s);
             }
           } catch (...) {
             task_status.store(CP2_ERR_ALLOC);
           }
-          ring.pending[r].fetch_sub(1);
+          ring.task_done(r);
         });
       }
       return CP2_OK;
@@ -884,7 +1004,7 @@ extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, u
         const int r = (int)(k % StreamRing::DEPTH);
         // ring slot r was last used by pass k - DEPTH: its tasks must have been handed out and finished
         while (consumed + StreamRing::DEPTH <= k) { CP2_TRY(consume(consumed)); ++consumed; }
-        while (ring.pending[r].load() != 0) std::this_thread::yield();
+        ring.wait_free(r);
         CP2_HIP(ctx, hipEventRecord(trees_ready, tree_stream));   // the group's layer passes end on one of the two hashing streams
         CP2_HIP(ctx, hipStreamWaitEvent(aux, trees_ready, 0));
         CP2_TRY(enqueue_sampling(t, geom, dev, ring.host[r], nullptr, g0, g1 - g0, ns, md, !from_file, aux));
@@ -906,7 +1026,10 @@ extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, u
     trace.lap("last bodies");
     if (st != CP2_OK) return st;
   }
-  if (task_status.load() != CP2_OK) return task_status.load();
+  if (task_status.load() != CP2_OK) {
+    if (!io_error.empty()) ctx->err = io_error;
+    return task_status.load();
+  }
   ds->prepared = true;
   *out = ds.release();
   return CP2_OK;
@@ -937,10 +1060,10 @@ extern "C" int cp2_dataset_export_streamed(cp2_dataset* ds, const char* dir, int
         head.clear();
         fill_slot_proof(ds, slot, proof);
         text_head(head, ds->cfg, slot, &ds->dlayers[ds->dlayers.size() - 32], ds->prep_entropy, &ds->dlayers[slot * 32], proof.data());
-        bytes[t] += head.size() + ds->bodies[s].size();
+        bytes[t] += head.size() + ds->bodies.size[s];
         if (dir) {
           std::string name = std::string(dir) + "/input_" + std::to_string(slot) + ".json";
-          int st = write_parts(name.c_str(), head, ds->bodies[s]);
+          int st = write_head_and_body(name.c_str(), head, ds->bodies, s);
           if (st != CP2_OK) status[t] = st;
         }
       }
@@ -977,14 +1100,13 @@ extern "C" int cp2_dataset_streamed_json(cp2_dataset* ds, uint64_t slot_idx, cha
   std::vector<uint8_t> proof;
   fill_slot_proof(ds, slot_idx, proof);
   text_head(head, ds->cfg, slot_idx, &ds->dlayers[ds->dlayers.size() - 32], ds->prep_entropy, &ds->dlayers[slot_idx * 32], proof.data());
-  const std::string& body = ds->bodies[slot_idx - ds->first_slot];
-  char* buf = (char*)std::malloc(head.size() + body.size() + 1);
+  CP2_TRY(ds->bodies.append(slot_idx - ds->first_slot, head));
+  char* buf = (char*)std::malloc(head.size() + 1);
   if (!buf) return CP2_ERR_ALLOC;
   std::memcpy(buf, head.data(), head.size());
-  std::memcpy(buf + head.size(), body.data(), body.size());
-  buf[head.size() + body.size()] = 0;
+  buf[head.size()] = 0;
   *text = buf;
-  if (len) *len = head.size() + body.size();
+  if (len) *len = head.size();
   return CP2_OK;
 } catch (const std::bad_alloc&) {
   return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI

@@ -61,6 +61,17 @@ int cp2_device_is_native(const cp2_ctx* ctx);
  * (environment CP2_INGEST_THREADS / CP2_INGEST_RING / CP2_INGEST_CHUNK_MB, else 8 threads, depth 3 and one full
  * residency of the hash kernel per chunk: 768 x 256 cells, 384 MiB at 2 KiB cells). */
 int cp2_set_ingest(cp2_ctx* ctx, int fill_threads, int ring_depth, size_t chunk_bytes);
+/* Memory a long-lived context holds.  Scratch blocks (device staging, pinned landing zones) are cached per context so that
+ * repeated calls stop allocating: up to 6 GiB of device memory and 3 GiB of PINNED host memory stay with the context after
+ * the calls that needed them.  cp2_trim waits for the context's streams and gives all cached blocks back to the system
+ * (blocks still referenced by live proof inputs return when those are freed); the next call allocates again. */
+int cp2_trim(cp2_ctx* ctx);
+/* Host memory of the streamed proof-input path (cp2_dataset_build_streamed): the JSON body of every local slot (about 0.7 MB
+ * at nSamples = 100, cellSize = 2048) is kept until the dataset is freed.  Bodies beyond `max_resident_bytes` in total are
+ * written to "<spill_dir>/cp2_body_<pid>_<dataset>_<slot>.part" instead and read back by cp2_dataset_export_streamed /
+ * cp2_dataset_streamed_json; the files are removed by cp2_dataset_free.  Defaults: 4 GiB (environment CP2_BODY_BUDGET_MB),
+ * spill_dir NULL = $TMPDIR or /tmp.  max_resident_bytes = 0 keeps the current budget; (size_t)-1 = never spill. */
+int cp2_set_body_budget(cp2_ctx* ctx, size_t max_resident_bytes, const char* spill_dir);
 
 /* ---- a1: Poseidon2 t=3 permutation --------------------------------------------------------- */
 /* replaces nim-poseidon2 `perm` as specified by reference/haskell/src/Poseidon2/Permutation.hs:40-45.
@@ -120,7 +131,7 @@ int cp2_gen_fake_cells_dev(cp2_ctx* ctx, uint64_t seed, uint64_t first, size_t n
 
 /* ---- a12: sampling ---------------------------------------------------------------------------- */
 /* replaces `cellIndices`, reference/nim/proof_input/src/sample/bn254.nim:16-27 (counters 1..n_samples).
- * n_cells must be a power of two. */
+ * n_cells must be a power of two and at least 2 (`extractLowBits` asserts k > 0, types/bn254.nim:48). */
 int cp2_cell_indices(cp2_ctx* ctx, const uint8_t entropy[32], const uint8_t slot_root[32], uint64_t n_cells,
                      size_t n_samples, uint64_t* out);
 
