@@ -1,6 +1,7 @@
-"""One rank of the sharded dataset build on a real GPU (child process of tests/test_gpu_sharded.py).
+"""One rank of the sharded dataset build on a real GPU (child process of tests/rank_helpers.py).
 
-  RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment; argv: <out.json> <gpu index> <config json> <entropy>
+  RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment; argv: <out.json> <gpu index> <config json> <entropy> [roots.npy]
+  (roots.npy: rank 0 saves the gathered (n_slots, 32) root array there, for the parent's oracle comparisons)
 
 Uses the PRODUCT path only (distributed.HipBackend -> libcodex_p2.so); collectives over gloo so that several ranks can
 share one GPU (RCCL refuses two ranks per device).  The parent compares what is written here with the oracle."""
@@ -15,6 +16,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     out_path, gpu, cfg_json, entropy = sys.argv[1], int(sys.argv[2]), json.loads(sys.argv[3]), int(sys.argv[4])
+    roots_path = sys.argv[5] if len(sys.argv) > 5 else None
     import importlib
     import torch.distributed as dist
     import __graft_entry__ as g
@@ -27,6 +29,9 @@ def main():
     cfg = pkg.make_config(**cfg_json)
     backend = d.HipBackend(pkg, ctx)
     root, all_roots, (first, count) = d.dataset_root_sharded(backend, cfg, rank, world, dist if world > 1 else None, "cpu")
+    if roots_path and rank == 0:
+        import numpy as np
+        np.save(roots_path, all_roots)
     res = {"rank": rank, "world": world, "first": first, "count": count, "dataset_root_hex": root.tobytes()[::-1].hex(),
            "all_roots_sha256": hashlib.sha256(all_roots.tobytes()).hexdigest(), "inputs": {}}
     for slot in sorted({first, first + count - 1}) if count else []:

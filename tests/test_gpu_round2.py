@@ -2,16 +2,13 @@
 (multi-rank) product path on one GPU, the streamed build+export pipeline, slot files against the oracle directly,
 cache validation and ingestion knobs.  Everything goes through the C ABI (ctypes) of libcodex_p2.so."""
 import hashlib
-import json
 import os
-import socket
-import subprocess
-import sys
 
 import numpy as np
 import pytest
 
 from oracle_helpers import expected_proof_input_fast
+from rank_helpers import run_ranks
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -155,35 +152,6 @@ def test_sharded_datasets_equal_unsharded(pkg, ctx, oracle, golden, tmp_path, so
     assert sb.streamed_json(3) == golden("input_testmain_small.json")
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-def _run_ranks(world, cfg, entropy, tmp_path):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world))
-    procs, outs = [], []
-    for r in range(world):
-        out = str(tmp_path / ("rank%d_of%d.json" % (r, world)))
-        outs.append(out)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_rank_child.py"), out, "0", json.dumps(cfg), str(entropy)],
-                                      env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    res = []
-    for p, out in zip(procs, outs):
-        try:
-            so, se = p.communicate(timeout=600)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        assert p.returncode == 0, se[-3000:]
-        res.append(json.load(open(out)))
-    return res
-
-
 @pytest.mark.parametrize("world", [1, 2])
 def test_hipbackend_sharded_ranks_vs_oracle(pkg, oracle, tmp_path, world):
     """BASELINE.json configs[4]'s code path: distributed.dataset_root_sharded with HipBackend, one fresh process per
@@ -192,7 +160,7 @@ def test_hipbackend_sharded_ranks_vs_oracle(pkg, oracle, tmp_path, world):
     C, P = oracle
     c = dict(maxDepth=16, maxLog2NSlots=3, cellSize=2048, blockSize=65536, nSlots=5, nCells=256, nSamples=20, seed=2024)
     entropy = 987654321
-    res = _run_ranks(world, c, entropy, tmp_path)
+    res = run_ranks(world, c, entropy, tmp_path)
     roots = np.stack([C.fake_slot_root(C.slot_seed(c["seed"], s), c["cellSize"], c["blockSize"], c["nCells"], 4) for s in range(c["nSlots"])])
     want_root = hexroot(C.merkle_root(roots))
     want_sha = hashlib.sha256(roots.tobytes()).hexdigest()

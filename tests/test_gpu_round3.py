@@ -1,0 +1,86 @@
+"""GPU suite, round 3 additions (-m gpu): bounded host memory of the streamed path (spilled bodies), cp2_trim, error reporting of
+the streamed workers, the reference's `k > 0` assert in sampling, launches sliced beyond one grid's worth of items."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle_helpers import expected_proof_input_fast
+
+pytestmark = pytest.mark.gpu
+
+
+def test_streamed_bodies_spill_beyond_the_budget(pkg, ctx, oracle, tmp_path):
+    """cp2_set_body_budget: the same texts whether a body stayed in memory or went through a spill file; files are removed
+    with the dataset; an unwritable spill directory is an I/O error with the file name, not silent truncation."""
+    C, P = oracle
+    c = dict(maxDepth=12, maxLog2NSlots=4, cellSize=256, blockSize=2048, nSlots=11, nCells=128, nSamples=7, seed=424242)
+    cfg = pkg.make_config(**c)
+    want = {s: P.export_json(expected_proof_input_fast(C, P, c, s, 55555, threads=4)) for s in (0, 3, 10)}
+    body = len(want[0])                                  # a little more than one body
+    spill = tmp_path / "spill"
+    spill.mkdir()
+    try:
+        for budget, lo, hi in ((1, 11, 11), (3 * body, 7, 10), (1 << 30, 0, 0)):
+            ctx.set_body_budget(budget, str(spill))
+            ds = ctx.dataset_streamed(cfg, 55555, threads=3, group_slots=2)
+            assert lo <= len(os.listdir(spill)) <= hi, (budget, os.listdir(spill))
+            out = tmp_path / ("out%d" % budget)
+            out.mkdir()
+            total = ds.export_streamed(str(out), threads=2)
+            assert total == sum(os.path.getsize(out / f) for f in os.listdir(out))
+            for s, t in want.items():
+                assert ds.streamed_json(s) == t and open(out / ("input_%d.json" % s)).read() == t
+            ds.free()
+            assert os.listdir(spill) == []
+        ctx.set_body_budget(1, str(tmp_path / "does" / "not" / "exist"))
+        with pytest.raises(pkg.CodexP2Error) as e:
+            ctx.dataset_streamed(cfg, 55555, threads=2, group_slots=2)
+        assert e.value.status == -5 and "cp2_body_" in str(e.value)
+    finally:
+        ctx.set_body_budget(4 << 30, None)
+
+
+def test_streamed_missing_slot_file_names_the_file(pkg, ctx, oracle, tmp_path):
+    """A slot file that disappears between the build and the sampling of its cells: CP2_ERR_IO and "cannot open <file>", like
+    the classic path (the trees were built from the page-cache copy; here the file is simply absent from the start)."""
+    C, _ = oracle
+    base = str(tmp_path / "slot")
+    for k in (0, 2):
+        C.gen_fake_cells(C.slot_seed(1, k), 0, 64, 128).tofile("%s%d.dat" % (base, k))
+    cfg = pkg.make_config(maxDepth=10, maxLog2NSlots=2, cellSize=128, blockSize=1024, nSlots=3, nCells=64, nSamples=4, file=base)
+    for build in (lambda: ctx.dataset(cfg), lambda: ctx.dataset_streamed(cfg, 7, threads=2, group_slots=1)):
+        with pytest.raises(pkg.CodexP2Error) as e:
+            build()
+        assert e.value.status == -5 and "cannot open" in str(e.value) and "slot1.dat" in str(e.value)
+
+
+def test_trim_releases_cached_scratch_and_context_keeps_working(pkg, ctx, oracle):
+    import torch
+    C, _ = oracle
+    cells = np.random.default_rng(3).integers(0, 256, size=(40000, 2048), dtype=np.uint8)     # 78 MiB: through the pinned ring
+    want = ctx.hash_cells(cells, 2048)
+    assert np.array_equal(want[:64], C.hash_cells(cells[:64], 2048, threads=4))
+    free_cached, _ = torch.cuda.mem_get_info()
+    ctx.trim()
+    free_trimmed, _ = torch.cuda.mem_get_info()
+    assert free_trimmed >= free_cached + (64 << 20)                # the device ring (3 chunks) went back to the system
+    assert np.array_equal(ctx.hash_cells(cells, 2048), want)       # and the next call simply allocates again
+    ctx.trim()
+
+
+def test_sampling_rejects_a_single_cell_like_the_reference(pkg, ctx):
+    """numberOfCells = 1 means log2 = 0 and `extractLowBits` asserts k > 0 (types/bn254.nim:48)."""
+    e, r = pkg.felt_bytes(5), pkg.felt_bytes(6)
+    with pytest.raises(pkg.CodexP2Error):
+        ctx.cell_indices(e, r, 1, 3)
+    assert list(ctx.cell_indices(e, r, 2, 3)) == [int(v) & 1 for v in ctx.cell_indices(e, r, 1 << 20, 3)]
+    cfg = pkg.make_config(maxDepth=4, maxLog2NSlots=1, cellSize=64, blockSize=64, nSlots=2, nCells=1, nSamples=2, seed=3)
+    ds = ctx.dataset(cfg)                                           # the trees exist (one cell, one block) ...
+    assert ds.local_roots().shape == (2, 32)
+    with pytest.raises(pkg.CodexP2Error):
+        ds.proof_input(0, 1)                                        # ... but nothing can be sampled from them
+    with pytest.raises(pkg.CodexP2Error):
+        ctx.dataset_streamed(cfg, 1, threads=1)
+    cfg0 = pkg.make_config(maxDepth=4, maxLog2NSlots=1, cellSize=64, blockSize=64, nSlots=2, nCells=1, nSamples=0, seed=3)
+    assert '"cellData"' in ctx.dataset(cfg0).proof_input(1, 1).json()   # no samples, no cellIndex call: allowed

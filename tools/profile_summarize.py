@@ -2,7 +2,7 @@
 """Turns gpurun_out/prof_<round>/ (tools/profile_round.sh) into the committed summaries under profiles/."""
 import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 O = os.path.join(ROOT, "gpurun_out", "prof_" + R)
 P = os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
@@ -25,22 +25,33 @@ if trace:
             launches.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
 
 
-def counters_of(dirs, kernel):
-    out = {}
+def counters_of(dirs, kernel, grid=None):
+    """Per-launch averages of every counter collected for `kernel` in the given passes; `_pass_kernel_ms[d]` = that kernel's own
+    average duration INSIDE pass d (its dispatch timestamps in the counter CSV), so that a counter is only ever set against
+    the time and the clock of the pass it was collected in."""
+    out, pass_ms = {}, {}
     for d in dirs:
         fs = newest(os.path.join(O, d, "*", "*_counter_collection.csv"))
         if not fs:
             continue
         agg = collections.defaultdict(list)
+        dur = {}
         for r in csv.DictReader(open(fs[0])):
-            if r["Kernel_Name"].startswith(kernel):
+            if r["Kernel_Name"].startswith(kernel) and (grid is None or int(r["Grid_Size"]) == grid):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                    dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
         for k, v in agg.items():
-            out[k] = {"per_launch_avg": sum(v) / len(v), "per_launch_max": max(v), "launches": len(v)}
+            out[k] = {"per_launch_avg": sum(v) / len(v), "per_launch_max": max(v), "launches": len(v), "pass": d}
+        if dur:
+            pass_ms[d] = sum(dur.values()) / len(dur)
+    out["_pass_kernel_ms"] = pass_ms
     return out
 
 
-counters = counters_of(("fetch", "write", "sq", "sq2"), "cp2k::k_permute_batch")
+counters = counters_of(("fetch", "write", "sq", "sq2"), "cp2k::k_permute_batch", grid=1 << 24)
+pass_ms = counters.pop("_pass_kernel_ms")
+box = open(os.path.join(O, "box.txt")).read().strip().splitlines() if os.path.exists(os.path.join(O, "box.txt")) else []
 n = 1 << 24
 perm = [r for r in rows if "k_permute_batch" in r["Name"]][0]
 avg_ms = sum(launches) / len(launches) if launches else float(perm["AverageNs"]) * 1e-6
@@ -50,9 +61,9 @@ res = {
     "commands": "tools/profile_round.sh: rocprofv3 --kernel-trace --stats / --pmc <group> (separate passes) -- python3 bench.py ...",
     "kernel_trace_avg_launch_ms": avg_ms,
     "kernel_trace_launches_ms": [round(x, 4) for x in launches],
-    "kernel_trace_note": "average over the 2^24-state launches of the kernel trace (3 warm-up + 10 timed), listed one by one; the --stats CSV "
+    "kernel_trace_note": "average over the 2^24-state launches of the kernel trace (5 warm-up + 20 timed: the driver's command), listed one by one; the --stats CSV "
                          "row of this kernel also averages in the 2^20-state chunk launches of the ingest leg's host-array call "
-                         "(%s calls, %.3f ms on average), so it is not comparable; bench.py's own average (HIP events) covers the 10 timed launches"
+                         "(%s calls, %.3f ms on average), so it is not comparable; bench.py's own average (HIP events) covers the 20 timed launches"
                          % (perm["Calls"], float(perm["AverageNs"]) * 1e-6),
     "kernel_trace_avg_excluding_first_ms": (sum(launches[1:]) / len(launches[1:])) if len(launches) > 1 else None,
     "counters": counters,
@@ -63,19 +74,34 @@ res = {
     "algorithmic_bytes_per_launch": 192 * n,
     "valu_insts_per_wave": counters["SQ_INSTS_VALU"]["per_launch_avg"] / (n / 64),
     "mad_u64_u32_per_permutation": 33120,
-    "shader_clock_GHz_from_GRBM_GUI_ACTIVE": counters["GRBM_GUI_ACTIVE"]["per_launch_avg"] / 8 / (avg_ms * 1e-3) / 1e9,
-    # SQ_ACTIVE_INST_VALU counts quad-cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs.  Unclamped: in this
-    # kernel every VALU instruction costs about one 4-cycle issue slot (profiles/r02_marginal_cost_probe.txt), so the
-    # ratio is instructions x 4 / cycles and can read slightly above 1 when the PMC pass and the timing pass clock differently
-    "valu_busy_frac_raw": counters["SQ_ACTIVE_INST_VALU"]["per_launch_avg"] * 4 / (counters["GRBM_GUI_ACTIVE"]["per_launch_avg"] / 8 * 1024),
-    "issue_cycles_per_wave_model": None,
+    "box": box,
+    "kernel_ms_inside_each_pmc_pass": {k: round(v, 4) for k, v in pass_ms.items()},
+}
+# The instruction-issue view, from ONE pass (`sq`): GRBM_GUI_ACTIVE is summed over the 8 XCDs, so /8 = shader cycles of the
+# launch; 1024 SIMDs issue SQ_INSTS_VALU wave-instructions in them.  No time and no clock enters the ratio; the clock of the
+# pass (cycles / the kernel's duration inside the same pass) is reported beside it.
+cyc = counters["GRBM_GUI_ACTIVE"]["per_launch_avg"] / 8
+insts = counters["SQ_INSTS_VALU"]["per_launch_avg"]
+sq_ms = pass_ms.get("sq")
+res["valu_issue"] = {
+    "bound": "valu-issue", "pass": "sq (rocprofv3 --pmc SQ_INSTS_VALU ... GRBM_GUI_ACTIVE, one pass)",
+    "cycles_per_valu_instruction": round(cyc * 1024 / insts, 4),
+    "full_rate_cycles_per_instruction": 4.0,
+    "valu_insts_per_permutation": insts / (n / 64),
+    "mad_u64_u32_per_permutation": 33120, "mad_share_of_valu_insts": round(33120 / (insts / (n / 64)), 4),
+    "shader_cycles_per_launch": cyc, "valu_wave_insts_per_launch": insts,
+    "kernel_ms_in_this_pass": sq_ms, "shader_clock_GHz_in_this_pass": (cyc / (sq_ms * 1e-3) / 1e9) if sq_ms else None,
+    "explanation": "a wave64 VALU instruction occupies a 16-lane SIMD for 4 cycles: 4.0 cycles per instruction per SIMD is what a "
+                   "saturated issue port reads.  The marginal-cost probe (profiles/r02_marginal_cost_probe.txt) prices every instruction "
+                   "kind of this kernel at 3.9-4.4 cycles except v_mov_b32 (0.9; about 3 % of the stream), which is why the average can "
+                   "sit a little under 4.  The port is saturated; the only lever left is the instruction count",
 }
 json.dump(res, open(os.path.join(P, "%s_permute_batch_traffic.json" % R), "w"), indent=1)
 print(json.dumps({k: res[k] for k in ("kernel_trace_avg_launch_ms", "kernel_trace_avg_excluding_first_ms", "hbm_bytes_per_launch",
-                                      "algorithmic_bytes_per_launch", "valu_insts_per_wave", "shader_clock_GHz_from_GRBM_GUI_ACTIVE",
-                                      "valu_busy_frac_raw")}))
+                                      "algorithmic_bytes_per_launch", "valu_insts_per_wave", "valu_issue")}))
 # config 3's kernel: the launch over the whole 8 GiB slot is the one with the largest counter value
 hc = counters_of(("hfetch", "hwrite"), "cp2k::k_hash_cells")
+hc.pop("_pass_kernel_ms", None)
 if "FETCH_SIZE" in hc and "WRITE_SIZE" in hc:
     rd, wr = hc["FETCH_SIZE"]["per_launch_max"] * 1024 * 2, hc["WRITE_SIZE"]["per_launch_max"] * 1024
     h = {"round": R, "kernel": "cp2k::k_hash_cells", "workload": "configs[2]: 2^22 cells x 2048 B (8 GiB slot), the largest launch of the run",
