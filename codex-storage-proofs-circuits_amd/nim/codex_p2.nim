@@ -29,6 +29,8 @@ proc cp2_init(device: cint, ctx: ptr Cp2Ctx): cint {.importc.}
 proc cp2_free(ctx: Cp2Ctx) {.importc.}
 proc cp2_strerror(status: cint): cstring {.importc.}
 proc cp2_last_error(ctx: Cp2Ctx): cstring {.importc.}
+proc cp2_trim(ctx: Cp2Ctx): cint {.importc.}
+proc cp2_set_body_budget(ctx: Cp2Ctx, maxResidentBytes: csize_t, spillDir: cstring): cint {.importc.}
 proc cp2_permute_batch(ctx: Cp2Ctx, inp, outp: ptr byte, n: csize_t): cint {.importc.}
 proc cp2_compress_batch(ctx: Cp2Ctx, xy: ptr byte, key: uint32, outp: ptr byte, n: csize_t): cint {.importc.}
 proc cp2_sponge2_felts(ctx: Cp2Ctx, felts: ptr byte, n: csize_t, outp: ptr byte): cint {.importc.}
@@ -45,6 +47,9 @@ proc cp2_cell_indices(ctx: Cp2Ctx, entropy, slotRoot: ptr byte, nCells: uint64, 
                       outp: ptr uint64): cint {.importc.}
 proc cp2_dataset_build(ctx: Cp2Ctx, cfg: ptr Cp2Config, firstSlot, nLocal: uint64, ds: ptr Cp2Dataset): cint {.importc.}
 proc cp2_dataset_free(ds: Cp2Dataset) {.importc.}
+proc cp2_dataset_build_streamed(ctx: Cp2Ctx, cfg: ptr Cp2Config, firstSlot, nLocal: uint64, entropy: ptr byte, threads: cint,
+                                groupSlots: csize_t, ds: ptr Cp2Dataset): cint {.importc.}
+proc cp2_dataset_export_streamed(ds: Cp2Dataset, dir: cstring, threads: cint, totalBytes: ptr uint64): cint {.importc.}
 proc cp2_proof_input_generate(ds: Cp2Dataset, slotIdx: uint64, entropy: ptr byte, p: ptr Cp2ProofInput): cint {.importc.}
 proc cp2_proof_input_free(p: Cp2ProofInput) {.importc.}
 proc cp2_proof_input_write_json(p: Cp2ProofInput, path: cstring): cint {.importc.}
@@ -74,6 +79,12 @@ proc check(st: cint, what: string) =
   ## nothing aborts across the C ABI; keep the reference's behaviour (assert -> AssertionDefect) on this side
   if st != 0: raiseAssert(what & ": " & $cp2_strerror(st) & " " & $cp2_last_error(ctx()))
 
+# Empty inputs are legal at the seam (nim-poseidon2 hashes the padding of an empty sequence, and so does the C ABI when
+# the length is 0), but `unsafeAddr a[0]` of an empty openArray raises IndexDefect: hand the engine a valid dummy address.
+var gDummy: array[32, byte]
+template firstByte[T](a: openArray[T]): ptr byte =
+  (if a.len > 0: cast[ptr byte](unsafeAddr a[0]) else: addr gDummy[0])
+
 # ---- the nim-poseidon2 / constantine names the reference imports -------------------------------------
 const zero*: F = default(F)
 
@@ -94,29 +105,29 @@ type Merkle* = object
 proc digest*(_: type Sponge, input: openArray[F], rate: static int = 2): F =
   ## Sponge.digest(seq[F], rate = 2)  (sample/bn254.nim:23)
   static: doAssert rate == 2
-  check(cp2_sponge2_felts(ctx(), cast[ptr byte](unsafeAddr input[0]), csize_t(input.len), addr result[0]), "Sponge.digest")
+  check(cp2_sponge2_felts(ctx(), firstByte(input), csize_t(input.len), addr result[0]), "Sponge.digest")
 
 proc digest*(_: type Sponge, input: openArray[byte], rate: static int = 2): F =
   ## Sponge.digest(bytes, rate = 2)  (blocks/bn254.nim:27): 10* byte padding, 31-byte chunks, rate-2 sponge
   static: doAssert rate == 2
-  check(cp2_hash_cells(ctx(), unsafeAddr input[0], csize_t(input.len), 1, addr result[0]), "Sponge.digest(bytes)")
+  check(cp2_hash_cells(ctx(), firstByte(input), csize_t(input.len), 1, addr result[0]), "Sponge.digest(bytes)")
 
 proc hashCells*(data: openArray[byte], cellSize: int): seq[F] =
   ## data.len / cellSize cells hashed in one launch (blocks/bn254.nim:23-29 applied to every cell of a block)
   doAssert cellSize > 0 and data.len mod cellSize == 0
   result = newSeq[F](data.len div cellSize)
   if result.len > 0:
-    check(cp2_hash_cells(ctx(), unsafeAddr data[0], csize_t(cellSize), csize_t(result.len), cast[ptr byte](addr result[0])), "hashCells")
+    check(cp2_hash_cells(ctx(), firstByte(data), csize_t(cellSize), csize_t(result.len), cast[ptr byte](addr result[0])), "hashCells")
 
 proc digest*(_: type Merkle, xs: openArray[F]): F =
-  ## Merkle.digest (merkle/bn254.nim:20)
-  check(cp2_merkle_root(ctx(), cast[ptr byte](unsafeAddr xs[0]), csize_t(xs.len), addr result[0]), "Merkle.digest")
+  ## Merkle.digest (merkle/bn254.nim:20); an empty input is refused by the engine (Merkle.hs:72 "input is empty") -> raiseAssert
+  check(cp2_merkle_root(ctx(), firstByte(xs), csize_t(xs.len), addr result[0]), "Merkle.digest")
 
 iterator elements*(bytes: openArray[byte], _: type F): F =
   ## poseidon2/io elements (json/bn254.nim:11,25)
   let n = int(cp2_felts_per_bytes(csize_t(bytes.len)))
-  var buf = newSeq[F](n)
-  check(cp2_bytes_to_felts(unsafeAddr bytes[0], csize_t(bytes.len), cast[ptr byte](addr buf[0])), "elements")
+  var buf = newSeq[F](n)            # n >= 1: even empty input yields the chunk that carries the 0x01 marker
+  check(cp2_bytes_to_felts(firstByte(bytes), csize_t(bytes.len), cast[ptr byte](addr buf[0])), "elements")
   for f in buf: yield f
 
 func toDecimal*(a: F): string =
@@ -216,7 +227,7 @@ proc engineMerkleLayers*(xs: openArray[F]): seq[seq[F]] =
   var flat = newSeq[F](total)
   var sizes = newSeq[csize_t](80)
   var nl: csize_t
-  check(cp2_merkle_tree(ctx(), cast[ptr byte](unsafeAddr xs[0]), csize_t(xs.len), cast[ptr byte](addr flat[0]),
+  check(cp2_merkle_tree(ctx(), firstByte(xs), csize_t(xs.len), cast[ptr byte](addr flat[0]),
                         addr sizes[0], addr nl), "cp2_merkle_tree")
   var off = 0
   for k in 0 ..< int(nl):
@@ -233,3 +244,19 @@ proc engineCellIndices*(entropy, slotRoot: F, numberOfCells, nSamples: int): seq
 
 proc writeCircomMainComponentP2*(cfg: var Cp2Config, fname: string) =
   check(cp2_write_circom_main(addr cfg, cstring(fname)), "cp2_write_circom_main")
+
+proc engineExportAllProofInputs*(cfg: var Cp2Config, entropy: F, dir: string, threads: int = 8): uint64 =
+  ## every slot's input.json ("<dir>/input_<slot>.json") in ONE overlapped pass (no reference counterpart: the reference makes
+  ## one proof input per run): gen_input/bn254.nim:35-79 + json/bn254.nim:57-78 for all slots, trees built once
+  var ds: Cp2Dataset
+  var e = entropy
+  check(cp2_dataset_build_streamed(ctx(), addr cfg, 0, cfg.nSlots, addr e[0], cint(threads), 0, addr ds), "cp2_dataset_build_streamed")
+  defer: cp2_dataset_free(ds)
+  check(cp2_dataset_export_streamed(ds, cstring(dir), cint(threads), addr result), "cp2_dataset_export_streamed")
+
+proc engineTrim*() =
+  ## give the engine's cached device / pinned scratch back to the system (a long-lived process between runs)
+  check(cp2_trim(ctx()), "cp2_trim")
+
+proc engineSetBodyBudget*(maxResidentBytes: int, spillDir: string = "") =
+  check(cp2_set_body_budget(ctx(), csize_t(maxResidentBytes), (if spillDir.len > 0: cstring(spillDir) else: nil)), "cp2_set_body_budget")
