@@ -1,4 +1,4 @@
-"""Soak of the round-2 host pipelines (streamed build + export, sharded datasets, ingestion knobs, host-array streaming):
+"""Soak of the host pipelines (streamed build + export with spilled bodies, sharded datasets, ingestion knobs, host-array streaming, cp2_trim):
 random shapes, the streamed text against the object path on every slot and against the oracle on some, with resident
 host memory and free device memory watched for leaks.  Usage: soak_pipeline.py [seconds]"""
 import hashlib, os, resource, sys, tempfile, time
@@ -23,7 +23,7 @@ while time.time() - t0 < budget:
     cpb = int(rng.choice([1, 2, 4, 32]))
     nblocks = int(rng.choice([1, 2, 8, 64, 256]))
     nc = cpb * nblocks
-    if nc & (nc - 1):
+    if nc & (nc - 1) or nc < 2:      # one cell: nothing can be sampled (extractLowBits asserts k > 0, types/bn254.nim:48)
         continue
     ns_slots = int(rng.integers(1, 24))
     c = dict(maxDepth=16, maxLog2NSlots=5, cellSize=cs, blockSize=cs * cpb, nSlots=ns_slots, nCells=nc, nSamples=int(rng.integers(1, 40)),
@@ -41,6 +41,8 @@ while time.time() - t0 < budget:
         cc["file"] = base
     cfg = pkg.make_config(**cc)
     ctx.set_ingest(int(rng.choice([0, 1, 3])), int(rng.choice([0, 2, 4])), int(rng.choice([0, 1 << 16, 1 << 20])))
+    # bodies kept in memory up to a random budget (1 byte: every body spills; 50 KB: some do; 4 GiB: none does)
+    ctx.set_body_budget(int(rng.choice([1, 50000, 4 << 30])), tmp)
     ref = ctx.dataset(cfg)
     sd = ctx.dataset_streamed(cfg, entropy, threads=threads, group_slots=group)
     sd.export_streamed(None, threads=threads)
@@ -65,6 +67,11 @@ while time.time() - t0 < budget:
             print("MISMATCH sharded", c, flush=True)
         a.free(); b.free()
     ref.free(); sd.free()
+    if any(f.endswith(".part") for f in os.listdir(tmp)):
+        bad += 1
+        print("spill files left behind", os.listdir(tmp)[:4], flush=True)
+    if it % 50 == 0:
+        ctx.trim()              # cached scratch back to the system; the next iteration allocates again
     if use_file:
         for k in range(ns_slots):
             os.remove("%s%d.dat" % (base, k))
@@ -83,5 +90,6 @@ while time.time() - t0 < budget:
         print("iteration %d  bad=%d  maxrss %.0f MB  device free %.2f GiB (first reading %.2f)  %.0f s" %
               (it, bad, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024, free / 2**30, free0 / 2**30, time.time() - t0), flush=True)
 ctx.set_ingest(0, 0, 0)
+ctx.set_body_budget(4 << 30, None)
 print("pipeline soak done: %d iterations, mismatches: %d, %.0f s" % (it, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
