@@ -68,6 +68,9 @@ def spawn_ranks(n):
     are polled: the first one that exits non-zero ends the others (a dead rank would otherwise leave the rest waiting in
     the rendezvous until its timeout)."""
     import tempfile
+    # rendezvous through a file store in a private directory: no port is picked here that another process could take
+    # before the children bind it (MASTER_ADDR / MASTER_PORT stay set for anything that reads them)
+    rdv = os.path.join(tempfile.mkdtemp(prefix="cp2_bench_rdv_"), "store")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -76,7 +79,7 @@ def spawn_ranks(n):
     out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_INIT_TIMEOUT_S="120")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_INIT_TIMEOUT_S="120", BENCH_INIT_FILE=rdv)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=out0 if r == 0 else subprocess.DEVNULL))
     rc = 0
@@ -95,6 +98,8 @@ def spawn_ranks(n):
             p.wait(timeout=20)
         except subprocess.TimeoutExpired:
             p.kill()
+    import shutil
+    shutil.rmtree(os.path.dirname(rdv), ignore_errors=True)
     out0.seek(0)
     sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
@@ -172,6 +177,8 @@ def main():
         kw = {}
         if os.environ.get("BENCH_INIT_TIMEOUT_S"):                   # self-spawned ranks: a short rendezvous timeout
             kw["timeout"] = datetime.timedelta(seconds=int(os.environ["BENCH_INIT_TIMEOUT_S"]))
+        if os.environ.get("BENCH_INIT_FILE"):                        # self-spawned ranks: file store instead of a TCP port
+            kw.update(init_method="file://" + os.environ["BENCH_INIT_FILE"], rank=rank, world_size=world)
         with _stdout_to_stderr():
             if backend == "nccl":
                 try:
@@ -488,6 +495,7 @@ def ingest_leg(torch, ctx, pkg, dev):
         cells.tofile(path_base + "0.dat")
         cfg = pkg.make_config(maxDepth=32, maxLog2NSlots=1, cellSize=cs, blockSize=bs, nSlots=1, nCells=nc, nSamples=5, file=path_base)
         ingest_table(ctx, pkg, np, cells, cfg, cs, bs, nc, nbytes, want, table)
+        cold = cold_file_rates(ctx, np, path_base + "0.dat", cfg, nbytes, want)
     finally:                      # whatever happened: the 4 GiB file goes, the context's ingestion knobs go back to their defaults
         shutil.rmtree(tmpdir, ignore_errors=True)
         ctx.set_ingest(0, 0, 0)
@@ -498,7 +506,30 @@ def ingest_leg(torch, ctx, pkg, dev):
                        "pinned_h2d_peak_GBps": round(best, 2), "hash_from_hbm_GBps": round(kernel_gbps, 2), "by_fill_threads": table,
                        "best_host_pointer_GBps": bh, "best_page_cache_file_GBps": bf,
                        "host_pointer_frac_of_h2d_peak": round(bh / best, 3), "file_frac_of_h2d_peak": round(bf / best, 3),
-                       "host_pointer_frac_of_kernel_rate": round(bh / kernel_gbps, 3)}}
+                       "host_pointer_frac_of_kernel_rate": round(bh / kernel_gbps, 3), "cold_file": cold}}
+
+
+def cold_file_rates(ctx, np, path, cfg, nbytes, want):
+    """The same slot file when it is NOT in the page cache (fsync + POSIX_FADV_DONTNEED evicts it; no root needed): what the
+    box's storage delivers through buffered reads and through O_DIRECT reads straight into the pinned ring."""
+    out = {"note": "file evicted from the page cache before each build (fsync + posix_fadvise DONTNEED); storage-bound, box dependent"}
+    try:
+        for direct, name in ((0, "buffered_GBps"), (1, "o_direct_GBps")):
+            fd = os.open(path, os.O_RDONLY)
+            os.fsync(fd)
+            os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+            os.close(fd)
+            ctx.set_ingest_direct(direct)
+            t = time.perf_counter()
+            ds = ctx.dataset(cfg)
+            dt = time.perf_counter() - t
+            ok = bool(np.array_equal(ds.local_roots()[0], want))
+            ds.free()
+            out[name] = round(nbytes / dt / 1e9, 2)
+            out[name.replace("_GBps", "_root_ok")] = ok
+    finally:
+        ctx.set_ingest_direct(-1)
+    return out
 
 
 def ingest_table(ctx, pkg, np, cells, cfg, cs, bs, nc, nbytes, want, table):

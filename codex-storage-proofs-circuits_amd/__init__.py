@@ -85,6 +85,7 @@ def load_library():
         "cp2_last_error": (cp, [vp]),
         "cp2_device_is_native": (i32, [vp]),
         "cp2_set_ingest": (i32, [vp, i32, i32, sz]),
+        "cp2_set_ingest_direct": (i32, [vp, i32]),
         "cp2_trim": (i32, [vp]),
         "cp2_set_body_budget": (i32, [vp, sz, cp]),
         "cp2_permute_batch": (i32, [vp, vp, vp, sz]),
@@ -227,6 +228,10 @@ class Context:
 
     def set_ingest(self, fill_threads=0, ring_depth=0, chunk_bytes=0):
         self._ck(self.L.cp2_set_ingest(self.h, fill_threads, ring_depth, chunk_bytes), "cp2_set_ingest")
+
+    def set_ingest_direct(self, on):
+        """O_DIRECT reads of slot files (1 / 0; -1 = environment CP2_INGEST_DIRECT)."""
+        self._ck(self.L.cp2_set_ingest_direct(self.h, on), "cp2_set_ingest_direct")
 
     def trim(self):
         """Give the context's cached device / pinned scratch back to the system (cp2_trim)."""

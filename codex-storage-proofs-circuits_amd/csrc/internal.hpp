@@ -104,6 +104,7 @@ struct cp2_ctx {
   size_t stage_bytes = (size_t)1 << 31;   // device staging chunk of the fake-data builder
   int ingest_threads = 0, ingest_ring = 0;   // 0: CP2_INGEST_* environment or the built-in default (cp2_set_ingest)
   size_t ingest_chunk = 0;
+  int ingest_direct = -1;                    // SlotFile reads with O_DIRECT: 1 on, 0 off, -1 = environment CP2_INGEST_DIRECT (cp2_set_ingest_direct)
   size_t body_budget = 0;                    // streamed proof-input bodies kept in host memory; 0: CP2_BODY_BUDGET_MB or 4 GiB (cp2_set_body_budget)
   std::string spill_dir;                     // where bodies beyond the budget go; empty: $TMPDIR or /tmp
   std::string err;

@@ -290,6 +290,8 @@ size_t env_size(const char* name, size_t dflt) {
 
 struct IngestPipe {
   static constexpr int MAX_DEPTH = 8;
+  static constexpr size_t DIRECT_ALIGN = 4096;   // offset, length and address granule of O_DIRECT reads
+  size_t cell_multiple = 1;                      // chunk sizes are multiples of this many cells (direct reads: whole 4 KiB blocks)
   cp2_ctx* ctx = nullptr;
   hipStream_t copy = nullptr;
   int depth = 0;
@@ -326,7 +328,7 @@ struct IngestPipe {
     hash_stream[0] = ctx->stream;
     CP2_TRY(aux_stream(ctx, &hash_stream[1]));
     for (int b = 0; b < want_depth; ++b) {
-      CP2_TRY(pinned[b].alloc(ctx, chunk * cell_size));
+      CP2_TRY(pinned[b].alloc(ctx, chunk * cell_size + DIRECT_ALIGN));   // slack: an O_DIRECT read is rounded up to whole blocks
       CP2_TRY(dev[b].scratch(ctx, chunk * cell_size));
       CP2_HIP(ctx, hipEventCreateWithFlags(&copied[b], hipEventDisableTiming));
       CP2_HIP(ctx, hipEventCreateWithFlags(&hashed[b], hipEventDisableTiming));
@@ -336,12 +338,14 @@ struct IngestPipe {
     if (threads > 1) pool.reset(new Workers(threads - 1));
     return CP2_OK;
   }
-  // f(a, b) over [0, n) split across the fill threads (the calling thread takes the first range)
-  template <typename F> void parallel_ranges(size_t n, size_t grain, F f) {
+  // f(a, b) over [0, n) split across the fill threads (the calling thread takes the first range); inner boundaries are
+  // multiples of `align` (O_DIRECT reads need block-aligned offsets)
+  template <typename F> void parallel_ranges(size_t n, size_t grain, F f, size_t align = 1) {
     int nt = (int)std::min<size_t>((size_t)threads, std::max<size_t>(1, n / grain));
     if (nt <= 1 || !pool) { f(0, n); return; }
-    for (int t = 1; t < nt; ++t) pool->submit([=] { f(n * t / nt, n * (t + 1) / nt); });
-    f(0, n / nt);
+    auto cut = [=](int t) { return t >= nt ? n : n * t / nt / align * align; };
+    for (int t = 1; t < nt; ++t) pool->submit([=] { f(cut(t), cut(t + 1)); });
+    f(0, cut(1));
     pool->wait_idle();
   }
   // cells of the next chunk: a quarter, a half, three quarters of the ring slot, then whole slots.  The GPU starts hashing
@@ -349,6 +353,7 @@ struct IngestPipe {
   // kernel (43 GB/s, never under 3.75 ms) has finished, so the start-up bubble stays under a millisecond.
   size_t next_cells(size_t remaining) const {
     size_t m = turn < 3 ? std::max<size_t>(chunk * (turn + 1) / 4, std::min<size_t>(chunk, 32768)) : chunk;
+    if (m > cell_multiple) m -= m % cell_multiple;
     return std::min(m, remaining);
   }
   // the pinned buffer the host may fill next (blocks until the kernel that last used this ring slot is done)
@@ -438,28 +443,49 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
     st = pipe.init(ctx, cell_size, n_cells);
     LayerScheduler sched{t.get(), group, done};
     if (st == CP2_OK) st = sched.init();
+    // O_DIRECT (cp2_set_ingest_direct / CP2_INGEST_DIRECT=1): slot files that are not in the page cache are read straight into
+    // the pinned ring, block-aligned, without passing through (and evicting) the page cache.  Chunks then start on 4 KiB file
+    // offsets (a whole number of `cell_multiple` cells); a file system that refuses O_DIRECT (tmpfs) is read buffered.
+    const bool want_direct = ctx->ingest_direct > 0 || (ctx->ingest_direct < 0 && env_size("CP2_INGEST_DIRECT", 0) != 0);
+    if (want_direct) {
+      size_t g = cell_size, h = IngestPipe::DIRECT_ALIGN;
+      while (h) { size_t r = g % h; g = h; h = r; }               // gcd(cell_size, 4096)
+      pipe.cell_multiple = IngestPipe::DIRECT_ALIGN / g;
+    }
     for (size_t s = 0; st == CP2_OK && s < n_slots; ++s) {
       std::string fname = slot_file_name(base, first_slot + s);
       int fd = open(fname.c_str(), O_RDONLY);
       if (fd < 0) { ctx->err = "cannot open " + fname; st = CP2_ERR_IO; break; }
+      const int dfd = want_direct ? open(fname.c_str(), O_RDONLY | O_DIRECT) : -1;
       for (size_t c0 = 0, m = 0; st == CP2_OK && c0 < n_cells; c0 += m) {
         m = pipe.next_cells(n_cells - c0);
         uint8_t* buf = nullptr;
         st = pipe.acquire(&buf);
         if (st != CP2_OK) break;
         const size_t off = c0 * cell_size;
+        const bool direct = dfd >= 0 && off % IngestPipe::DIRECT_ALIGN == 0;
         // bytes [off, off+n) of the file into the pinned buffer, zero-filled past EOF (slot.nim:61-66)
         pipe.parallel_ranges(m * cell_size, (size_t)2 << 20, [=](size_t a, size_t b) {
           size_t pos = a;
+          if (direct) {          // a is block aligned; the last request is rounded up into the buffer's slack
+            while (pos < b) {
+              const size_t want = (b - pos + IngestPipe::DIRECT_ALIGN - 1) / IngestPipe::DIRECT_ALIGN * IngestPipe::DIRECT_ALIGN;
+              ssize_t r = pread(dfd, buf + pos, want, (off_t)(off + pos));
+              if (r <= 0) break;
+              pos += std::min<size_t>((size_t)r, b - pos);
+              if ((size_t)r % IngestPipe::DIRECT_ALIGN) break;   // short, unaligned: end of file (or the buffered path finishes it)
+            }
+          }
           while (pos < b) {
             ssize_t r = pread(fd, buf + pos, b - pos, (off_t)(off + pos));
             if (r <= 0) break;
             pos += (size_t)r;
           }
           if (pos < b) std::memset(buf + pos, 0, b - pos);
-        });
+        }, direct ? IngestPipe::DIRECT_ALIGN : 1);
         st = pipe.submit(m, cell_size, t->nodes.u8() + (s * n_cells + c0) * 32);
       }
+      if (dfd >= 0) close(dfd);
       close(fd);
       if (st == CP2_OK) st = pipe.finish();   // the context's stream now follows everything hashed on the second one
       if (st == CP2_OK) st = sched.hashed_on(0);
@@ -471,6 +497,14 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
   if (st != CP2_OK) return st;
   *out = t.release();
   return CP2_OK;
+}
+
+extern "C" int cp2_set_ingest_direct(cp2_ctx* ctx, int on) try {
+  if (!ctx) return CP2_ERR_INVALID;
+  ctx->ingest_direct = on < 0 ? -1 : (on ? 1 : 0);
+  return CP2_OK;
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 extern "C" int cp2_set_ingest(cp2_ctx* ctx, int fill_threads, int ring_depth, size_t chunk_bytes) try {

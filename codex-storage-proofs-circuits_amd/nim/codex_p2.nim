@@ -30,6 +30,7 @@ proc cp2_free(ctx: Cp2Ctx) {.importc.}
 proc cp2_strerror(status: cint): cstring {.importc.}
 proc cp2_last_error(ctx: Cp2Ctx): cstring {.importc.}
 proc cp2_trim(ctx: Cp2Ctx): cint {.importc.}
+proc cp2_set_ingest_direct(ctx: Cp2Ctx, on: cint): cint {.importc.}
 proc cp2_set_body_budget(ctx: Cp2Ctx, maxResidentBytes: csize_t, spillDir: cstring): cint {.importc.}
 proc cp2_permute_batch(ctx: Cp2Ctx, inp, outp: ptr byte, n: csize_t): cint {.importc.}
 proc cp2_compress_batch(ctx: Cp2Ctx, xy: ptr byte, key: uint32, outp: ptr byte, n: csize_t): cint {.importc.}
@@ -257,6 +258,10 @@ proc engineExportAllProofInputs*(cfg: var Cp2Config, entropy: F, dir: string, th
 proc engineTrim*() =
   ## give the engine's cached device / pinned scratch back to the system (a long-lived process between runs)
   check(cp2_trim(ctx()), "cp2_trim")
+
+proc engineSetIngestDirect*(on: bool) =
+  ## SlotFile source: O_DIRECT reads of slot files that are not in the page cache
+  check(cp2_set_ingest_direct(ctx(), cint(ord(on))), "cp2_set_ingest_direct")
 
 proc engineSetBodyBudget*(maxResidentBytes: int, spillDir: string = "") =
   check(cp2_set_body_budget(ctx(), csize_t(maxResidentBytes), (if spillDir.len > 0: cstring(spillDir) else: nil)), "cp2_set_body_budget")

@@ -61,6 +61,11 @@ int cp2_device_is_native(const cp2_ctx* ctx);
  * (environment CP2_INGEST_THREADS / CP2_INGEST_RING / CP2_INGEST_CHUNK_MB, else 8 threads, depth 3 and one full
  * residency of the hash kernel per chunk: 768 x 256 cells, 384 MiB at 2 KiB cells). */
 int cp2_set_ingest(cp2_ctx* ctx, int fill_threads, int ring_depth, size_t chunk_bytes);
+/* SlotFile source: read the slot files with O_DIRECT (block-aligned requests straight into the pinned ring, no page-cache copy
+ * and no eviction of what the cache holds): for files that are NOT cached -- a cached file reads faster through the cache.
+ * on = 1 / 0; -1 = the environment variable CP2_INGEST_DIRECT (default off).  A file system that refuses O_DIRECT is read
+ * buffered; results are identical either way. */
+int cp2_set_ingest_direct(cp2_ctx* ctx, int on);
 /* Memory a long-lived context holds.  Scratch blocks (device staging, pinned landing zones) are cached per context so that
  * repeated calls stop allocating: up to 6 GiB of device memory and 3 GiB of PINNED host memory stay with the context after
  * the calls that needed them.  cp2_trim waits for the context's streams and gives all cached blocks back to the system

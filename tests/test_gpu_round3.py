@@ -84,3 +84,58 @@ def test_sampling_rejects_a_single_cell_like_the_reference(pkg, ctx):
         ctx.dataset_streamed(cfg, 1, threads=1)
     cfg0 = pkg.make_config(maxDepth=4, maxLog2NSlots=1, cellSize=64, blockSize=64, nSlots=2, nCells=1, nSamples=0, seed=3)
     assert '"cellData"' in ctx.dataset(cfg0).proof_input(1, 1).json()   # no samples, no cellIndex call: allowed
+
+
+@pytest.mark.parametrize("cell_size,n_cells,cpb", [(2048, 4096, 32), (100, 2048, 8), (31, 4096, 1)])
+def test_slot_files_through_o_direct_give_identical_trees(pkg, ctx, oracle, tmp_path, cell_size, n_cells, cpb):
+    """cp2_set_ingest_direct: block-aligned O_DIRECT reads into the pinned ring (chunks of a whole number of 4 KiB blocks, the
+    last request rounded up into the buffer's slack, a short / odd-length file finished through the buffered descriptor and
+    zero-filled) against the buffered path and the oracle.  Where the file system refuses O_DIRECT the call falls back to
+    buffered reads, so this passes on tmpfs as well."""
+    C, P = oracle
+    c = dict(maxDepth=16, maxLog2NSlots=2, cellSize=cell_size, blockSize=cell_size * cpb, nSlots=3, nCells=n_cells, nSamples=5)
+    base = str(tmp_path / "d")
+    for k in range(3):
+        data = C.gen_fake_cells(C.slot_seed(99, k), 0, n_cells, cell_size).tobytes()
+        if k == 1:
+            data = data[:len(data) // 2 + 1234]                    # short file of odd length: the tail reads as zeros
+        open("%s%d.dat" % (base, k), "wb").write(data)
+    cfg = pkg.make_config(file=base, **c)
+    got = {}
+    try:
+        for direct in (0, 1):
+            ctx.set_ingest_direct(direct)
+            for chunk in (0, 3 * 4096 * 5):                         # default chunking, and many small chunks per slot
+                ctx.set_ingest(3, 3, chunk)
+                ds = ctx.dataset(cfg)
+                got[(direct, chunk)] = (ds.local_roots().copy(), ds.proof_input(1, 77).json())
+                ds.free()
+    finally:
+        ctx.set_ingest_direct(-1)
+        ctx.set_ingest(0, 0, 0)
+    ref_roots, ref_json = got[(0, 0)]
+    for k in (0, 2):
+        assert np.array_equal(ref_roots[k], C.fake_slot_root(C.slot_seed(99, k), cell_size, cell_size * cpb, n_cells, 4))
+    # the short slot, by the oracle: its cells with the missing tail as zeros -> cell hashes -> block trees -> slot tree
+    raw = np.frombuffer(open(base + "1.dat", "rb").read(), dtype=np.uint8)
+    cells = np.zeros(n_cells * cell_size, dtype=np.uint8)
+    cells[:raw.size] = raw
+    leaves = C.hash_cells(cells.reshape(n_cells, cell_size), cell_size, threads=8)
+    block_roots = np.stack([C.merkle_root(leaves[b * cpb:(b + 1) * cpb]) for b in range(n_cells // cpb)])
+    assert np.array_equal(ref_roots[1], C.merkle_root(block_roots))
+    # its proof input: the sampled cells are the file's bytes (zeros past the end), every path re-derives the slot root
+    pi = ctx.dataset(cfg).proof_input(1, 77)
+    idx, cd, paths = pi.cell_indices(), pi.cell_data(), pi.merkle_paths()
+    root = pkg.array_to_felts(ref_roots[1:2])[0]
+    nb = n_cells // cpb
+    db, dt = (cpb - 1).bit_length() if cpb > 1 else 1, (nb - 1).bit_length() if nb > 1 else 1
+    for k in range(5):
+        ci = int(idx[k])
+        assert np.array_equal(cd[k], cells[ci * cell_size:(ci + 1) * cell_size])
+        leaf = C.array_to_felts(C.hash_bytes(cd[k]))[0]
+        path = pkg.array_to_felts(paths[k])
+        bot = P.reconstruct_root({"numberOfLeaves": cpb, "leafIndex": ci % cpb, "leafValue": leaf, "merklePath": path[:db]})
+        top = P.reconstruct_root({"numberOfLeaves": nb, "leafIndex": ci // cpb, "leafValue": bot, "merklePath": path[db:db + dt]})
+        assert top == root
+    for key, (roots, text) in got.items():
+        assert np.array_equal(roots, ref_roots) and text == ref_json, key
