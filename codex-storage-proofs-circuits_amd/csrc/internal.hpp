@@ -162,6 +162,7 @@ struct DevBuf {
       e = hipMalloc(&p, n);
     }
     if (e != hipSuccess) {
+      (void)hipGetLastError();   // reported here; must not resurface from a later hipGetLastError()
       p = nullptr;
       ctx->err = std::string("hipMalloc(") + std::to_string(n) + "): " + hipGetErrorString(e);
       return CP2_ERR_ALLOC;

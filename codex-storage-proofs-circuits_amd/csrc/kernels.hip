@@ -417,6 +417,9 @@ __global__ void __launch_bounds__(TPB) k_gather_rows(const uint8_t* __restrict__
 // Workgroups for n work items.  A grid holds at most 2^31 - 1 workgroups in x; the per-item kernels are launched in slices of
 // at most MAX_ITEMS items (every item is independent and addressed from a base pointer), the layer / sampling kernels, whose
 // item index is decomposed inside the kernel, refuse what does not fit one grid (2^38 nodes: far beyond any HBM).
+// hipGetLastError() returns (and clears) the last error of ANY earlier runtime call of this thread, e.g. a hipMalloc that failed
+// and was already reported to the caller: clear it before a launch so that the status read after the launch is the launch's own.
+#define CP2K_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 constexpr size_t MAX_BLOCKS = (size_t)1 << 30;
 constexpr size_t MAX_ITEMS = MAX_BLOCKS * TPB;
 static inline bool fits_one_grid(size_t n) { return (n + TPB - 1) / TPB <= MAX_BLOCKS; }
@@ -425,7 +428,7 @@ static inline unsigned grid_for(size_t n) { return (unsigned)((n + TPB - 1) / TP
 hipError_t launch_permute_batch(const void* in, void* out, size_t n, hipStream_t st) {
   for (size_t i0 = 0; i0 < n; i0 += MAX_ITEMS) {
     const size_t m = n - i0 < MAX_ITEMS ? n - i0 : MAX_ITEMS;
-    hipLaunchKernelGGL(k_permute_batch, dim3(grid_for(m)), dim3(TPB), 0, st, (const uint4*)in + 6 * i0, (uint4*)out + 6 * i0, m);
+    CP2K_LAUNCH(k_permute_batch, dim3(grid_for(m)), dim3(TPB), 0, st, (const uint4*)in + 6 * i0, (uint4*)out + 6 * i0, m);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -437,7 +440,7 @@ hipError_t launch_compress_layer(const void* in, void* out, size_t m_in, size_t 
   size_t m_out = (m_in + 1) / 2;
   if (m_out * nseg == 0) return hipSuccess;
   if (!fits_one_grid(m_out * nseg)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_compress_layer, dim3(grid_for(m_out * nseg)), dim3(TPB), 0, st, (const uint4*)in, (uint4*)out,
+  CP2K_LAUNCH(k_compress_layer, dim3(grid_for(m_out * nseg)), dim3(TPB), 0, st, (const uint4*)in, (uint4*)out,
                      m_in, m_out, nseg, bottom ? 1u : 0u, in_seg_stride, out_seg_stride);
   return hipGetLastError();
 }
@@ -445,7 +448,7 @@ hipError_t launch_compress_layer(const void* in, void* out, size_t m_in, size_t 
 hipError_t launch_compress_pairs(const void* xy, uint32_t key, void* out, size_t n, hipStream_t st) {
   for (size_t i0 = 0; i0 < n; i0 += MAX_ITEMS) {
     const size_t m = n - i0 < MAX_ITEMS ? n - i0 : MAX_ITEMS;
-    hipLaunchKernelGGL(k_compress_pairs, dim3(grid_for(m)), dim3(TPB), 0, st, (const uint4*)xy + 4 * i0, key, (uint4*)out + 2 * i0, m);
+    CP2K_LAUNCH(k_compress_pairs, dim3(grid_for(m)), dim3(TPB), 0, st, (const uint4*)xy + 4 * i0, key, (uint4*)out + 2 * i0, m);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -455,7 +458,7 @@ hipError_t launch_compress_pairs(const void* xy, uint32_t key, void* out, size_t
 hipError_t launch_sponge2_felts(const void* felts, size_t nf, size_t nitems, void* out, hipStream_t st) {
   for (size_t i0 = 0; i0 < nitems; i0 += MAX_ITEMS) {
     const size_t m = nitems - i0 < MAX_ITEMS ? nitems - i0 : MAX_ITEMS;
-    hipLaunchKernelGGL(k_sponge2_felts, dim3(grid_for(m)), dim3(TPB), 0, st, (const uint4*)felts + 2 * nf * i0, nf, m, (uint4*)out + 2 * i0);
+    CP2K_LAUNCH(k_sponge2_felts, dim3(grid_for(m)), dim3(TPB), 0, st, (const uint4*)felts + 2 * nf * i0, nf, m, (uint4*)out + 2 * i0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -479,8 +482,8 @@ hipError_t launch_hash_cells_block(int block, const void* cells, size_t cell_siz
     const size_t m = n_cells - i0 < max_items ? n_cells - i0 : max_items;
     const unsigned grid = (unsigned)((m + block - 1) / block);
     const uint8_t* src = (const uint8_t*)cells + i0 * cell_size;
-    if (block == 64) hipLaunchKernelGGL(k_hash_cells<64>, dim3(grid), dim3(64), 0, st, src, cell_size, m, (uint4*)out + 2 * i0);
-    else hipLaunchKernelGGL(k_hash_cells<256>, dim3(grid), dim3(256), 0, st, src, cell_size, m, (uint4*)out + 2 * i0);
+    if (block == 64) CP2K_LAUNCH(k_hash_cells<64>, dim3(grid), dim3(64), 0, st, src, cell_size, m, (uint4*)out + 2 * i0);
+    else CP2K_LAUNCH(k_hash_cells<256>, dim3(grid), dim3(256), 0, st, src, cell_size, m, (uint4*)out + 2 * i0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -496,7 +499,7 @@ hipError_t launch_gen_fake_cells(uint64_t seed0, uint64_t cells_per_slot, uint64
                                  size_t n_cells, size_t cell_size, void* out, hipStream_t st) {
   if (n_cells == 0 || cell_size == 0) return hipSuccess;
   if (!fits_one_grid(n_cells)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_gen_fake_cells, dim3(grid_for(n_cells)), dim3(TPB), 0, st, seed0, cells_per_slot, first, list,
+  CP2K_LAUNCH(k_gen_fake_cells, dim3(grid_for(n_cells)), dim3(TPB), 0, st, seed0, cells_per_slot, first, list,
                      n_cells, cell_size, (uint8_t*)out);
   return hipGetLastError();
 }
@@ -506,7 +509,7 @@ hipError_t launch_sample_paths(const TreeGeom& g, const void* nodes, const void*
                                hipStream_t st) {
   if (n_items == 0 || ns == 0) return hipSuccess;
   if (!fits_one_grid(n_items * ns)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_sample_paths, dim3(grid_for(n_items * ns)), dim3(TPB), 0, st, g, (const uint4*)nodes, (const uint4*)d_entropy,
+  CP2K_LAUNCH(k_sample_paths, dim3(grid_for(n_items * ns)), dim3(TPB), 0, st, g, (const uint4*)nodes, (const uint4*)d_entropy,
                      slots, slot0, n_items, ns, md, indices, gcell, rows);
   return hipGetLastError();
 }
@@ -515,7 +518,7 @@ hipError_t launch_gather_rows(const void* src, const uint64_t* index, size_t nro
   if (nrows == 0) return hipSuccess;
   size_t work = nrows * (row_bytes / 4);
   unsigned grid = work > (size_t)4096 * TPB ? 4096u : grid_for(work);
-  hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(TPB), 0, st, (const uint8_t*)src, index, nrows, row_bytes, (uint8_t*)out);
+  CP2K_LAUNCH(k_gather_rows, dim3(grid), dim3(TPB), 0, st, (const uint8_t*)src, index, nrows, row_bytes, (uint8_t*)out);
   return hipGetLastError();
 }
 

@@ -139,3 +139,14 @@ def test_slot_files_through_o_direct_give_identical_trees(pkg, ctx, oracle, tmp_
         assert top == root
     for key, (roots, text) in got.items():
         assert np.array_equal(roots, ref_roots) and text == ref_json, key
+
+
+def test_device_allocation_failure_is_an_error_not_a_crash(pkg, ctx, oracle):
+    """A batch whose node buffer cannot fit the GPU (2^31 cells x 64 B of nodes = 128+ GiB twice over) comes back as
+    CP2_ERR_ALLOC with the size in the message; the context keeps working afterwards."""
+    C, _ = oracle
+    with pytest.raises(pkg.CodexP2Error) as e:
+        ctx.slot_trees_fake(1, 0, 1 << 13, 64, 64 * 32, 1 << 20)          # 2^33 cells: 512 GiB of nodes
+    assert e.value.status == -4 and "hipMalloc" in str(e.value)
+    cells = C.gen_fake_cells(5, 0, 64, 128)
+    assert np.array_equal(ctx.hash_cells(cells, 128), C.hash_cells(cells, 128, threads=2))
