@@ -150,3 +150,48 @@ def test_device_allocation_failure_is_an_error_not_a_crash(pkg, ctx, oracle):
     assert e.value.status == -4 and "hipMalloc" in str(e.value)
     cells = C.gen_fake_cells(5, 0, 64, 128)
     assert np.array_equal(ctx.hash_cells(cells, 128), C.hash_cells(cells, 128, threads=2))
+
+
+def test_independent_contexts_on_concurrent_host_threads(pkg, ctx, oracle):
+    """"One context per host thread; contexts are independent" (include/codex_p2.h): three threads, each with its own context,
+    run the streamed pipeline, the object path, host-array hashing and slot-tree paths at the same time on one GPU; every
+    result equals what the session's context computes alone."""
+    import threading
+    C, P = oracle
+    jobs = []
+    for k in range(3):
+        c = dict(maxDepth=14, maxLog2NSlots=4, cellSize=[2048, 256, 100][k], blockSize=[2048, 256, 100][k] * 8, nSlots=7 + k, nCells=256,
+                 nSamples=9, seed=1000 + k)
+        cfg = pkg.make_config(**c)
+        ref = ctx.dataset(cfg)
+        want = [ref.proof_input(s, 4242 + k).json() for s in range(c["nSlots"])]
+        cells = np.random.default_rng(k).integers(0, 256, size=(3000, c["cellSize"]), dtype=np.uint8)
+        jobs.append((c, want, cells, ctx.hash_cells(cells, c["cellSize"])))
+        ref.free()
+    errors = []
+
+    def work(k):
+        try:
+            c, want, cells, want_hashes = jobs[k]
+            mine = pkg.Context(0)
+            for rep in range(4):
+                cfg = pkg.make_config(**c)
+                sd = mine.dataset_streamed(cfg, 4242 + k, threads=2, group_slots=1 + rep % 3)
+                sd.export_streamed(None, threads=2)
+                got = [sd.streamed_json(s) for s in range(c["nSlots"])]
+                assert got == want, ("streamed", k, rep)
+                assert sd.proof_input(rep % c["nSlots"], 4242 + k).json() == want[rep % c["nSlots"]], ("object", k, rep)
+                sd.free()
+                assert np.array_equal(mine.hash_cells(cells, c["cellSize"]), want_hashes), ("hash", k, rep)
+            mine.close()
+        except BaseException as e:   # noqa: B902 -- reported by the main thread
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in threads)
+    assert want and P.export_json(expected_proof_input_fast(C, P, jobs[2][0], 0, 4244, threads=4)) == jobs[2][1][0]
