@@ -12,9 +12,12 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -535,22 +538,70 @@ struct TreeFileHeader {
   uint64_t node_checksum;
 };
 
-// 64-bit multiply-mix over 8-byte words (not cryptographic: detects truncation and bit rot, not an adversary)
-uint64_t checksum64(const uint8_t* p, size_t n) {
+// 64-bit multiply-mix over 8-byte words (not cryptographic: detects truncation and bit rot, not an adversary), fed chunk by
+// chunk while the nodes stream between the device and the file.  Every chunk but the last must be a multiple of 32 bytes.
+struct Checksum64 {
   uint64_t h[4] = {0x9e3779b97f4a7c15ULL, 0xc2b2ae3d27d4eb4fULL, 0x165667b19e3779f9ULL, 0x27d4eb2f165667c5ULL};
-  size_t i = 0;
-  for (; i + 32 <= n; i += 32) {
-    uint64_t w[4];
-    std::memcpy(w, p + i, 32);
-    for (int k = 0; k < 4; ++k) {
-      h[k] = (h[k] ^ w[k]) * 0x100000001b3ULL;
-      h[k] = (h[k] << 29) | (h[k] >> 35);
+  uint64_t total = 0;
+  uint64_t tail = 0;
+  bool tailed = false;
+  void update(const uint8_t* p, size_t n) {
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+      uint64_t w[4];
+      std::memcpy(w, p + i, 32);
+      for (int k = 0; k < 4; ++k) {
+        h[k] = (h[k] ^ w[k]) * 0x100000001b3ULL;
+        h[k] = (h[k] << 29) | (h[k] >> 35);
+      }
+    }
+    total += n;
+    if (i < n) {                 // only ever the last chunk
+      tailed = true;
+      tail = h[0] ^ (h[1] * 3) ^ (h[2] * 5) ^ (h[3] * 7) ^ total;
+      for (; i < n; ++i) tail = (tail ^ p[i]) * 0x100000001b3ULL;
     }
   }
-  uint64_t r = h[0] ^ (h[1] * 3) ^ (h[2] * 5) ^ (h[3] * 7) ^ (uint64_t)n;
-  for (; i < n; ++i) r = (r ^ p[i]) * 0x100000001b3ULL;
-  r ^= r >> 33; r *= 0xff51afd7ed558ccdULL; r ^= r >> 33;
-  return r;
+  uint64_t finish() const {
+    uint64_t r = tailed ? tail : (h[0] ^ (h[1] * 3) ^ (h[2] * 5) ^ (h[3] * 7) ^ total);
+    r ^= r >> 33; r *= 0xff51afd7ed558ccdULL; r ^= r >> 33;
+    return r;
+  }
+};
+
+// ring-slot flags shared between the streaming thread and its I/O worker
+struct SlotFlags {
+  static constexpr int K = 3;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool flag[K] = {false, false, false};
+  bool failed = false;
+  void set(int r, bool v) { { std::lock_guard<std::mutex> lk(mu); flag[r] = v; } cv.notify_all(); }
+  void fail() { { std::lock_guard<std::mutex> lk(mu); failed = true; } cv.notify_all(); }
+  // waits until flag[r] == v; false if the worker reported a failure
+  bool wait(int r, bool v) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return failed || flag[r] == v; });
+    return !failed;
+  }
+};
+constexpr size_t CACHE_CHUNK = (size_t)64 << 20;
+
+bool pwrite_all(int fd, const uint8_t* p, size_t n, off_t off) {
+  while (n) {
+    ssize_t w = pwrite(fd, p, n, off);
+    if (w <= 0) return false;
+    p += w; n -= (size_t)w; off += w;
+  }
+  return true;
+}
+bool pread_all(int fd, uint8_t* p, size_t n, off_t off) {
+  while (n) {
+    ssize_t r = pread(fd, p, n, off);
+    if (r <= 0) return false;
+    p += r; n -= (size_t)r; off += r;
+  }
+  return true;
 }
 
 // (size, mtime in ns) of each slot file; a missing file stamps as (~0, ~0)
@@ -569,6 +620,8 @@ std::vector<uint64_t> file_stamps(const std::string& base, uint64_t first_slot, 
 }
 }  // namespace
 
+// The nodes stream device -> pinned ring -> file in 64 MiB chunks: the download of chunk i+1, the checksum of chunk i and the
+// write of chunk i-1 overlap, and no host copy of the whole node buffer exists (8 GiB for 32 768 slots of 2^12 cells).
 extern "C" int cp2_slot_trees_save(cp2_slot_trees* t, const char* path) try {
   if (!t || !path) return CP2_ERR_INVALID;
   cp2_ctx* ctx = t->ctx;
@@ -582,49 +635,101 @@ extern "C" int cp2_slot_trees_save(cp2_slot_trees* t, const char* path) try {
   if (t->src == CellSrc::File) stamps = file_stamps(t->file_base, t->first_slot, t->n_slots);
   h.n_stamps = stamps.size() / 2;
   h.n_nodes = t->nodes.bytes / 32;
-  std::vector<uint8_t> host(t->nodes.bytes);
-  CP2_HIP(ctx, hipMemcpyAsync(host.data(), t->nodes.p, host.size(), hipMemcpyDeviceToHost, ctx->stream));
-  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  h.node_checksum = checksum64(host.data(), host.size());
+  const size_t total = t->nodes.bytes;
   const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid());
-  FILE* f = std::fopen(tmp.c_str(), "wb");
-  if (!f) return CP2_ERR_IO;
-  bool ok = std::fwrite(&h, sizeof h, 1, f) == 1 &&
-            (h.file_base_len == 0 || std::fwrite(t->file_base.data(), 1, h.file_base_len, f) == h.file_base_len) &&
-            (stamps.empty() || std::fwrite(stamps.data(), 8, stamps.size(), f) == stamps.size()) &&
-            std::fwrite(host.data(), 1, host.size(), f) == host.size();
-  ok = (std::fclose(f) == 0) && ok;
-  if (ok) ok = std::rename(tmp.c_str(), path) == 0;
-  if (!ok) std::remove(tmp.c_str());
-  return ok ? CP2_OK : CP2_ERR_IO;
+  const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0) { ctx->err = "cannot create " + tmp; return CP2_ERR_IO; }
+  struct FdGuard { int fd; std::string tmp; bool keep = false; ~FdGuard() { if (fd >= 0) close(fd); if (!keep) std::remove(tmp.c_str()); } } guard{fd, tmp};
+  const off_t data_off = (off_t)(sizeof h + h.file_base_len + stamps.size() * 8);
+  bool ok = (h.file_base_len == 0 || pwrite_all(fd, reinterpret_cast<const uint8_t*>(t->file_base.data()), h.file_base_len, sizeof h)) &&
+            (stamps.empty() || pwrite_all(fd, reinterpret_cast<const uint8_t*>(stamps.data()), stamps.size() * 8, (off_t)(sizeof h + h.file_base_len)));
+  if (!ok) return CP2_ERR_IO;
+  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));                  // the trees are complete
+  if (ctx->aux_stream) CP2_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
+  Checksum64 sum;
+  {
+    constexpr int K = SlotFlags::K;
+    PinBuf pin[K];
+    hipEvent_t ev[K] = {};
+    struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int i = 0; i < K; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } ev_guard{ev};
+    const size_t chunk = std::min(CACHE_CHUNK, std::max<size_t>(total, 32));
+    for (int r = 0; r < K; ++r) {
+      CP2_TRY(pin[r].alloc(ctx, chunk));
+      CP2_HIP(ctx, hipEventCreateWithFlags(&ev[r], hipEventDisableTiming));
+    }
+    SlotFlags busy;                                                 // flag[r]: the writer still reads pin[r]
+    const size_t n_chunks = (total + chunk - 1) / chunk;
+    int st = CP2_OK;
+    {
+      Workers writer(1);                                            // joins before the pinned blocks go back to the pool
+      auto finish_chunk = [&](size_t c) -> int {                    // landed -> checksum -> hand to the writer
+        const int r = (int)(c % K);
+        const size_t m = std::min(chunk, total - c * chunk);
+        CP2_HIP(ctx, hipEventSynchronize(ev[r]));
+        sum.update(pin[r].u8(), m);
+        busy.set(r, true);
+        const uint8_t* src = pin[r].u8();
+        const off_t off = data_off + (off_t)(c * chunk);
+        writer.submit([&busy, r, fd, src, m, off] {
+          if (pwrite_all(fd, src, m, off)) busy.set(r, false);
+          else busy.fail();
+        });
+        return CP2_OK;
+      };
+      for (size_t c = 0; c < n_chunks && st == CP2_OK; ++c) {
+        const int r = (int)(c % K);
+        const size_t m = std::min(chunk, total - c * chunk);
+        if (!busy.wait(r, false)) { st = CP2_ERR_IO; break; }       // chunk c - K has left pin[r]
+        hipError_t e = hipMemcpyAsync(pin[r].p, t->nodes.u8() + c * chunk, m, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(ev[r], ctx->stream);
+        if (e != hipSuccess) { ctx->err = std::string("cache download: ") + hipGetErrorString(e); st = CP2_ERR_HIP; break; }
+        if (c > 0) st = finish_chunk(c - 1);                        // overlaps the download just enqueued
+      }
+      if (st == CP2_OK && n_chunks) st = finish_chunk(n_chunks - 1);
+      writer.wait_idle();
+      (void)hipStreamSynchronize(ctx->stream);
+      if (st == CP2_OK && busy.failed) st = CP2_ERR_IO;
+    }
+    if (st != CP2_OK) return st;
+  }
+  h.node_checksum = sum.finish();
+  if (!pwrite_all(fd, reinterpret_cast<const uint8_t*>(&h), sizeof h, 0)) return CP2_ERR_IO;
+  if (close(fd) != 0) { guard.fd = -1; return CP2_ERR_IO; }
+  guard.fd = -1;
+  if (std::rename(tmp.c_str(), path) != 0) return CP2_ERR_IO;
+  guard.keep = true;
+  return CP2_OK;
 } catch (const std::bad_alloc&) {
   return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
 } catch (...) {
   return CP2_ERR_INVALID;
 }
 
+// file -> pinned ring -> device in 64 MiB chunks: the read of chunk i+1, the checksum of chunk i and the upload of chunk i-1
+// overlap.  The nodes reach the device before the checksum is known; a mismatch discards them.
 extern "C" int cp2_slot_trees_load(cp2_ctx* ctx, const char* path, cp2_slot_trees** out) try {
   if (!ctx || !path || !out) return CP2_ERR_INVALID;
   *out = nullptr;
-  FILE* f = std::fopen(path, "rb");
-  if (!f) return CP2_ERR_IO;
-  struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{f};
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) return CP2_ERR_IO;
+  struct Closer { int fd; ~Closer() { close(fd); } } closer{fd};
   TreeFileHeader h{};
   // every header field is bounded before anything is sized from it
-  if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, "CP2TREE2", 8) != 0 || h.file_base_len > 4096 ||
+  if (!pread_all(fd, reinterpret_cast<uint8_t*>(&h), sizeof h, 0) || std::memcmp(h.magic, "CP2TREE2", 8) != 0 || h.file_base_len > 4096 ||
       trees_check_geometry(h.cell_size, h.block_size, h.n_cells, h.n_slots) != CP2_OK || h.src > (uint64_t)CellSrc::File ||
       (h.n_stamps != 0 && h.n_stamps != h.n_slots) || (h.src == (uint64_t)CellSrc::File) != (h.n_stamps != 0)) {
     ctx->err = std::string("not a slot-tree cache of this version: ") + path;
     return CP2_ERR_IO;
   }
   std::string base(h.file_base_len, '\0');
-  if (h.file_base_len && std::fread(&base[0], 1, h.file_base_len, f) != h.file_base_len) return CP2_ERR_IO;
+  if (h.file_base_len && !pread_all(fd, reinterpret_cast<uint8_t*>(&base[0]), h.file_base_len, sizeof h)) return CP2_ERR_IO;
   std::vector<uint64_t> stamps(2 * h.n_stamps);
-  if (!stamps.empty() && std::fread(stamps.data(), 8, stamps.size(), f) != stamps.size()) return CP2_ERR_IO;
+  if (!stamps.empty() && !pread_all(fd, reinterpret_cast<uint8_t*>(stamps.data()), stamps.size() * 8, (off_t)(sizeof h + h.file_base_len))) return CP2_ERR_IO;
   if (h.src == (uint64_t)CellSrc::File && stamps != file_stamps(base, h.first_slot, h.n_slots)) {
     ctx->err = std::string("slot files changed since the cache was written: ") + path;
     return CP2_ERR_IO;   // size or mtime of a slot file differs: the trees no longer describe the data
   }
+  const off_t data_off = (off_t)(sizeof h + h.file_base_len + stamps.size() * 8);
   if (hipSetDevice(ctx->device) != hipSuccess) return CP2_ERR_HIP;
   std::unique_ptr<cp2_slot_trees> t(trees_new(ctx, h.n_slots, h.cell_size, h.block_size, h.n_cells));
   if (!t) return CP2_ERR_ALLOC;
@@ -634,14 +739,65 @@ extern "C" int cp2_slot_trees_load(cp2_ctx* ctx, const char* path, cp2_slot_tree
   t->file_base = base;
   CP2_TRY(trees_layout(t.get()));
   if (t->nodes.bytes / 32 != h.n_nodes) return CP2_ERR_IO;
-  std::vector<uint8_t> host(t->nodes.bytes);
-  if (std::fread(host.data(), 1, host.size(), f) != host.size()) return CP2_ERR_IO;
-  if (checksum64(host.data(), host.size()) != h.node_checksum) {
+  {
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || (uint64_t)sb.st_size != (uint64_t)data_off + t->nodes.bytes) {
+      ctx->err = std::string("slot-tree cache is truncated: ") + path;
+      return CP2_ERR_IO;
+    }
+  }
+  const size_t total = t->nodes.bytes;
+  Checksum64 sum;
+  {
+    constexpr int K = SlotFlags::K;
+    PinBuf pin[K];
+    hipEvent_t ev[K] = {};
+    struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int i = 0; i < K; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } ev_guard{ev};
+    const size_t chunk = std::min(CACHE_CHUNK, std::max<size_t>(total, 32));
+    for (int r = 0; r < K; ++r) {
+      CP2_TRY(pin[r].alloc(ctx, chunk));
+      CP2_HIP(ctx, hipEventCreateWithFlags(&ev[r], hipEventDisableTiming));
+      CP2_HIP(ctx, hipEventRecord(ev[r], ctx->stream));
+    }
+    SlotFlags ready;                                                // flag[r]: pin[r] holds the chunk the main thread waits for
+    const size_t n_chunks = (total + chunk - 1) / chunk;
+    int st = CP2_OK;
+    {
+      Workers reader(1);
+      size_t submitted = 0;
+      auto submit_read = [&](size_t c) -> int {                     // pin[c % K] is free once the upload of chunk c - K has finished
+        const int r = (int)(c % K);
+        CP2_HIP(ctx, hipEventSynchronize(ev[r]));
+        uint8_t* dst = pin[r].u8();
+        const size_t m = std::min(chunk, total - c * chunk);
+        const off_t off = data_off + (off_t)(c * chunk);
+        reader.submit([&ready, r, fd, dst, m, off] {
+          if (pread_all(fd, dst, m, off)) ready.set(r, true);
+          else ready.fail();
+        });
+        return CP2_OK;
+      };
+      for (size_t c = 0; c < n_chunks && st == CP2_OK; ++c) {
+        while (st == CP2_OK && submitted < n_chunks && submitted < c + K) st = submit_read(submitted++);
+        if (st != CP2_OK) break;
+        const int r = (int)(c % K);
+        const size_t m = std::min(chunk, total - c * chunk);
+        if (!ready.wait(r, true)) { st = CP2_ERR_IO; break; }
+        ready.set(r, false);
+        sum.update(pin[r].u8(), m);
+        hipError_t e = hipMemcpyAsync(t->nodes.u8() + c * chunk, pin[r].p, m, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(ev[r], ctx->stream);
+        if (e != hipSuccess) { ctx->err = std::string("cache upload: ") + hipGetErrorString(e); st = CP2_ERR_HIP; }
+      }
+      reader.wait_idle();
+      if (hipStreamSynchronize(ctx->stream) != hipSuccess && st == CP2_OK) st = CP2_ERR_HIP;
+    }
+    if (st != CP2_OK) return st;
+  }
+  if (sum.finish() != h.node_checksum) {
     ctx->err = std::string("slot-tree cache is corrupt (checksum): ") + path;
     return CP2_ERR_IO;
   }
-  CP2_HIP(ctx, hipMemcpyAsync(t->nodes.p, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream));
-  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *out = t.release();
   return CP2_OK;
 } catch (const std::bad_alloc&) {

@@ -195,3 +195,47 @@ def test_independent_contexts_on_concurrent_host_threads(pkg, ctx, oracle):
     assert not errors, errors
     assert not any(t.is_alive() for t in threads)
     assert want and P.export_json(expected_proof_input_fast(C, P, jobs[2][0], 0, 4244, threads=4)) == jobs[2][1][0]
+
+
+def test_tree_cache_streams_large_node_buffers(pkg, ctx, golden, tmp_path):
+    """cp2_slot_trees_save / _load as pipelines over a 3-deep pinned ring of 64 MiB chunks: 1 GiB of nodes (4096 slots x 2^12
+    cells: sixteen chunks, five times around the ring) round-trips to the same roots (the oracle fixture's) and paths; one
+    flipped byte in a middle chunk, a missing tail, or bytes appended to the file are all refused."""
+    import hashlib
+    g4 = golden("fullsize.json")["config4"]
+    c = g4["config"]
+    trees = ctx.slot_trees_fake(c["seed"], 0, c["nSlots"], c["cellSize"], c["blockSize"], c["nCells"])
+    roots = trees.roots()
+    assert hashlib.sha256(roots.tobytes()).hexdigest() == g4["slot_roots_sha256"]
+    cells = np.array([0, 1, 4095, 2048, 77], dtype=np.uint64)
+    want_paths, want_leaves = trees.paths(4095, cells, 32)
+    path = str(tmp_path / "big.cp2")
+    trees.save(path)
+    trees.free()
+    size = os.path.getsize(path)
+    assert size > (1 << 30) - (1 << 20)                # 2 x 4096 x 2^12 nodes less the halving tail, plus the header
+    back = ctx.slot_trees_load(path)
+    assert np.array_equal(back.roots(), roots)
+    got_paths, got_leaves = back.paths(4095, cells, 32)
+    assert np.array_equal(got_paths, want_paths) and np.array_equal(got_leaves, want_leaves)
+    back.free()
+    with open(path, "r+b") as f:                      # one byte in the ninth chunk
+        f.seek(size // 2 + 12345)
+        b = f.read(1)
+        f.seek(size // 2 + 12345)
+        f.write(bytes([b[0] ^ 1]))
+    with pytest.raises(pkg.CodexP2Error) as e:
+        ctx.slot_trees_load(path)
+    assert "checksum" in str(e.value)
+    with open(path, "r+b") as f:                      # repaired, then cut short / extended
+        f.seek(size // 2 + 12345)
+        f.write(b)
+    ctx.slot_trees_load(path).free()
+    os.truncate(path, size - 32)
+    with pytest.raises(pkg.CodexP2Error):
+        ctx.slot_trees_load(path)
+    with open(path, "ab") as f:
+        f.write(bytes(64))
+    with pytest.raises(pkg.CodexP2Error):
+        ctx.slot_trees_load(path)
+    os.remove(path)
