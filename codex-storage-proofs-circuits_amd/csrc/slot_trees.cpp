@@ -146,6 +146,7 @@ struct LayerScheduler {
   size_t group;
   const SlotsDone& done;
   size_t built = 0;
+  bool take_all = false;                     // groups of varying size (the fake builder's ramp-down): every complete slot goes at once
   hipStream_t hs[2] = {nullptr, nullptr};
   hipEvent_t ev[2] = {nullptr, nullptr};     // the latest hashing enqueued on each stream
   ~LayerScheduler() {
@@ -176,7 +177,8 @@ struct LayerScheduler {
     for (;;) {
       const size_t avail = complete - built;
       size_t take = 0;
-      if (group && avail >= group) take = group;
+      if (group && take_all) take = avail;
+      else if (group && avail >= group) take = group;
       else if (final && avail) take = avail;
       if (!take) return CP2_OK;
       (void)s;
@@ -218,10 +220,22 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
   if (two) CP2_TRY(stage[1].scratch(ctx, chunk * cell_size));
   const uint64_t seed0 = cp2_slot_seed(dataset_seed, first_slot);
   LayerScheduler sched{t.get(), group, done};
+  // Groups (the streamed proof-input path): what follows a group on the host -- the JSON bodies of its slots -- overlaps the
+  // hashing of the NEXT group, so the last group's formatting overlaps nothing.  When a chunk is a whole number of slots the
+  // last groups are therefore halved down to one residency of the hash kernel (768 x 256 cells): 256, 256, ..., 128, 64, 48
+  // slots of 2^12 cells instead of a final 256, and the un-overlapped tail shrinks from ~50 ms of formatting to ~10.
+  const char* ramp_env = std::getenv("CP2_STREAM_RAMP");                                                  // "0": A/B tooling
+  const bool ramp = group && chunk >= n_cells && chunk % n_cells == 0 && !(ramp_env && ramp_env[0] == '0');
+  const size_t g_slots = ramp ? chunk / n_cells : 0, g_min = ramp ? std::max<size_t>(1, std::min(g_slots, (size_t)768 * 256 / n_cells)) : 0;
+  sched.take_all = ramp;
   int st = sched.init();
   size_t turn = 0;
-  for (size_t c0 = 0; st == CP2_OK && c0 < total_cells; c0 += chunk, ++turn) {
-    size_t n = std::min(chunk, total_cells - c0);
+  for (size_t c0 = 0, n = 0; st == CP2_OK && c0 < total_cells; c0 += n, ++turn) {
+    n = std::min(chunk, total_cells - c0);
+    if (ramp) {
+      const size_t left = (total_cells - c0) / n_cells;
+      n = (left >= 2 * g_slots ? g_slots : (left > g_min ? std::max(g_min, (left + 1) / 2) : left)) * n_cells;
+    }
     const int s = group ? 0 : (int)(turn & 1);                 // generation + hashing of this chunk on stream s, in its own staging buffer
     hipError_t e = cp2k::launch_gen_fake_cells(seed0, n_cells, c0, nullptr, n, cell_size, stage[s].p, sched.hs[s]);
     if (e == hipSuccess) e = cp2k::launch_hash_cells(stage[s].p, cell_size, n, t->nodes.u8() + c0 * 32, sched.hs[s]);
