@@ -72,7 +72,7 @@ int cp2_set_ingest_direct(cp2_ctx* ctx, int on);
  * (blocks still referenced by live proof inputs return when those are freed); the next call allocates again. */
 int cp2_trim(cp2_ctx* ctx);
 /* Host memory of the streamed proof-input path (cp2_dataset_build_streamed): the JSON body of every local slot (about 0.7 MB
- * at nSamples = 100, cellSize = 2048) is kept until the dataset is freed.  Bodies beyond `max_resident_bytes` in total are
+ * at nSamples = 100, cellSize = 2048) is kept until the dataset is freed.  Bodies beyond `max_resident_bytes` per dataset are
  * written to "<spill_dir>/cp2_body_<pid>_<dataset>_<slot>.part" instead and read back by cp2_dataset_export_streamed /
  * cp2_dataset_streamed_json; the files are removed by cp2_dataset_free.  Defaults: 4 GiB (environment CP2_BODY_BUDGET_MB),
  * spill_dir NULL = $TMPDIR or /tmp.  max_resident_bytes = 0 keeps the current budget; (size_t)-1 = never spill. */
@@ -255,7 +255,9 @@ int cp2_dataset_export_proof_inputs(cp2_dataset* ds, const uint64_t* slot_idx, s
  * finished ones are sampled (sample/bn254.nim:16-27), their paths and cells gathered on the device, downloaded into pinned
  * memory and formatted (cellData + merklePaths) on `threads` host threads.  Only the lines that need all slot roots
  * (dataSetRoot, slotProof: gen_input/bn254.nim:49-51,72) are left for cp2_dataset_export_streamed.  The returned dataset
- * is a normal cp2_dataset (roots, set_roots, proof inputs for other entropies all work). */
+ * is a normal cp2_dataset (roots, set_roots, proof inputs for other entropies all work).
+ * Host memory: the formatted bodies stay with the dataset until cp2_dataset_free, in memory up to the context's body budget
+ * and in spill files beyond it (cp2_set_body_budget above). */
 int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local,
                                const uint8_t entropy[32], int threads, size_t group_slots, cp2_dataset** out);
 /* Finish what cp2_dataset_build_streamed prepared: needs the dataset tree (cp2_dataset_set_roots; implied when all slots
