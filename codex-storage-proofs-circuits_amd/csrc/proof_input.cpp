@@ -372,20 +372,36 @@ static int host_cells_global(cp2_slot_trees* t, const uint64_t* g, size_t n, uin
     return CP2_OK;
   }
   if (t->src == CellSrc::File) {
-    int fd = -1;
-    size_t open_slot = ~(size_t)0;
-    for (size_t i = 0; i < n; ++i) {
-      size_t slot = g[i] / t->n_cells, cell = g[i] % t->n_cells;
-      if (slot != open_slot) {
-        if (fd >= 0) close(fd);
-        std::string fname = slot_file_name(t->file_base, t->first_slot + slot);
-        fd = open(fname.c_str(), O_RDONLY);
-        if (fd < 0) { ctx->err = "cannot open " + fname; return CP2_ERR_IO; }
-        open_slot = slot;
+    // a batch of proof inputs samples hundreds of thousands of cells (4096 slots x 100): the reads are spread over the
+    // context's fill threads, each taking a contiguous range of the (slot-ordered) list and opening a slot file once per run
+    const int threads = (int)std::min<size_t>(ctx->ingest_threads > 0 ? (size_t)ctx->ingest_threads : 8, std::max<size_t>(1, n / 256));
+    std::vector<std::string> failed(threads);
+    auto work = [&](int w) {
+      int fd = -1;
+      size_t open_slot = ~(size_t)0;
+      for (size_t i = n * w / threads; i < n * (w + 1) / threads; ++i) {
+        size_t slot = g[i] / t->n_cells, cell = g[i] % t->n_cells;
+        if (slot != open_slot) {
+          if (fd >= 0) close(fd);
+          std::string fname = slot_file_name(t->file_base, t->first_slot + slot);
+          fd = open(fname.c_str(), O_RDONLY);
+          if (fd < 0) { failed[w] = fname; return; }
+          open_slot = slot;
+        }
+        read_file_cell(fd, cs, cell, out + i * cs);
       }
-      read_file_cell(fd, cs, cell, out + i * cs);
+      if (fd >= 0) close(fd);
+    };
+    if (threads <= 1) {
+      work(0);
+    } else {
+      Workers pool(threads - 1);
+      for (int w = 1; w < threads; ++w) pool.submit([&work, w] { work(w); });
+      work(0);
+      pool.wait_idle();
     }
-    if (fd >= 0) close(fd);
+    for (const auto& f : failed)
+      if (!f.empty()) { ctx->err = "cannot open " + f; return CP2_ERR_IO; }
     return CP2_OK;
   }
   if (t->src == CellSrc::Dev) {   // cell sizes the row gather cannot take: plain copies

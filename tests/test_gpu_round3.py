@@ -239,3 +239,28 @@ def test_tree_cache_streams_large_node_buffers(pkg, ctx, golden, tmp_path):
     with pytest.raises(pkg.CodexP2Error):
         ctx.slot_trees_load(path)
     os.remove(path)
+
+
+def test_batch_proof_inputs_from_slot_files_read_cells_in_parallel(pkg, ctx, oracle, tmp_path):
+    """cp2_proof_inputs_generate_batch on the SlotFile source: 40 slots x 20 samples = 800 sampled cells read by several
+    threads (each a contiguous, slot-ordered range) equal the one-slot calls (single thread), the streamed path (its own
+    workers) and the oracle; a missing file is named."""
+    C, P = oracle
+    c = dict(maxDepth=10, maxLog2NSlots=6, cellSize=256, blockSize=2048, nSlots=40, nCells=64, nSamples=20, seed=31)
+    base = str(tmp_path / "f")
+    for k in range(40):
+        C.gen_fake_cells(C.slot_seed(31, k), 0, 64, 256).tofile("%s%d.dat" % (base, k))
+    cf = {k: v for k, v in c.items() if k != "seed"}
+    cfg = pkg.make_config(file=base, **cf)
+    ds = ctx.dataset(cfg)
+    batch = [p.json() for p in ds.proof_inputs(list(range(40)), 2025)]
+    assert batch == [ds.proof_input(s, 2025).json() for s in range(40)]
+    for s in (0, 17, 39):
+        assert batch[s] == P.export_json(expected_proof_input_fast(C, P, c, s, 2025, threads=4))
+    sd = ctx.dataset_streamed(cfg, 2025, threads=3, group_slots=7)
+    sd.export_streamed(None, threads=2)
+    assert [sd.streamed_json(s) for s in range(40)] == batch
+    os.remove(base + "23.dat")
+    with pytest.raises(pkg.CodexP2Error) as e:
+        ds.proof_inputs(list(range(40)), 2025)
+    assert "cannot open" in str(e.value) and "f23.dat" in str(e.value)
