@@ -1,6 +1,6 @@
 """Soak of the host pipelines (streamed build + export with spilled bodies, sharded datasets, ingestion knobs, host-array streaming, cp2_trim):
 random shapes, the streamed text against the object path on every slot and against the oracle on some, with resident
-host memory and free device memory watched for leaks.  Usage: soak_pipeline.py [seconds]"""
+host memory and free device memory watched for leaks.  Usage: soak_pipeline.py [seconds] [seed]"""
 import hashlib, os, resource, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -12,7 +12,7 @@ pkg = g.load_package()
 C, P = g.load_oracle()
 ctx = pkg.Context(0)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 180.0
-rng = np.random.default_rng(20261004)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20261004)
 t0 = time.time()
 it = bad = 0
 free0 = None
