@@ -19,6 +19,11 @@ int main(void) {
   memset(&cfg, 0, sizeof cfg);
   if (cp2_write_circom_main(&cfg, "/nonexistent/x") == CP2_OK) return 7;
   if (cp2_permute_batch(NULL, data, data, 1) != CP2_ERR_INVALID) return 8;
+  /* context-level knobs refuse a missing context instead of dereferencing it */
+  if (cp2_trim(NULL) != CP2_ERR_INVALID || cp2_set_body_budget(NULL, 1, "/tmp") != CP2_ERR_INVALID ||
+      cp2_set_ingest_direct(NULL, 1) != CP2_ERR_INVALID || cp2_set_ingest(NULL, 1, 2, 3) != CP2_ERR_INVALID) return 9;
+  if (cp2_slot_trees_load(NULL, "/nonexistent", NULL) != CP2_ERR_INVALID || cp2_slot_trees_save(NULL, "/tmp/x") != CP2_ERR_INVALID) return 10;
+  if (cp2_dataset_export_streamed(NULL, NULL, 1, NULL) != CP2_ERR_INVALID || cp2_dataset_streamed_json(NULL, 0, NULL, NULL) != CP2_ERR_INVALID) return 11;
   printf("c abi ok\n");
   return 0;
 }
