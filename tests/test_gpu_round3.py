@@ -264,3 +264,30 @@ def test_batch_proof_inputs_from_slot_files_read_cells_in_parallel(pkg, ctx, ora
     with pytest.raises(pkg.CodexP2Error) as e:
         ds.proof_inputs(list(range(40)), 2025)
     assert "cannot open" in str(e.value) and "f23.dat" in str(e.value)
+
+
+@pytest.mark.parametrize("cpb,nblocks", [(3, 5), (5, 7), (2, 9), (7, 1), (1, 11), (6, 3)])
+def test_every_leaf_proof_reconstructs_the_root_in_odd_trees(pkg, ctx, oracle, cpb, nblocks):
+    """The reference's own Merkle property test (reference/haskell/src/Poseidon2/Merkle.hs:141-152: the proof of EVERY leaf
+    re-derives the root) on slot trees whose block trees and big trees are odd at several levels (keys 2 / 3, a zero sibling
+    where the reference reads out of range, merkle.nim:33-34): bottom proof inside the block, top proof over the block roots,
+    both through the oracle's reconstructRoot (merkle.nim:51-74)."""
+    C, P = oracle
+    cs, n_cells = 64, cpb * nblocks
+    trees = ctx.slot_trees_fake(77, 1, 2, cs, cs * cpb, n_cells)
+    depth = trees.depth
+    db = max(1, (cpb - 1).bit_length())
+    dt = max(1, (nblocks - 1).bit_length())
+    assert depth == db + dt
+    for s in range(2):
+        root = pkg.array_to_felts(trees.roots()[s:s + 1])[0]
+        assert np.array_equal(trees.roots()[s], C.fake_slot_root(C.slot_seed(77, 1 + s), cs, cs * cpb, n_cells, 2))
+        cells = C.gen_fake_cells(C.slot_seed(77, 1 + s), 0, n_cells, cs)
+        paths, leaves = trees.paths(s, list(range(n_cells)), depth + 1)
+        for ci in range(n_cells):
+            leaf = pkg.array_to_felts(leaves[ci:ci + 1])[0]
+            assert leaf == C.array_to_felts(C.hash_bytes(cells[ci]))[0]
+            path = pkg.array_to_felts(paths[ci])
+            bot = P.reconstruct_root({"numberOfLeaves": cpb, "leafIndex": ci % cpb, "leafValue": leaf, "merklePath": path[:db]})
+            top = P.reconstruct_root({"numberOfLeaves": nblocks, "leafIndex": ci // cpb, "leafValue": bot, "merklePath": path[db:depth]})
+            assert top == root and path[depth] == 0, (s, ci)
