@@ -565,15 +565,39 @@ def dataset_leg(torch, dist, ctx, pkg, dev, rank, world):
                           nSamples=100, seed=12345)
     ctx.reset_stream()
     torch.cuda.synchronize()
+
+    def all_ranks_ok(err):
+        """Every rank reaches every collective: a rank whose local step failed says so in an all-reduce instead of leaving
+        the others waiting in the gather (which would cost the whole JSON line)."""
+        if world > 1:
+            flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                raise RuntimeError("a rank failed in the dataset leg: %r" % (err,))
+        elif err:
+            raise err
+
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     backend = d.HipBackend(pkg, ctx)
-    root, all_roots, (first, count) = d.dataset_root_sharded(backend, cfg, rank, world, dist if world > 1 else None, dev)
-    t1 = time.perf_counter()
-    pi = backend.dataset.proof_input(first, 1234567)          # a proof input for one of this rank's own slots
-    text = pi.json()
-    torch.cuda.synchronize()
+    first, count = d.shard_range(n_slots, rank, world)
+    err, local = None, None
+    try:
+        local = backend.local_slot_roots(cfg, first, count)          # this rank's slot trees: no communication
+    except Exception as e:
+        err = e
+    all_ranks_ok(err)
+    all_roots = d.gather_slot_roots(local, n_slots, rank, world, dist if world > 1 else None, dev)   # THE exchange step
+    err, root, text = None, None, ""
+    try:
+        root = backend.dataset_root(cfg, all_roots)                  # 15-level dataset tree on every rank
+        t1 = time.perf_counter()
+        text = backend.dataset.proof_input(first, 1234567).json()    # a proof input for one of this rank's own slots
+        torch.cuda.synchronize()
+    except Exception as e:
+        err = e
+    all_ranks_ok(err)
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
