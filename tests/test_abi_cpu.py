@@ -154,3 +154,21 @@ def test_json_writer_host_only_vs_oracle_edge_values(pkg, oracle):
     want0 = P.export_json({"dataSetRoot": 1, "entropy": 2, "nCells": 2, "nSlots": 1, "slotIndex": 0, "slotRoot": 3,
                            "slotProof": {"merklePath": []}, "proofInputs": []})
     assert got0 == want0
+
+
+def test_bench_self_spawn_fails_fast_without_gpus(tmp_path):
+    """`python bench.py --gpus 2` without a launcher starts its own rank processes; when they die (here: no GPU) the parent
+    must notice at once, stop the rest, clean its rendezvous directory and exit non-zero with nothing on stdout -- never
+    sit in a rendezvous waiting for a rank that is gone."""
+    import glob
+    import sys
+    import time
+    if _have_gpu():
+        pytest.skip("GPU present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    before = set(glob.glob("/tmp/cp2_bench_rdv_*"))
+    t = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 1 and r.stdout == "" and time.time() - t < 120
+    assert set(glob.glob("/tmp/cp2_bench_rdv_*")) == before
