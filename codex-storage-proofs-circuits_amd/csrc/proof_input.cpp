@@ -128,6 +128,28 @@ struct cp2_dataset {
   ~cp2_dataset() { cp2_slot_trees_free(trees); }
 };
 
+// The field modulus r as four little-endian 64-bit words (README.md:76 of the reference), and a 32-byte value reduced into [0, r):
+// `Entropy` is a field element in the reference (types/bn254.nim:21), so what is stored and printed is the canonical
+// representative even when the caller hands in 32 arbitrary bytes (at most five subtractions: 2^256 / r < 5.3).
+static const uint64_t FR_MODULUS_LE64[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+static void canonical_felt(const uint8_t in[32], uint8_t out[32]) {
+  uint64_t w[4];
+  std::memcpy(w, in, 32);
+  for (;;) {
+    bool ge = true;
+    for (int i = 3; i >= 0; --i)
+      if (w[i] != FR_MODULUS_LE64[i]) { ge = w[i] > FR_MODULUS_LE64[i]; break; }
+    if (!ge) break;
+    unsigned __int128 borrow = 0;
+    for (int i = 0; i < 4; ++i) {
+      unsigned __int128 d = (unsigned __int128)w[i] - FR_MODULUS_LE64[i] - borrow;
+      w[i] = (uint64_t)d;
+      borrow = (d >> 64) & 1;
+    }
+  }
+  std::memcpy(out, w, 32);
+}
+
 static int dataset_check(const cp2_config* cfg, uint64_t first_slot, uint64_t n_local) {
   if (n_local == 0 || first_slot + n_local > cfg->n_slots) return CP2_ERR_INVALID;
   if (cfg->max_depth < 0 || cfg->max_log2_nslots < 0) return CP2_ERR_INVALID;
@@ -416,9 +438,11 @@ static int host_cells_global(cp2_slot_trees* t, const uint64_t* g, size_t n, uin
 
 // generateProofInput (gen_input/bn254.nim:35-79) for `n` slots of the dataset at once: one sampling launch,
 // one path gather, one cell fetch for all of them.
-extern "C" int cp2_proof_inputs_generate_batch(cp2_dataset* ds, const uint64_t* slot_idx, size_t n, const uint8_t entropy[32],
+extern "C" int cp2_proof_inputs_generate_batch(cp2_dataset* ds, const uint64_t* slot_idx, size_t n, const uint8_t entropy_in[32],
                                                cp2_proof_input** out) try {
-  if (!ds || !entropy || (n && (!slot_idx || !out))) return CP2_ERR_INVALID;
+  if (!ds || !entropy_in || (n && (!slot_idx || !out))) return CP2_ERR_INVALID;
+  uint8_t entropy[32];
+  canonical_felt(entropy_in, entropy);
   for (size_t i = 0; i < n; ++i) out[i] = nullptr;
   if (n == 0) return CP2_OK;
   const cp2_config& cfg = ds->cfg;
@@ -913,8 +937,10 @@ struct StreamRing {
 }  // namespace
 
 extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local,
-                                          const uint8_t entropy[32], int threads, size_t group_slots, cp2_dataset** out) try {
-  if (!ctx || !cfg || !out || !entropy) return CP2_ERR_INVALID;
+                                          const uint8_t entropy_in[32], int threads, size_t group_slots, cp2_dataset** out) try {
+  if (!ctx || !cfg || !out || !entropy_in) return CP2_ERR_INVALID;
+  uint8_t entropy[32];
+  canonical_felt(entropy_in, entropy);
   *out = nullptr;
   CP2_TRY(dataset_check(cfg, first_slot, n_local));
   if (!is_pow2(cfg->n_cells)) return CP2_ERR_INVALID;                    // sample/bn254.nim:19-20

@@ -291,3 +291,20 @@ def test_every_leaf_proof_reconstructs_the_root_in_odd_trees(pkg, ctx, oracle, c
             bot = P.reconstruct_root({"numberOfLeaves": cpb, "leafIndex": ci % cpb, "leafValue": leaf, "merklePath": path[:db]})
             top = P.reconstruct_root({"numberOfLeaves": nblocks, "leafIndex": ci // cpb, "leafValue": bot, "merklePath": path[db:depth]})
             assert top == root and path[depth] == 0, (s, ci)
+
+
+def test_entropy_is_stored_and_printed_as_its_canonical_representative(pkg, ctx, oracle):
+    """`Entropy` is a field element in the reference (types/bn254.nim:21): 32 bytes that encode r + 5, 4r + 5 or 2^256 - 1 give the
+    proof input (indices, paths, and the "entropy" line of input.json) of their residues, on both paths."""
+    C, P = oracle
+    c = dict(maxDepth=8, maxLog2NSlots=2, cellSize=64, blockSize=256, nSlots=3, nCells=16, nSamples=4, seed=9)
+    cfg = pkg.make_config(**c)
+    ds = ctx.dataset(cfg)
+    as_bytes = lambda v: np.frombuffer(int(v).to_bytes(32, "little"), dtype=np.uint8)   # noqa: E731
+    for raw in (P.R_MOD + 5, 4 * P.R_MOD + 5, 2 ** 256 - 1, P.R_MOD):
+        want = P.export_json(P.generate_proof_input(dict(c), 1, raw % P.R_MOD))
+        assert ds.proof_input(1, as_bytes(raw)).json() == want
+        sd = ctx.dataset_streamed(cfg, as_bytes(raw), threads=2, group_slots=1)
+        sd.export_streamed(None)
+        assert sd.streamed_json(1) == want
+        sd.free()
