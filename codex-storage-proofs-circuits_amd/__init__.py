@@ -126,6 +126,32 @@ def load_library():
         "cp2_dataset_local_roots": (i32, [vp, vp]),
         "cp2_dataset_set_roots": (i32, [vp, vp]),
         "cp2_dataset_root": (i32, [vp, vp]),
+        "cp2_dataset_local_roots_dev": (vp, [vp]),
+        "cp2_dataset_copy_local_roots_dev": (i32, [vp, vp]),
+        "cp2_dataset_set_roots_dev": (i32, [vp, vp]),
+        "cp2_dataset_range": (i32, [vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]),
+        "cp2_dataset_ctx": (vp, [vp]),
+        "cp2_multi_init": (i32, [ctypes.POINTER(ctypes.c_int), i32, pvp]),
+        "cp2_multi_free": (None, [vp]),
+        "cp2_multi_count": (i32, [vp]),
+        "cp2_multi_device": (i32, [vp, i32]),
+        "cp2_multi_ctx": (vp, [vp, i32]),
+        "cp2_multi_last_error": (cp, [vp]),
+        "cp2_multi_gather_mode": (cp, [vp]),
+        "cp2_multi_set_policy": (i32, [vp, i32, u64]),
+        "cp2_shard_range": (None, [u64, i32, i32, ctypes.POINTER(u64), ctypes.POINTER(u64)]),
+        "cp2_multi_dataset_build": (i32, [vp, ctypes.POINTER(Config), pvp]),
+        "cp2_multi_dataset_build_cached": (i32, [vp, ctypes.POINTER(Config), cp, pvp]),
+        "cp2_multi_dataset_build_streamed": (i32, [vp, ctypes.POINTER(Config), vp, i32, sz, pvp]),
+        "cp2_multi_dataset_free": (None, [vp]),
+        "cp2_multi_dataset_shards": (i32, [vp]),
+        "cp2_multi_dataset_shard": (vp, [vp, i32, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(u64), ctypes.POINTER(u64)]),
+        "cp2_multi_dataset_root": (i32, [vp, vp]),
+        "cp2_multi_dataset_slot_roots": (i32, [vp, vp]),
+        "cp2_multi_proof_input_generate": (i32, [vp, u64, vp, pvp]),
+        "cp2_multi_dataset_export_proof_inputs": (i32, [vp, vp, sz, vp, cp, i32, sz, ctypes.POINTER(u64)]),
+        "cp2_multi_dataset_export_streamed": (i32, [vp, cp, i32, ctypes.POINTER(u64)]),
+        "cp2_multi_dataset_streamed_json": (i32, [vp, u64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz)]),
         "cp2_proof_input_generate": (i32, [vp, u64, vp, pvp]),
         "cp2_proof_inputs_generate_batch": (i32, [vp, vp, sz, vp, pvp]),
         "cp2_proof_inputs_write_json_batch": (i32, [pvp, sz, ctypes.POINTER(cp), i32, ctypes.POINTER(u64)]),
@@ -476,6 +502,18 @@ class Dataset:
             assert r.shape[0] == self.cfg.n_slots
             self.ctx._ck(self.ctx.L.cp2_dataset_set_roots(self.h, _p(r)), "cp2_dataset_set_roots")
 
+    def local_roots_dev(self):
+        """device pointer to the n_local x 32 bytes of local slot roots"""
+        return self.ctx.L.cp2_dataset_local_roots_dev(self.h)
+
+    def copy_local_roots_dev(self, d_out):
+        """enqueue a device-to-device copy of the local roots into the caller's buffer (context's stream; ctx.sync() after)"""
+        self.ctx._ck(self.ctx.L.cp2_dataset_copy_local_roots_dev(self.h, ctypes.c_void_p(d_out)), "cp2_dataset_copy_local_roots_dev")
+
+    def set_roots_dev(self, d_all_roots):
+        """all n_slots roots from device memory (the gathered buffer): no host copy on the way in"""
+        self.ctx._ck(self.ctx.L.cp2_dataset_set_roots_dev(self.h, ctypes.c_void_p(d_all_roots)), "cp2_dataset_set_roots_dev")
+
     def root(self):
         out = np.empty(32, dtype=np.uint8)
         self.ctx._ck(self.ctx.L.cp2_dataset_root(self.h, _p(out)), "cp2_dataset_root")
@@ -520,6 +558,171 @@ class Dataset:
         hs = (ctypes.c_void_p * idx.size)()
         self.ctx._ck(self.ctx.L.cp2_proof_inputs_generate_batch(self.h, _p(idx), idx.size, _p(e), hs), "cp2_proof_inputs_generate_batch")
         return [ProofInput(self.ctx, ctypes.c_void_p(h), self.cfg) for h in hs]
+
+
+GATHER_AUTO, GATHER_RCCL, GATHER_HOST = 0, 1, 2
+
+
+def shard_range(n_items, rank, world):
+    """cp2_shard_range: (first, count) of the contiguous range rank `rank` of `world` holds."""
+    L = load_library()
+    a, b = ctypes.c_uint64(), ctypes.c_uint64()
+    L.cp2_shard_range(n_items, rank, world, ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value
+
+
+class _BorrowedContext(Context):
+    """A cp2_ctx owned by a cp2_multi (never freed from here)."""
+
+    def __init__(self, L, h):
+        self.L, self.h = L, h
+
+    def close(self):
+        self.h = None
+
+
+class Multi:
+    """cp2_multi: one handle over several devices of the node (in-process sharding, include/codex_p2.h section e)."""
+
+    def __init__(self, devices=None):
+        self.L = load_library()
+        h = ctypes.c_void_p()
+        if devices:
+            arr = (ctypes.c_int * len(devices))(*devices)
+            st = self.L.cp2_multi_init(arr, len(devices), ctypes.byref(h))
+        else:
+            st = self.L.cp2_multi_init(None, 0, ctypes.byref(h))
+        if st != CP2_OK:
+            raise CodexP2Error(st, "cp2_multi_init", self.L.cp2_strerror(st).decode())
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.cp2_multi_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if _finalizing():
+                return
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, st, where):
+        if st != CP2_OK:
+            raise CodexP2Error(st, where, self.L.cp2_multi_last_error(self.h).decode() or self.L.cp2_strerror(st).decode())
+
+    @property
+    def count(self):
+        return self.L.cp2_multi_count(self.h)
+
+    def devices(self):
+        return [self.L.cp2_multi_device(self.h, i) for i in range(self.count)]
+
+    def ctx(self, i=0):
+        h = self.L.cp2_multi_ctx(self.h, i)
+        if not h:
+            raise CodexP2Error(-2, "cp2_multi_ctx")
+        return _BorrowedContext(self.L, ctypes.c_void_p(h))
+
+    def gather_mode(self):
+        return self.L.cp2_multi_gather_mode(self.h).decode()
+
+    def set_policy(self, gather=GATHER_AUTO, min_cells_per_device=0):
+        self._ck(self.L.cp2_multi_set_policy(self.h, gather, min_cells_per_device), "cp2_multi_set_policy")
+
+    def dataset(self, cfg, cache=None):
+        return MultiDataset(self, cfg, cache=cache)
+
+    def dataset_streamed(self, cfg, entropy, threads=1, group_slots=0):
+        return MultiDataset(self, cfg, streamed=(entropy, threads, group_slots))
+
+
+class MultiDataset:
+    def __init__(self, multi, cfg, cache=None, streamed=None):
+        self.multi, self.cfg = multi, cfg
+        L = multi.L
+        h = ctypes.c_void_p()
+        if streamed is not None:
+            entropy, threads, group = streamed
+            e = _u8(entropy if not isinstance(entropy, int) else felt_bytes(entropy))
+            multi._ck(L.cp2_multi_dataset_build_streamed(multi.h, ctypes.byref(cfg), _p(e), threads, group, ctypes.byref(h)),
+                      "cp2_multi_dataset_build_streamed")
+        elif cache:
+            multi._ck(L.cp2_multi_dataset_build_cached(multi.h, ctypes.byref(cfg), cache.encode(), ctypes.byref(h)), "cp2_multi_dataset_build_cached")
+        else:
+            multi._ck(L.cp2_multi_dataset_build(multi.h, ctypes.byref(cfg), ctypes.byref(h)), "cp2_multi_dataset_build")
+        self.h = h
+
+    def free(self):
+        if self.h:
+            self.multi.L.cp2_multi_dataset_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if _finalizing():
+                return
+            self.free()
+        except Exception:
+            pass
+
+    def shards(self):
+        """[(device, first_slot, n_local)] of every shard"""
+        L, out = self.multi.L, []
+        for i in range(L.cp2_multi_dataset_shards(self.h)):
+            d, a, b = ctypes.c_int(), ctypes.c_uint64(), ctypes.c_uint64()
+            L.cp2_multi_dataset_shard(self.h, i, ctypes.byref(d), ctypes.byref(a), ctypes.byref(b))
+            out.append((d.value, a.value, b.value))
+        return out
+
+    def root(self):
+        out = np.empty(32, dtype=np.uint8)
+        self.multi._ck(self.multi.L.cp2_multi_dataset_root(self.h, _p(out)), "cp2_multi_dataset_root")
+        return out
+
+    def shard_root(self, i):
+        """the dataset root as shard i's device computed it (every device builds the tree itself)"""
+        L = self.multi.L
+        ds = L.cp2_multi_dataset_shard(self.h, i, None, None, None)
+        out = np.empty(32, dtype=np.uint8)
+        self.multi._ck(L.cp2_dataset_root(ctypes.c_void_p(ds), _p(out)), "cp2_dataset_root")
+        return out
+
+    def slot_roots(self):
+        out = np.empty((self.cfg.n_slots, 32), dtype=np.uint8)
+        self.multi._ck(self.multi.L.cp2_multi_dataset_slot_roots(self.h, _p(out)), "cp2_multi_dataset_slot_roots")
+        return out
+
+    def proof_input(self, slot_idx, entropy):
+        e = _u8(entropy if not isinstance(entropy, int) else felt_bytes(entropy))
+        h = ctypes.c_void_p()
+        self.multi._ck(self.multi.L.cp2_multi_proof_input_generate(self.h, slot_idx, _p(e), ctypes.byref(h)), "cp2_multi_proof_input_generate")
+        pi = ProofInput(self.multi, h, self.cfg)
+        pi.slot_idx = slot_idx
+        return pi
+
+    def export_proof_inputs(self, slot_indices, entropy, directory=None, threads=1, batch=0):
+        e = _u8(entropy if not isinstance(entropy, int) else felt_bytes(entropy))
+        idx = np.ascontiguousarray(np.asarray(slot_indices, dtype=np.uint64))
+        total = ctypes.c_uint64()
+        self.multi._ck(self.multi.L.cp2_multi_dataset_export_proof_inputs(self.h, _p(idx), idx.size, _p(e), directory.encode() if directory else None,
+                                                                          threads, batch, ctypes.byref(total)), "cp2_multi_dataset_export_proof_inputs")
+        return total.value
+
+    def export_streamed(self, directory=None, threads=1):
+        total = ctypes.c_uint64()
+        self.multi._ck(self.multi.L.cp2_multi_dataset_export_streamed(self.h, directory.encode() if directory else None, threads,
+                                                                      ctypes.byref(total)), "cp2_multi_dataset_export_streamed")
+        return total.value
+
+    def streamed_json(self, slot_idx):
+        text, ln = ctypes.c_void_p(), ctypes.c_size_t()
+        self.multi._ck(self.multi.L.cp2_multi_dataset_streamed_json(self.h, slot_idx, ctypes.byref(text), ctypes.byref(ln)), "cp2_multi_dataset_streamed_json")
+        s = ctypes.string_at(text, ln.value).decode()
+        self.multi.L.cp2_free_buffer(text)
+        return s
 
 
 def write_json_batch(ctx, proof_inputs, paths=None, threads=1):

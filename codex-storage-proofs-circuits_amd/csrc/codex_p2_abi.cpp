@@ -13,8 +13,7 @@
 #include <string>
 #include <vector>
 
-#include "internal.hpp"
-#include "kernels.hpp"
+#include "trees.hpp"
 
 using namespace cp2i;
 
@@ -24,11 +23,13 @@ using namespace cp2i;
 extern "C" int cp2_init(int device, cp2_ctx** out) try {
   if (!out) return CP2_ERR_INVALID;
   *out = nullptr;
+  StageTimer trace;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return CP2_ERR_NO_DEVICE;
   if (hipSetDevice(device) != hipSuccess) return CP2_ERR_NO_DEVICE;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return CP2_ERR_NO_DEVICE;
+  trace.lap("context: HIP runtime + device query");
   cp2_ctx* c = new (std::nothrow) cp2_ctx();
   if (!c) return CP2_ERR_ALLOC;
   c->device = device;
@@ -42,6 +43,11 @@ extern "C" int cp2_init(int device, cp2_ctx** out) try {
     return CP2_ERR_HIP;
   }
   c->stream = c->own_stream;
+  trace.lap("context: stream");
+  if (trace.on) {   // tracing only: the code object is otherwise loaded by the first launch, inside that launch's time
+    (void)cp2k::load_code_object();
+    trace.lap("context: code object load");
+  }
   *out = c;
   return CP2_OK;
 } catch (const std::bad_alloc&) {

@@ -514,6 +514,13 @@ hipError_t launch_sample_paths(const TreeGeom& g, const void* nodes, const void*
   return hipGetLastError();
 }
 
+// Forces the code object of this library onto the current device without launching anything (what the first launch of a
+// process otherwise does implicitly): lets a trace show module loading apart from the first kernel's own time.
+hipError_t load_code_object() {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_permute_batch));
+}
+
 hipError_t launch_gather_rows(const void* src, const uint64_t* index, size_t nrows, size_t row_bytes, void* out, hipStream_t st) {
   if (nrows == 0) return hipSuccess;
   size_t work = nrows * (row_bytes / 4);

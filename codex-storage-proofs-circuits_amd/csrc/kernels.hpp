@@ -41,6 +41,8 @@ hipError_t launch_gen_fake_cells(uint64_t seed0, uint64_t cells_per_slot, uint64
 hipError_t launch_sample_paths(const TreeGeom& g, const void* nodes, const void* d_entropy, const uint64_t* slots, uint64_t slot0,
                                size_t n_items, uint32_t ns, uint32_t md, uint64_t* indices, uint64_t* gcell, uint64_t* rows,
                                hipStream_t st);
+// load this library's code object on the current device now (tracing only; launches do it implicitly)
+hipError_t load_code_object();
 hipError_t launch_gather_rows(const void* src, const uint64_t* index, size_t nrows, size_t row_bytes, void* out,
                               hipStream_t st);
 

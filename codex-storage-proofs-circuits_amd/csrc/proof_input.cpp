@@ -12,10 +12,12 @@
 #include <hip/hip_runtime.h>
 
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -35,22 +37,27 @@ using namespace cp2i;
 // ---------------------------------------------------------------------------------------------
 // JSON bodies (", \"cellData\": ... }") of the streamed build, one per local slot.  Bodies stay in host memory up to the
 // context's budget (cp2_set_body_budget; 0.7 MB each at nSamples = 100, cellSize = 2048: 23 GB for 32 768 local slots if
-// nothing bounded it); beyond it they go to "<dir>/cp2_body_<pid>_<dataset>_<slot>.part" and are read back at export.
-// put() is called from the formatting workers, everything else from the owning thread.
+// nothing bounded it); beyond it they go to files and are read back at export.  The bodies hold sampled cell data, so the
+// files live in a PRIVATE directory made by mkdtemp (mode 0700, unpredictable name) under the spill directory, each file
+// created with O_EXCL | O_NOFOLLOW and mode 0600: nothing planted in a shared /tmp is followed or overwritten, two processes
+// with equal pids (containers sharing a spill volume) cannot meet, and nobody else can read them.  The directory and its
+// files go with the dataset.  put() is called from the formatting workers, everything else from the owning thread.
 struct BodyStore {
   std::vector<std::string> mem;
   std::vector<uint64_t> size;        // text length of every body, resident or spilled
   std::vector<uint8_t> spilled;
-  std::string dir, tag;
+  std::string base, dir;             // base: the caller's spill directory; dir: the private directory, made at the first spill
+  std::string error;                 // first spill failure, with the path (read by the owning thread after the workers are idle)
   size_t budget = 0;
   std::atomic<size_t> resident{0};
   std::atomic<size_t> n_spilled{0};
+  std::mutex mu;
   ~BodyStore() {
     for (size_t s = 0; s < spilled.size(); ++s)
-      if (spilled[s]) std::remove(file_of(s).c_str());
+      if (spilled[s]) (void)unlink(file_of(s).c_str());
+    if (!dir.empty()) (void)rmdir(dir.c_str());
   }
   void init(cp2_ctx* ctx, size_t n) {
-    static std::atomic<unsigned> serial{0};
     mem.assign(n, std::string());
     size.assign(n, 0);
     spilled.assign(n, 0);
@@ -60,11 +67,29 @@ struct BodyStore {
       const unsigned long long mb = e ? std::strtoull(e, nullptr, 10) : 0;
       budget = mb ? (size_t)mb << 20 : (size_t)4 << 30;
     }
-    dir = ctx->spill_dir;
-    if (dir.empty()) { const char* t = std::getenv("TMPDIR"); dir = (t && *t) ? t : "/tmp"; }
-    tag = std::to_string((long)getpid()) + "_" + std::to_string(serial.fetch_add(1));
+    base = ctx->spill_dir;
+    if (base.empty()) { const char* t = std::getenv("TMPDIR"); base = (t && *t) ? t : "/tmp"; }
   }
-  std::string file_of(size_t s) const { return dir + "/cp2_body_" + tag + "_" + std::to_string(s) + ".part"; }
+  std::string file_of(size_t s) const { return dir + "/body_" + std::to_string(s) + ".part"; }
+  // the private directory, created once (any worker may be the first to spill)
+  bool ensure_dir() {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!dir.empty()) return true;
+    std::string tmpl = base + "/cp2_bodies_XXXXXX";
+    std::vector<char> buf(tmpl.begin(), tmpl.end());
+    buf.push_back(0);
+    if (!mkdtemp(buf.data())) {
+      if (error.empty()) error = "cannot create a private spill directory under " + base + ": " + std::strerror(errno);
+      return false;
+    }
+    dir = buf.data();
+    return true;
+  }
+  int fail(const std::string& what) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (error.empty()) error = what;
+    return CP2_ERR_IO;
+  }
   // takes a copy of exactly text.size() bytes (the caller's buffer is sized for the worst case and reused)
   int put(size_t s, const std::string& text) {
     size[s] = text.size();
@@ -74,10 +99,25 @@ struct BodyStore {
       return CP2_OK;
     }
     resident.fetch_sub(text.size());
-    FILE* f = std::fopen(file_of(s).c_str(), "wb");
-    if (!f) return CP2_ERR_IO;
-    const bool ok = std::fwrite(text.data(), 1, text.size(), f) == text.size();
-    if (std::fclose(f) != 0 || !ok) { std::remove(file_of(s).c_str()); return CP2_ERR_IO; }
+    if (!ensure_dir()) return CP2_ERR_IO;
+    const std::string name = file_of(s);
+    const int fd = open(name.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd < 0) return fail("cannot create spill file " + name + ": " + std::strerror(errno));
+    const char* p = text.data();
+    size_t left = text.size();
+    bool ok = true;
+    while (ok && left) {
+      const ssize_t w = write(fd, p, left);
+      if (w <= 0) { ok = false; break; }
+      p += w;
+      left -= (size_t)w;
+    }
+    const int err = errno;
+    if (close(fd) != 0) ok = false;
+    if (!ok) {
+      (void)unlink(name.c_str());
+      return fail("cannot write spill file " + name + ": " + std::strerror(err));
+    }
     spilled[s] = 1;
     n_spilled.fetch_add(1);
     return CP2_OK;
@@ -85,7 +125,7 @@ struct BodyStore {
   // appends the body of slot s to `out`
   int append(size_t s, std::string& out) const {
     if (!spilled[s]) { out.append(mem[s]); return CP2_OK; }
-    FILE* f = std::fopen(file_of(s).c_str(), "rb");
+    FILE* f = open_spilled(s);
     if (!f) return CP2_ERR_IO;
     const size_t at = out.size();
     out.resize(at + size[s]);
@@ -96,7 +136,7 @@ struct BodyStore {
   // writes the body of slot s to an open file (spilled bodies are copied through a bounded buffer)
   int write_to(size_t s, FILE* dst) const {
     if (!spilled[s]) return std::fwrite(mem[s].data(), 1, mem[s].size(), dst) == mem[s].size() ? CP2_OK : CP2_ERR_IO;
-    FILE* f = std::fopen(file_of(s).c_str(), "rb");
+    FILE* f = open_spilled(s);
     if (!f) return CP2_ERR_IO;
     std::vector<char> buf((size_t)1 << 20);
     uint64_t left = size[s];
@@ -108,6 +148,15 @@ struct BodyStore {
     }
     std::fclose(f);
     return ok ? CP2_OK : CP2_ERR_IO;
+  }
+
+ private:
+  FILE* open_spilled(size_t s) const {
+    const int fd = open(file_of(s).c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) return nullptr;
+    FILE* f = fdopen(fd, "rb");
+    if (!f) close(fd);
+    return f;
   }
 };
 
@@ -236,29 +285,78 @@ extern "C" int cp2_dataset_local_roots(cp2_dataset* ds, uint8_t* out) try {
   return CP2_ERR_INVALID;
 }
 
+// The dataset tree over the slot roots (gen_input/bn254.nim:49-50; odd layers use keys 2 / 3) from a DEVICE buffer holding
+// all n_slots roots: the layers are built in device scratch and downloaded once (slotProof and the JSON heads are made on the
+// host).  The buffer may live on another device or be the tree's own root layer; it is read on the context's stream.
+static int dataset_tree_from_dev(cp2_dataset* ds, const void* d_all_roots) {
+  cp2_ctx* ctx = ds->ctx;
+  const size_t n = ds->cfg.n_slots;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  ds->dsizes = layer_sizes_of(n);
+  const size_t total = cp2_merkle_total(n);
+  ds->dlayers.assign(total * 32, 0);
+  StageTimer trace;
+  DevBuf d;
+  CP2_TRY(d.scratch(ctx, total * 32));
+  CP2_TRY(merkle_trees_dev(ctx, d_all_roots, n, 1, d.p, false));
+  CP2_HIP(ctx, hipMemcpyAsync(ds->dlayers.data(), d.p, total * 32, hipMemcpyDeviceToHost, ctx->stream));
+  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  trace.lap("dataset tree");
+  ds->have_roots = true;
+  return CP2_OK;
+}
+
 extern "C" int cp2_dataset_set_roots(cp2_dataset* ds, const uint8_t* all_roots) try {
   if (!ds) return CP2_ERR_INVALID;
   cp2_ctx* ctx = ds->ctx;
   const size_t n = ds->cfg.n_slots;
-  std::vector<uint8_t> roots(n * 32);
-  if (all_roots) {
-    std::memcpy(roots.data(), all_roots, n * 32);
-  } else {
+  if (!all_roots) {   // single GPU: the local roots are all of them and are already on the device
     if (ds->first_slot != 0 || ds->n_local != n) return CP2_ERR_INVALID;   // roots of other ranks' slots are missing
-    CP2_TRY(cp2_slot_trees_roots(ds->trees, roots.data()));
+    return dataset_tree_from_dev(ds, cp2_slot_trees_roots_dev(ds->trees));
   }
-  // dataset tree over the slot roots (gen_input/bn254.nim:49-50); odd layers use keys 2/3
-  ds->dsizes = layer_sizes_of(n);
-  size_t total = cp2_merkle_total(n);
-  ds->dlayers.assign(total * 32, 0);
-  CP2_TRY(cp2_merkle_tree(ctx, roots.data(), n, ds->dlayers.data(), nullptr, nullptr));
-  ds->have_roots = true;
-  return CP2_OK;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  DevBuf d;
+  CP2_TRY(d.scratch(ctx, n * 32));
+  CP2_HIP(ctx, hipMemcpyAsync(d.p, all_roots, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  return dataset_tree_from_dev(ds, d.p);
 } catch (const std::bad_alloc&) {
   return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
 } catch (...) {
   return CP2_ERR_INVALID;
 }
+
+// The same from a device buffer (what a device-to-device gather leaves behind: RCCL all-gather output, a torch tensor):
+// no host copy of the roots is made on the way in.
+extern "C" int cp2_dataset_set_roots_dev(cp2_dataset* ds, const void* d_all_roots) try {
+  if (!ds || !d_all_roots) return CP2_ERR_INVALID;
+  if (reinterpret_cast<uintptr_t>(d_all_roots) & 15) return CP2_ERR_ALIGN;
+  return dataset_tree_from_dev(ds, d_all_roots);
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
+}
+
+extern "C" const void* cp2_dataset_local_roots_dev(const cp2_dataset* ds) { return ds ? cp2_slot_trees_roots_dev(ds->trees) : nullptr; }
+
+extern "C" int cp2_dataset_copy_local_roots_dev(cp2_dataset* ds, void* d_out) try {
+  if (!ds || !d_out) return CP2_ERR_INVALID;
+  cp2_ctx* ctx = ds->ctx;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  CP2_HIP(ctx, hipMemcpyAsync(d_out, cp2_slot_trees_roots_dev(ds->trees), ds->n_local * 32, hipMemcpyDeviceToDevice, ctx->stream));
+  return CP2_OK;
+} catch (...) {
+  return CP2_ERR_INVALID;
+}
+
+extern "C" int cp2_dataset_range(const cp2_dataset* ds, uint64_t* first_slot, uint64_t* n_local) {
+  if (!ds) return CP2_ERR_INVALID;
+  if (first_slot) *first_slot = ds->first_slot;
+  if (n_local) *n_local = ds->n_local;
+  return CP2_OK;
+}
+
+extern "C" cp2_ctx* cp2_dataset_ctx(const cp2_dataset* ds) { return ds ? ds->ctx : nullptr; }
 
 extern "C" int cp2_dataset_root(cp2_dataset* ds, uint8_t out[32]) try {
   if (!ds || !out) return CP2_ERR_INVALID;
@@ -565,7 +663,7 @@ extern "C" int cp2_proof_input_create(const cp2_config* cfg, uint64_t slot_idx, 
   p->cfg.n_samples = n_samples;
   p->slot_idx = slot_idx;
   std::memcpy(p->dataset_root, dataset_root, 32);
-  std::memcpy(p->entropy, entropy, 32);
+  canonical_felt(entropy, p->entropy);   // a field element in the reference (types/bn254.nim:21): stored and printed as its residue, like the generate paths
   std::memcpy(p->slot_root, slot_root, 32);
   p->slot_proof.assign(slot_proof, slot_proof + (size_t)cfg->max_log2_nslots * 32);
   p->n_samples = n_samples;
@@ -1023,11 +1121,7 @@ extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, u
             } else {
               text_body(body, cfgv, ns, ring.host[r].cells.u8() + (s - a) * ns * cs, paths);
             }
-            if (have && dsp->bodies.put(s, body) != CP2_OK) {
-              task_status.store(CP2_ERR_IO);
-              std::lock_guard<std::mutex> lk(io_mu);
-              if (io_error.empty()) io_error = "cannot write " + dsp->bodies.file_of(s);
-            }
+            if (have && dsp->bodies.put(s, body) != CP2_OK) task_status.store(CP2_ERR_IO);   // the store names the path (bodies.error)
           } catch (...) {
             task_status.store(CP2_ERR_ALLOC);
           }
@@ -1070,6 +1164,7 @@ extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, u
   }
   if (task_status.load() != CP2_OK) {
     if (!io_error.empty()) ctx->err = io_error;
+    else if (!ds->bodies.error.empty()) ctx->err = ds->bodies.error;
     return task_status.load();
   }
   ds->prepared = true;
@@ -1160,9 +1255,12 @@ extern "C" void cp2_free_buffer(void* p) { std::free(p); }
 
 extern "C" int cp2_proof_input_write_json(const cp2_proof_input* p, const char* path) try {
   if (!p || !path) return CP2_ERR_INVALID;
+  StageTimer trace;
   std::string s;
   proof_input_text(p, s);
-  return write_parts(path, s, std::string());
+  const int st = write_parts(path, s, std::string());
+  trace.lap("input.json formatted + written");
+  return st;
 } catch (const std::bad_alloc&) {
   return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
 } catch (...) {

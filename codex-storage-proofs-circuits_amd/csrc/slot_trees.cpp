@@ -208,6 +208,7 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
   t->src = CellSrc::Fake;
   t->dataset_seed = dataset_seed;
   t->first_slot = first_slot;
+  StageTimer trace;
   CP2_TRY(trees_layout(t.get()));
   const size_t total_cells = n_slots * n_cells;
   // staging chunk: up to 2 GiB of generated cells, a whole number of slots when slots are smaller than that
@@ -218,6 +219,7 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
   DevBuf stage[2];
   CP2_TRY(stage[0].scratch(ctx, chunk * cell_size));
   if (two) CP2_TRY(stage[1].scratch(ctx, chunk * cell_size));
+  trace.lap("fake slots: node + staging buffers");
   const uint64_t seed0 = cp2_slot_seed(dataset_seed, first_slot);
   LayerScheduler sched{t.get(), group, done};
   // Groups (the streamed proof-input path): what follows a group on the host -- the JSON bodies of its slots -- overlaps the
@@ -244,6 +246,7 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
     if (st == CP2_OK) st = sched.advance(c0 + n, c0 + n == total_cells, s);
   }
   int fin = sched.finish();
+  trace.lap("fake slots: generate + hash + layers");
   if (st == CP2_OK) st = fin;
   if (st != CP2_OK) return st;
   *out = t.release();
@@ -332,7 +335,7 @@ struct IngestPipe {
     }
     if (copy) (void)hipStreamDestroy(copy);
   }
-  int init(cp2_ctx* c, size_t cell_size, size_t max_cells) {
+  int init(cp2_ctx* c, size_t cell_size, size_t max_cells, bool direct_slack = false) {
     ctx = c;
     size_t chunk_bytes = c->ingest_chunk ? c->ingest_chunk : env_size("CP2_INGEST_CHUNK_MB", 0) << 20;
     if (chunk_bytes == 0) chunk_bytes = std::max<size_t>((size_t)64 << 20, std::min<size_t>((size_t)768 * 256 * cell_size, (size_t)1 << 30));
@@ -345,7 +348,9 @@ struct IngestPipe {
     hash_stream[0] = ctx->stream;
     CP2_TRY(aux_stream(ctx, &hash_stream[1]));
     for (int b = 0; b < want_depth; ++b) {
-      CP2_TRY(pinned[b].alloc(ctx, chunk * cell_size + DIRECT_ALIGN));   // slack: an O_DIRECT read is rounded up to whole blocks
+      // slack for O_DIRECT only (its last read of a chunk is rounded up to a whole block): without it the default 384 MiB chunk
+      // stays in its own size class of the block pool instead of spilling into the next one (+32 MiB of pinned memory per slot)
+      CP2_TRY(pinned[b].alloc(ctx, chunk * cell_size + (direct_slack ? DIRECT_ALIGN : 0)));
       CP2_TRY(dev[b].scratch(ctx, chunk * cell_size));
       CP2_HIP(ctx, hipEventCreateWithFlags(&copied[b], hipEventDisableTiming));
       CP2_HIP(ctx, hipEventCreateWithFlags(&hashed[b], hipEventDisableTiming));
@@ -360,7 +365,8 @@ struct IngestPipe {
   template <typename F> void parallel_ranges(size_t n, size_t grain, F f, size_t align = 1) {
     int nt = (int)std::min<size_t>((size_t)threads, std::max<size_t>(1, n / grain));
     if (nt <= 1 || !pool) { f(0, n); return; }
-    auto cut = [=](int t) { return t >= nt ? n : n * t / nt / align * align; };
+    const size_t units = n / align;                       // whole `align`-sized units are dealt out evenly (any align, not only powers of two)
+    auto cut = [=](int t) { return t >= nt ? n : units * t / nt * align; };
     for (int t = 1; t < nt; ++t) pool->submit([=] { f(cut(t), cut(t + 1)); });
     f(0, cut(1));
     pool->wait_idle();
@@ -457,13 +463,13 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
   int st = CP2_OK;
   {
     IngestPipe pipe;
-    st = pipe.init(ctx, cell_size, n_cells);
+    const bool want_direct = ctx->ingest_direct > 0 || (ctx->ingest_direct < 0 && env_size("CP2_INGEST_DIRECT", 0) != 0);
+    st = pipe.init(ctx, cell_size, n_cells, want_direct);
     LayerScheduler sched{t.get(), group, done};
     if (st == CP2_OK) st = sched.init();
     // O_DIRECT (cp2_set_ingest_direct / CP2_INGEST_DIRECT=1): slot files that are not in the page cache are read straight into
     // the pinned ring, block-aligned, without passing through (and evicting) the page cache.  Chunks then start on 4 KiB file
     // offsets (a whole number of `cell_multiple` cells); a file system that refuses O_DIRECT (tmpfs) is read buffered.
-    const bool want_direct = ctx->ingest_direct > 0 || (ctx->ingest_direct < 0 && env_size("CP2_INGEST_DIRECT", 0) != 0);
     if (want_direct) {
       size_t g = cell_size, h = IngestPipe::DIRECT_ALIGN;
       while (h) { size_t r = g % h; g = h; h = r; }               // gcd(cell_size, 4096)

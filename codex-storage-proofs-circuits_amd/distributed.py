@@ -29,6 +29,11 @@ class HipBackend:
         self.dataset = self.ctx.dataset(cfg, first, count)
         return self.dataset.local_roots()
 
+    def build_local(self, cfg, first, count):
+        """The trees of this rank's slots, roots left on the device (the device-to-device gather reads them there)."""
+        self.dataset = self.ctx.dataset(cfg, first, count) if count else None
+        return self.dataset
+
     def dataset_root(self, cfg, all_roots):
         if self.dataset is not None:
             self.dataset.set_roots(all_roots)
@@ -38,7 +43,8 @@ class HipBackend:
 
 def gather_slot_roots(local_roots, n_slots, rank, world, dist=None, device="cpu"):
     """All-gather the per-rank (count, 32) uint8 root arrays into the (n_slots, 32) array in slot order.
-    Shards may differ by one row, so rows are padded to the largest shard for the collective."""
+    Shards may differ by one row, so rows are padded to the largest shard for the collective.  HOST arrays in, host array
+    out: the path of the gloo / CPU tests; on GPUs use gather_slot_roots_dev (no host hop on either side)."""
     if world == 1 or dist is None:
         assert local_roots.shape[0] == n_slots
         return np.ascontiguousarray(local_roots)
@@ -57,10 +63,45 @@ def gather_slot_roots(local_roots, n_slots, rank, world, dist=None, device="cpu"
     return np.ascontiguousarray(np.concatenate(rows, axis=0))
 
 
+def gather_slot_roots_dev(dataset, ctx, n_slots, rank, world, dist, device):
+    """THE exchange step, device to device: the local roots are copied inside HBM (cp2_dataset_copy_local_roots_dev) into this
+    rank's row block of one device tensor, ONE all_gather_into_tensor (RCCL over xGMI) fills the other blocks in place, and the
+    (n_slots, 32) device tensor that comes back is what cp2_dataset_set_roots_dev takes -- no host copy of a root anywhere
+    (round 3 bounced device -> host -> device -> RCCL -> host -> device).  Shards may differ by one row: blocks are padded to
+    the largest shard for the collective and the gaps closed on the device."""
+    import torch
+    max_rows = (n_slots + world - 1) // world
+    gath = torch.zeros((world, max_rows, 32), dtype=torch.uint8, device=device)
+    if dataset is not None:
+        dataset.copy_local_roots_dev(gath[rank].data_ptr())
+        ctx.sync()                                        # the copy ran on the context's stream; the collective runs on torch's
+    if world > 1:
+        if dist.get_backend() == "nccl":                  # RCCL: device buffers straight over xGMI
+            dist.all_gather_into_tensor(gath.view(world * max_rows, 32), gath[rank].clone())
+        else:                                             # rehearsal on one GPU (gloo has no device all-gather): staged by hand
+            parts = [torch.empty((max_rows, 32), dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(parts, gath[rank].cpu())
+            gath = torch.stack(parts).to(device)
+    if n_slots % world == 0:
+        all_roots = gath.view(n_slots, 32)
+    else:
+        all_roots = torch.cat([gath[r, :shard_range(n_slots, r, world)[1]] for r in range(world)], dim=0).contiguous()
+    torch.cuda.synchronize(device)                        # the library reads the tensor on its own stream next
+    return all_roots
+
+
 def dataset_root_sharded(backend, cfg, rank, world, dist=None, device="cpu"):
-    """Returns (dataset_root (32,) uint8, all_roots (n_slots, 32) uint8, (first, count))."""
+    """Returns (dataset_root (32,) uint8, all_roots (n_slots, 32) uint8, (first, count)).
+    With a HipBackend on a CUDA/HIP device the gather is device to device; otherwise (the CPU tests' oracle-backed backend,
+    gloo rehearsals) it goes through host arrays."""
     n_slots = int(cfg.n_slots)
     first, count = shard_range(n_slots, rank, world)
+    on_device = isinstance(backend, HipBackend) and str(device).startswith("cuda")
+    if on_device and count:
+        backend.build_local(cfg, first, count)
+        all_dev = gather_slot_roots_dev(backend.dataset, backend.ctx, n_slots, rank, world, dist, device)
+        backend.dataset.set_roots_dev(all_dev.data_ptr())
+        return backend.dataset.root(), all_dev.cpu().numpy(), (first, count)
     local = backend.local_slot_roots(cfg, first, count)
     all_roots = gather_slot_roots(local, n_slots, rank, world, dist, device)
     return backend.dataset_root(cfg, all_roots), all_roots, (first, count)

@@ -88,26 +88,39 @@ inline int64_t checkPowerOfTwo(int64_t x, const std::string& what) {
 inline int64_t pow2(int k) { return int64_t(1) << k; }
 
 // ---- the engine -----------------------------------------------------------------------------------
+// Every GPU of the node behind one object (cp2_multi, include/codex_p2.h section e): the seam calls (hashCell, compress,
+// merkleTree, cellIndices ...) run on the first device's context, generateProofInputBN254 cuts the dataset's slots over all
+// devices.  Engine() takes every visible gfx950 device (the environment variable CODEX_P2_GPUS restricts it: "<count>" or an
+// index list); Engine(d) exactly device d.
 class Engine {
  public:
-  explicit Engine(int device = 0) {
-    int st = cp2_init(device, &ctx_);
-    if (st != CP2_OK) throw std::runtime_error(std::string("cp2_init: ") + cp2_strerror(st));
-  }
-  ~Engine() { cp2_free(ctx_); }
+  Engine() { init(nullptr, 0); }
+  explicit Engine(int device) { init(&device, 1); }
+  explicit Engine(const std::vector<int>& devices) { init(devices.data(), (int)devices.size()); }
+  ~Engine() { cp2_multi_free(multi_); }
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;
-  cp2_ctx* ctx() const { return ctx_; }
+  cp2_multi* multi() const { return multi_; }
+  cp2_ctx* ctx() const {
+    cp2_ctx* c = cp2_multi_ctx(multi_, 0);
+    if (!c) throw std::runtime_error(std::string("cp2_init: ") + cp2_strerror(CP2_ERR_NO_DEVICE));
+    return c;
+  }
   void check(int st, const char* what) const {
     if (st == CP2_OK) return;
     std::string msg = std::string(what) + ": " + cp2_strerror(st);
-    const char* d = cp2_last_error(ctx_);
+    const char* d = cp2_multi_last_error(multi_);
+    if (!d || !*d) d = cp2_last_error(cp2_multi_ctx(multi_, 0));
     if (d && *d) msg += std::string(" (") + d + ")";
     if (st == CP2_ERR_INVALID) throw AssertionDefect(msg);
     throw std::runtime_error(msg);
   }
  private:
-  cp2_ctx* ctx_ = nullptr;
+  void init(const int* devices, int n) {
+    int st = cp2_multi_init(devices, n, &multi_);
+    if (st != CP2_OK) throw std::runtime_error(std::string("cp2_init: ") + cp2_strerror(st));
+  }
+  cp2_multi* multi_ = nullptr;
 };
 
 // ---- types/bn254.nim:27-59 --------------------------------------------------------------------------
@@ -290,14 +303,16 @@ inline SlotProofInput generateProofInputBN254(Engine& e, const HashConfig& hashC
   doAssert(dsetCfg.nCells % cellsPerBlock(globCfg) == 0, "nblocks * cellsPerBlock == ncells");
   doAssert(slotIdx >= 0 && slotIdx < dsetCfg.nSlots, "slot index out of range");
   cp2_config cfg = toEngineConfig(globCfg, dsetCfg);
-  cp2_dataset* ds = nullptr;
+  // all slot trees (gen_input/bn254.nim:41-42), the slots cut over the engine's devices; one gather of the slot roots and
+  // the dataset tree (:49-51) on every device; the proof input comes from the device that holds slotIdx
+  cp2_multi_dataset* ds = nullptr;
   // optional tree cache (not in the reference, which recomputes every tree on every run): CODEX_P2_CACHE=<file>
   const char* cache = std::getenv("CODEX_P2_CACHE");
-  if (cache && *cache) e.check(cp2_dataset_build_cached(e.ctx(), &cfg, 0, cfg.n_slots, cache, &ds), "buildSlotTree (cached)");
-  else e.check(cp2_dataset_build(e.ctx(), &cfg, 0, cfg.n_slots, &ds), "buildSlotTree (all slots)");
-  std::shared_ptr<cp2_dataset> ds_guard(ds, cp2_dataset_free);
+  if (cache && *cache) e.check(cp2_multi_dataset_build_cached(e.multi(), &cfg, cache, &ds), "buildSlotTree (cached)");
+  else e.check(cp2_multi_dataset_build(e.multi(), &cfg, &ds), "buildSlotTree (all slots)");
+  std::shared_ptr<cp2_multi_dataset> ds_guard(ds, cp2_multi_dataset_free);
   cp2_proof_input* pi = nullptr;
-  e.check(cp2_proof_input_generate(ds, (uint64_t)slotIdx, entropy.data(), &pi), "generateProofInput");
+  e.check(cp2_multi_proof_input_generate(ds, (uint64_t)slotIdx, entropy.data(), &pi), "generateProofInput");
   SlotProofInput out;
   std::shared_ptr<cp2_proof_input> pi_guard(pi, cp2_proof_input_free);   // `out` is a plain value, as in the reference
   cp2_proof_input_roots(pi, out.dataSetRoot.data(), out.slotRoot.data(), out.entropy.data());

@@ -19,6 +19,8 @@ type
   Cp2Ctx = distinct pointer
   Cp2Dataset = distinct pointer
   Cp2ProofInput = distinct pointer
+  Cp2Multi = distinct pointer          ## every GPU of the node behind one handle (include/codex_p2.h section e)
+  Cp2MultiDataset = distinct pointer
   Cp2Config* {.bycopy.} = object
     maxDepth*, maxLog2NSlots*: int32
     cellSize*, blockSize*, nSlots*, nCells*, nSamples*, seed*: uint64
@@ -65,20 +67,41 @@ proc cp2_proof_input_create(cfg: ptr Cp2Config, slotIdx: uint64, datasetRoot, en
                             nSamples: csize_t, cellIndices: ptr uint64, cellData, merklePaths, leafHashes: ptr byte,
                             p: ptr Cp2ProofInput): cint {.importc.}
 proc cp2_write_circom_main(cfg: ptr Cp2Config, path: cstring): cint {.importc.}
+proc cp2_multi_init(devices: ptr cint, nDev: cint, m: ptr Cp2Multi): cint {.importc.}
+proc cp2_multi_free(m: Cp2Multi) {.importc.}
+proc cp2_multi_count(m: Cp2Multi): cint {.importc.}
+proc cp2_multi_ctx(m: Cp2Multi, i: cint): Cp2Ctx {.importc.}
+proc cp2_multi_last_error(m: Cp2Multi): cstring {.importc.}
+proc cp2_multi_gather_mode(m: Cp2Multi): cstring {.importc.}
+proc cp2_multi_set_policy(m: Cp2Multi, gather: cint, minCellsPerDevice: uint64): cint {.importc.}
+proc cp2_multi_dataset_build(m: Cp2Multi, cfg: ptr Cp2Config, ds: ptr Cp2MultiDataset): cint {.importc.}
+proc cp2_multi_dataset_build_streamed(m: Cp2Multi, cfg: ptr Cp2Config, entropy: ptr byte, threads: cint, groupSlots: csize_t,
+                                      ds: ptr Cp2MultiDataset): cint {.importc.}
+proc cp2_multi_dataset_free(ds: Cp2MultiDataset) {.importc.}
+proc cp2_multi_dataset_shards(ds: Cp2MultiDataset): cint {.importc.}
+proc cp2_multi_proof_input_generate(ds: Cp2MultiDataset, slotIdx: uint64, entropy: ptr byte, p: ptr Cp2ProofInput): cint {.importc.}
+proc cp2_multi_dataset_export_streamed(ds: Cp2MultiDataset, dir: cstring, threads: cint, totalBytes: ptr uint64): cint {.importc.}
 {.pop.}
 
-var gCtx: Cp2Ctx
+var gMulti: Cp2Multi
+
+proc multi(): Cp2Multi =
+  ## one engine per process over EVERY visible GPU (the reference is single threaded, cli.nim:208-237): the seam calls run on
+  ## the first device's context, generateProofInput cuts the dataset's slots over all of them.  The environment variable
+  ## CODEX_P2_GPUS ("<count>" or an index list) restricts the devices; nothing in cli.nim changes.
+  if pointer(gMulti) == nil:
+    let st = cp2_multi_init(nil, 0, addr gMulti)
+    if st != 0: raiseAssert("cp2_multi_init: " & $cp2_strerror(st))
+  gMulti
 
 proc ctx(): Cp2Ctx =
-  ## one engine context per process (the reference is single threaded, cli.nim:208-237)
-  if pointer(gCtx) == nil:
-    let st = cp2_init(0, addr gCtx)
-    if st != 0: raiseAssert("cp2_init: " & $cp2_strerror(st))
-  gCtx
+  let c = cp2_multi_ctx(multi(), 0)
+  if pointer(c) == nil: raiseAssert("cp2_init: " & $cp2_strerror(-2))
+  c
 
 proc check(st: cint, what: string) =
   ## nothing aborts across the C ABI; keep the reference's behaviour (assert -> AssertionDefect) on this side
-  if st != 0: raiseAssert(what & ": " & $cp2_strerror(st) & " " & $cp2_last_error(ctx()))
+  if st != 0: raiseAssert(what & ": " & $cp2_strerror(st) & " " & $cp2_multi_last_error(multi()) & " " & $cp2_last_error(ctx()))
 
 # Empty inputs are legal at the seam (nim-poseidon2 hashes the padding of an empty sequence, and so does the C ABI when
 # the length is 0), but `unsafeAddr a[0]` of an empty openArray raises IndexDefect: hand the engine a valid dummy address.
@@ -166,14 +189,15 @@ proc felt(p: ptr UncheckedArray[byte], i: int): F =
   for k in 0 ..< 32: result[k] = p[32 * i + k]
 
 proc engineGenerateProofInput*(cfg: var Cp2Config, slotIdx: int, entropy: F): EngineProofInput =
-  ## every slot tree built once on the GPU, then sampling + paths + cells for `slotIdx`
+  ## every slot tree built once, the slots cut over all GPUs of the node (one device-to-device gather of the slot roots,
+  ## the dataset tree on every device), then sampling + paths + cells for `slotIdx` on the device that holds it
   ## (the whole of gen_input/bn254.nim:35-74)
-  var ds: Cp2Dataset
-  check(cp2_dataset_build(ctx(), addr cfg, 0, cfg.nSlots, addr ds), "cp2_dataset_build")
-  defer: cp2_dataset_free(ds)
+  var ds: Cp2MultiDataset
+  check(cp2_multi_dataset_build(multi(), addr cfg, addr ds), "cp2_multi_dataset_build")
+  defer: cp2_multi_dataset_free(ds)
   var p: Cp2ProofInput
   var e = entropy
-  check(cp2_proof_input_generate(ds, uint64(slotIdx), addr e[0], addr p), "cp2_proof_input_generate")
+  check(cp2_multi_proof_input_generate(ds, uint64(slotIdx), addr e[0], addr p), "cp2_multi_proof_input_generate")
   defer: cp2_proof_input_free(p)
   check(cp2_proof_input_roots(p, addr result.dataSetRoot[0], addr result.slotRoot[0], addr result.entropy[0]), "cp2_proof_input_roots")
   let ns = int(cp2_proof_input_nsamples(p))
@@ -249,11 +273,23 @@ proc writeCircomMainComponentP2*(cfg: var Cp2Config, fname: string) =
 proc engineExportAllProofInputs*(cfg: var Cp2Config, entropy: F, dir: string, threads: int = 8): uint64 =
   ## every slot's input.json ("<dir>/input_<slot>.json") in ONE overlapped pass (no reference counterpart: the reference makes
   ## one proof input per run): gen_input/bn254.nim:35-79 + json/bn254.nim:57-78 for all slots, trees built once
-  var ds: Cp2Dataset
+  var ds: Cp2MultiDataset
   var e = entropy
-  check(cp2_dataset_build_streamed(ctx(), addr cfg, 0, cfg.nSlots, addr e[0], cint(threads), 0, addr ds), "cp2_dataset_build_streamed")
-  defer: cp2_dataset_free(ds)
-  check(cp2_dataset_export_streamed(ds, cstring(dir), cint(threads), addr result), "cp2_dataset_export_streamed")
+  check(cp2_multi_dataset_build_streamed(multi(), addr cfg, addr e[0], cint(threads), 0, addr ds), "cp2_multi_dataset_build_streamed")
+  defer: cp2_multi_dataset_free(ds)
+  check(cp2_multi_dataset_export_streamed(ds, cstring(dir), cint(threads), addr result), "cp2_multi_dataset_export_streamed")
+
+proc engineDevices*(): int =
+  ## how many devices the engine holds
+  int(cp2_multi_count(multi()))
+
+proc engineGatherMode*(): string =
+  ## what the last build's exchange of slot roots went through: "rccl (...)", "host (<why>)", "none (one shard ...)"
+  $cp2_multi_gather_mode(multi())
+
+proc engineSetPolicy*(gather: int, minCellsPerDevice: uint64) =
+  ## 0 auto / 1 RCCL / 2 host gather; cells of hashing a device must have to get a shard (0: one hash-kernel residency)
+  check(cp2_multi_set_policy(multi(), cint(gather), minCellsPerDevice), "cp2_multi_set_policy")
 
 proc engineTrim*() =
   ## give the engine's cached device / pinned scratch back to the system (a long-lived process between runs)

@@ -1,6 +1,8 @@
 ## OVERLAY of reference/nim/proof_input/src/gen_input/bn254.nim: generateProofInputBN254 with the reference's own
 ## signature and result type, computed by the MI355X engine (every slot tree built ONCE; the reference builds all of
-## them and then the proving slot's again per sample, gen_input/bn254.nim:42,57).  cli.nim needs no change.
+## them and then the proving slot's again per sample, gen_input/bn254.nim:42,57) on EVERY GPU of the node: the slots are cut
+## into contiguous ranges, one per device, the slot roots gathered device to device (RCCL over xGMI) and the dataset tree
+## built on every device (cp2_multi_*, include/codex_p2.h section e).  cli.nim needs no change.
 ## Uncompiled (no Nim toolchain in the build image); mechanical by design.
 import ../types
 import ../types/bn254

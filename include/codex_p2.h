@@ -73,9 +73,11 @@ int cp2_set_ingest_direct(cp2_ctx* ctx, int on);
 int cp2_trim(cp2_ctx* ctx);
 /* Host memory of the streamed proof-input path (cp2_dataset_build_streamed): the JSON body of every local slot (about 0.7 MB
  * at nSamples = 100, cellSize = 2048) is kept until the dataset is freed.  Bodies beyond `max_resident_bytes` per dataset are
- * written to "<spill_dir>/cp2_body_<pid>_<dataset>_<slot>.part" instead and read back by cp2_dataset_export_streamed /
- * cp2_dataset_streamed_json; the files are removed by cp2_dataset_free.  Defaults: 4 GiB (environment CP2_BODY_BUDGET_MB),
- * spill_dir NULL = $TMPDIR or /tmp.  max_resident_bytes = 0 keeps the current budget; (size_t)-1 = never spill. */
+ * written to files instead and read back by cp2_dataset_export_streamed / cp2_dataset_streamed_json.  The files hold sampled
+ * cell data: they live in a private directory "<spill_dir>/cp2_bodies_XXXXXX" made by mkdtemp (mode 0700), each created with
+ * O_EXCL | O_NOFOLLOW and mode 0600; files and directory are removed by cp2_dataset_free.  Defaults: 4 GiB (environment
+ * CP2_BODY_BUDGET_MB), spill_dir NULL = $TMPDIR or /tmp.  max_resident_bytes = 0 keeps the current budget; (size_t)-1 = never
+ * spill.  A spill that fails is CP2_ERR_IO with the path in cp2_last_error. */
 int cp2_set_body_budget(cp2_ctx* ctx, size_t max_resident_bytes, const char* spill_dir);
 
 /* ---- a1: Poseidon2 t=3 permutation --------------------------------------------------------- */
@@ -206,7 +208,18 @@ int cp2_dataset_local_roots(cp2_dataset* ds, uint8_t* out);
 /* Supply the roots of ALL n_slots slots (after the multi-GPU gather; single GPU: pass NULL to use the
  * local ones) and build the dataset-level tree on the GPU. */
 int cp2_dataset_set_roots(cp2_dataset* ds, const uint8_t* all_roots);
+/* The same exchange without host copies of the roots (the gather of SURVEY.md 8e is device to device: RCCL, a torch tensor):
+ * cp2_dataset_local_roots_dev = device pointer to the n_local x 32 bytes of local roots (valid until the dataset is freed);
+ * cp2_dataset_copy_local_roots_dev ENQUEUES a device-to-device copy of them into the caller's buffer on the context's stream
+ * (cp2_sync before another stream reads it); cp2_dataset_set_roots_dev takes ALL n_slots roots in device memory (16-byte
+ * aligned, any device of the node), builds the dataset tree from them and synchronises. */
+const void* cp2_dataset_local_roots_dev(const cp2_dataset* ds);
+int cp2_dataset_copy_local_roots_dev(cp2_dataset* ds, void* d_out);
+int cp2_dataset_set_roots_dev(cp2_dataset* ds, const void* d_all_roots);
 int cp2_dataset_root(cp2_dataset* ds, uint8_t out[32]);
+/* the slot range and the context a dataset was built with */
+int cp2_dataset_range(const cp2_dataset* ds, uint64_t* first_slot, uint64_t* n_local);
+cp2_ctx* cp2_dataset_ctx(const cp2_dataset* ds);
 
 /* SlotProofInput, reference/nim/proof_input/src/types.nim:52-60 */
 typedef struct cp2_proof_input cp2_proof_input;
@@ -268,6 +281,62 @@ int cp2_dataset_export_streamed(cp2_dataset* ds, const char* dir, int threads, u
 int cp2_dataset_streamed_json(cp2_dataset* ds, uint64_t slot_idx, char** text, size_t* len);
 /* replaces `writeCircomMainComponent`, reference/nim/proof_input/src/cli.nim:186-204 */
 int cp2_write_circom_main(const cp2_config* cfg, const char* path);
+
+/* ---- e: every GPU of the node behind one handle ------------------------------------------------------ */
+/* `generateProofInput` hashes every slot of the dataset before it proves one (reference/nim/proof_input/src/gen_input/
+ * bn254.nim:41-42), and slots are independent until the dataset tree (:49-51).  A cp2_multi holds one context per device;
+ * a dataset built through it is cut into contiguous slot ranges (cp2_shard_range: the first n mod world ranges hold one
+ * slot more), each device builds its range on its own host thread with no communication, then ONE exchange -- an all-gather
+ * of the 32-byte slot roots, device to device (RCCL over xGMI: in-place ncclAllGather on every context's stream) -- and
+ * every device builds the identical dataset tree and serves the proof inputs of its own slots.  One process, no launcher:
+ * the caller makes the same calls on a one-GPU and on an eight-GPU node.
+ *   - librccl is opened at run time, and only when at least two distinct devices hold a shard.  Without it, or when a device
+ *     index repeats (two contexts on one device), the roots are gathered through host memory instead (1 MiB at 32 768 slots);
+ *     cp2_multi_gather_mode names what the last build did ("rccl (...)", "host (<why>)", "none (one shard ...)").
+ *   - Small datasets use fewer devices: a device gets a shard only when there is at least `min_cells_per_device` cells of
+ *     hashing for it (default: one residency of the hash kernel, 768 x 256 cells -- a device with less finishes no sooner),
+ *     so the reference's default run (11 slots x 512 cells, workflow/params.sh) stays on one GPU and pays one context.
+ *   - Contexts are created on first use; cp2_multi_ctx(m, i) hands one out for the seam calls and the tuning knobs. */
+typedef struct cp2_multi cp2_multi;
+typedef struct cp2_multi_dataset cp2_multi_dataset;
+enum { CP2_GATHER_AUTO = 0, CP2_GATHER_RCCL = 1, CP2_GATHER_HOST = 2 };
+/* devices: n_dev HIP device indices (an index may repeat: several contexts on one device).  n_dev = 0: the environment
+ * variable CODEX_P2_GPUS ("<count>" = the first <count> visible devices, or a comma-separated index list), else every
+ * visible gfx950 device. */
+int cp2_multi_init(const int* devices, int n_dev, cp2_multi** out);
+void cp2_multi_free(cp2_multi* m);
+int cp2_multi_count(const cp2_multi* m);
+int cp2_multi_device(const cp2_multi* m, int i);          /* HIP device index of entry i, -1 out of range */
+cp2_ctx* cp2_multi_ctx(cp2_multi* m, int i);              /* NULL when the device is unusable            */
+const char* cp2_multi_last_error(const cp2_multi* m);
+const char* cp2_multi_gather_mode(const cp2_multi* m);
+/* gather: CP2_GATHER_AUTO (RCCL when possible, else host), CP2_GATHER_RCCL (fail with CP2_ERR_INVALID when impossible),
+ * CP2_GATHER_HOST.  min_cells_per_device: 0 = the default above (or the environment variable CODEX_P2_MIN_CELLS, read by
+ * cp2_multi_init); 1 = always spread over every device. */
+int cp2_multi_set_policy(cp2_multi* m, int gather, uint64_t min_cells_per_device);
+/* the split rule: contiguous ranges, the first (n_items mod world) ranks hold one item more */
+void cp2_shard_range(uint64_t n_items, int rank, int world, uint64_t* first, uint64_t* count);
+/* cp2_dataset_build / _build_cached / _build_streamed for ALL cfg->n_slots slots over the devices of `m`, including the
+ * exchange and the dataset tree on every device.  Cached: shard i of n uses "<cache_path>.shard<i>of<n>" (one shard: the path
+ * itself).  Streamed: `threads` formatting threads in total, divided over the shards. */
+int cp2_multi_dataset_build(cp2_multi* m, const cp2_config* cfg, cp2_multi_dataset** out);
+int cp2_multi_dataset_build_cached(cp2_multi* m, const cp2_config* cfg, const char* cache_path, cp2_multi_dataset** out);
+int cp2_multi_dataset_build_streamed(cp2_multi* m, const cp2_config* cfg, const uint8_t entropy[32], int threads, size_t group_slots,
+                                     cp2_multi_dataset** out);
+void cp2_multi_dataset_free(cp2_multi_dataset* mds);
+int cp2_multi_dataset_shards(const cp2_multi_dataset* mds);
+/* shard i: its dataset (owned by mds; every single-dataset call works on it), device index and slot range */
+cp2_dataset* cp2_multi_dataset_shard(cp2_multi_dataset* mds, int i, int* device, uint64_t* first_slot, uint64_t* n_local);
+int cp2_multi_dataset_root(cp2_multi_dataset* mds, uint8_t out[32]);
+int cp2_multi_dataset_slot_roots(cp2_multi_dataset* mds, uint8_t* out /* n_slots x 32 */);
+/* replaces `generateProofInputBN254`, gen_input/bn254.nim:35-79, on whichever device holds `slot_idx` */
+int cp2_multi_proof_input_generate(cp2_multi_dataset* mds, uint64_t slot_idx, const uint8_t entropy[32], cp2_proof_input** out);
+/* cp2_dataset_export_proof_inputs / _export_streamed / _streamed_json over all shards (every device works through its own
+ * slots concurrently; `threads` host threads in total) */
+int cp2_multi_dataset_export_proof_inputs(cp2_multi_dataset* mds, const uint64_t* slot_idx, size_t n, const uint8_t entropy[32],
+                                          const char* dir, int threads, size_t batch, uint64_t* total_bytes);
+int cp2_multi_dataset_export_streamed(cp2_multi_dataset* mds, const char* dir, int threads, uint64_t* total_bytes);
+int cp2_multi_dataset_streamed_json(cp2_multi_dataset* mds, uint64_t slot_idx, char** text, size_t* len);
 
 #ifdef __cplusplus
 }

@@ -45,6 +45,7 @@ def lib():
             "p2o_gen_fake_cell": (None, [u64, u64, sz, u8p]),
             "p2o_slot_seed": (u64, [u64, u64]),
             "p2o_fake_slot_root": (None, [u64, sz, sz, sz, u8p, i32]),
+            "p2o_fake_slot_block_roots": (None, [u64, sz, sz, sz, u8p, i32]),
             "p2o_cell_index": (u64, [u8p, u8p, u64, u64]),
         }
         for name, (res, args) in sigs.items():
@@ -173,6 +174,13 @@ def slot_seed(seed, slot_idx):
 def fake_slot_root(slot_seed_, cell_size, block_size, n_cells, threads=1):
     out = np.empty(32, dtype=np.uint8)
     lib().p2o_fake_slot_root(slot_seed_, cell_size, block_size, n_cells, _ptr(out), threads)
+    return out
+
+
+def fake_slot_block_roots(slot_seed_, cell_size, block_size, n_cells, threads=1):
+    """(n_cells / cellsPerBlock, 32) uint8: the root of every block tree of a fake-data slot."""
+    out = np.empty((n_cells // (block_size // cell_size), 32), dtype=np.uint8)
+    lib().p2o_fake_slot_block_roots(slot_seed_, cell_size, block_size, n_cells, _ptr(out), threads)
     return out
 
 

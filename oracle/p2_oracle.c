@@ -402,6 +402,21 @@ static void slot_block_range(void* c, size_t lo, size_t hi) {
   free(cell); free(leaves); free(layers);
 }
 
+/* the block roots of a fake-data slot (blocks/bn254.nim:60-67 per block): n_cells / cellsPerBlock x 32 bytes.  What a
+ * full-size fixture generator needs beside the root: the tree over them gives the top part of every Merkle path, and only
+ * the sampled cells' own blocks have to be regenerated for the bottom part. */
+void p2o_fake_slot_block_roots(uint64_t slot_seed, size_t cell_size, size_t block_size, size_t n_cells,
+                               uint8_t* out, int threads) {
+  ensure_init();
+  size_t cpb = block_size / cell_size;
+  size_t nblocks = n_cells / cpb;
+  fr* roots = (fr*)malloc(sizeof(fr) * nblocks);
+  slot_ctx c = {slot_seed, cell_size, cpb, roots};
+  run_ranges(slot_block_range, &c, nblocks, threads);
+  for (size_t b = 0; b < nblocks; ++b) fr_to_bytes(out + 32 * b, &roots[b]);
+  free(roots);
+}
+
 void p2o_fake_slot_root(uint64_t slot_seed, size_t cell_size, size_t block_size, size_t n_cells,
                         uint8_t out[32], int threads) {
   ensure_init();

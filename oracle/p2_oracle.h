@@ -59,6 +59,10 @@ uint64_t p2o_slot_seed(uint64_t seed, uint64_t slot_idx);
 void p2o_fake_slot_root(uint64_t slot_seed, size_t cell_size, size_t block_size, size_t n_cells,
                         uint8_t out[32], int threads);
 
+/* the same slot's block roots (blocks/bn254.nim:60-67), n_cells / cellsPerBlock x 32 bytes */
+void p2o_fake_slot_block_roots(uint64_t slot_seed, size_t cell_size, size_t block_size, size_t n_cells,
+                               uint8_t* out, int threads);
+
 /* sample/bn254.nim:16-24 */
 uint64_t p2o_cell_index(const uint8_t entropy[32], const uint8_t slot_root[32], uint64_t n_cells, uint64_t counter);
 

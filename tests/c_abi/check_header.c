@@ -24,6 +24,26 @@ int main(void) {
       cp2_set_ingest_direct(NULL, 1) != CP2_ERR_INVALID || cp2_set_ingest(NULL, 1, 2, 3) != CP2_ERR_INVALID) return 9;
   if (cp2_slot_trees_load(NULL, "/nonexistent", NULL) != CP2_ERR_INVALID || cp2_slot_trees_save(NULL, "/tmp/x") != CP2_ERR_INVALID) return 10;
   if (cp2_dataset_export_streamed(NULL, NULL, 1, NULL) != CP2_ERR_INVALID || cp2_dataset_streamed_json(NULL, 0, NULL, NULL) != CP2_ERR_INVALID) return 11;
+  /* section e (several GPUs behind one handle): the split rule is plain arithmetic; handles refuse NULL */
+  {
+    uint64_t first = 99, count = 99, covered = 0;
+    int r;
+    for (r = 0; r < 3; ++r) {
+      cp2_shard_range(32767, r, 3, &first, &count);
+      if (first != covered || count != (r < 1 ? 10923u : 10922u)) return 12;
+      covered += count;
+    }
+    if (covered != 32767) return 13;
+    cp2_shard_range(5, 7, 3, &first, &count);
+    if (first != 0 || count != 0) return 14;
+  }
+  if (cp2_multi_init(NULL, -1, NULL) != CP2_ERR_INVALID || cp2_multi_count(NULL) != 0 || cp2_multi_ctx(NULL, 0) != NULL ||
+      cp2_multi_set_policy(NULL, CP2_GATHER_AUTO, 0) != CP2_ERR_INVALID || cp2_multi_device(NULL, 0) != -1) return 15;
+  if (cp2_multi_dataset_build(NULL, &cfg, NULL) != CP2_ERR_INVALID || cp2_multi_dataset_shards(NULL) != 0 ||
+      cp2_multi_proof_input_generate(NULL, 0, data, NULL) != CP2_ERR_INVALID ||
+      cp2_multi_dataset_export_streamed(NULL, NULL, 1, NULL) != CP2_ERR_INVALID) return 16;
+  if (cp2_dataset_set_roots_dev(NULL, NULL) != CP2_ERR_INVALID || cp2_dataset_copy_local_roots_dev(NULL, NULL) != CP2_ERR_INVALID ||
+      cp2_dataset_local_roots_dev(NULL) != NULL || cp2_dataset_ctx(NULL) != NULL || cp2_dataset_range(NULL, NULL, NULL) != CP2_ERR_INVALID) return 17;
   printf("c abi ok\n");
   return 0;
 }

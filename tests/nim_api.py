@@ -47,7 +47,8 @@ def public_api(text):
 
 
 # ---- C header ---------------------------------------------------------------------------------------------------
-HANDLES = {"cp2_ctx": "ctx", "cp2_dataset": "dataset", "cp2_proof_input": "proof_input", "cp2_slot_trees": "slot_trees"}
+HANDLES = {"cp2_ctx": "ctx", "cp2_dataset": "dataset", "cp2_proof_input": "proof_input", "cp2_slot_trees": "slot_trees",
+           "cp2_multi": "multi", "cp2_multi_dataset": "multi_dataset"}
 
 
 def c_type_class(t, array=False):
@@ -113,7 +114,8 @@ def header_config_fields(text):
 
 
 # ---- Nim binding ------------------------------------------------------------------------------------------------
-NIM_HANDLES = {"Cp2Ctx": "ctx", "Cp2Dataset": "dataset", "Cp2ProofInput": "proof_input", "Cp2SlotTrees": "slot_trees"}
+NIM_HANDLES = {"Cp2Ctx": "ctx", "Cp2Dataset": "dataset", "Cp2ProofInput": "proof_input", "Cp2SlotTrees": "slot_trees",
+               "Cp2Multi": "multi", "Cp2MultiDataset": "multi_dataset"}
 
 
 def nim_type_class(t):

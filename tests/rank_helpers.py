@@ -16,9 +16,10 @@ def free_port():
     return p
 
 
-def run_ranks(world, cfg, entropy, tmp_path, roots_path=None, timeout=900):
-    """`world` fresh processes on GPU 0 (gloo collectives: RCCL refuses two ranks per device); returns their result dicts."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(world))
+def run_ranks(world, cfg, entropy, tmp_path, roots_path=None, timeout=900, gather="dev"):
+    """`world` fresh processes on GPU 0 (gloo collectives: RCCL refuses two ranks per device); returns their result dicts.
+    gather: "dev" = the roots stay on the device on both sides of the exchange, "host" = host arrays (round 3's path)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(world), CP2_TEST_GATHER=gather)
     procs, outs = [], []
     for r in range(world):
         out = str(tmp_path / ("rank%d_of%d.json" % (r, world)))

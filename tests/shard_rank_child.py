@@ -28,7 +28,10 @@ def main():
     ctx = pkg.Context(gpu)
     cfg = pkg.make_config(**cfg_json)
     backend = d.HipBackend(pkg, ctx)
-    root, all_roots, (first, count) = d.dataset_root_sharded(backend, cfg, rank, world, dist if world > 1 else None, "cpu")
+    # CP2_TEST_GATHER=host: host arrays through the collective (round 3's path); default: the roots stay in HBM on both sides
+    # of the exchange (cp2_dataset_copy_local_roots_dev -> collective -> cp2_dataset_set_roots_dev)
+    where = "cpu" if os.environ.get("CP2_TEST_GATHER") == "host" else "cuda:%d" % gpu
+    root, all_roots, (first, count) = d.dataset_root_sharded(backend, cfg, rank, world, dist if world > 1 else None, where)
     if roots_path and rank == 0:
         import numpy as np
         np.save(roots_path, all_roots)

@@ -80,16 +80,28 @@ def test_circom_main_text(pkg, golden, tmp_path):
 
 
 def test_shard_ranges_cover_everything(entry):
+    """distributed.shard_range (one process per GPU) and cp2_shard_range (one process, cp2_multi) are the same rule."""
     import importlib
-    entry.load_package()
+    pkg = entry.load_package()
     d = importlib.import_module("codex_storage_proofs_circuits_amd.distributed")
-    for n in (1, 7, 8, 11, 4096, 32768):
+    for n in (1, 7, 8, 11, 4096, 32767, 32768):
         for world in (1, 2, 3, 8):
             got = []
             for r in range(world):
                 f, c = d.shard_range(n, r, world)
+                assert (f, c) == pkg.shard_range(n, r, world)
                 got += list(range(f, f + c))
             assert got == list(range(n))
+
+
+def test_multi_handle_fails_loudly_without_a_gpu(pkg):
+    """cp2_multi_init: no device, no handle (no CPU fallback behind the multi-GPU entry points either)."""
+    if _have_gpu():
+        pytest.skip("GPU present")
+    for devices in (None, [0], [0, 0]):
+        with pytest.raises(pkg.CodexP2Error) as e:
+            pkg.Multi(devices)
+        assert e.value.status == -2
 
 
 def test_header_is_plain_c99_and_links(pkg, tmp_path):
@@ -166,9 +178,9 @@ def test_bench_self_spawn_fails_fast_without_gpus(tmp_path):
     if _have_gpu():
         pytest.skip("GPU present")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    before = set(glob.glob("/tmp/cp2_bench_rdv_*"))
     t = time.time()
+    # a private TMPDIR: tempfile.mkdtemp honours it, so the rendezvous directory can only appear (and must disappear) here
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                       capture_output=True, text=True, timeout=240)
+                       capture_output=True, text=True, timeout=240, env=dict(os.environ, TMPDIR=str(tmp_path)))
     assert r.returncode == 1 and r.stdout == "" and time.time() - t < 120
-    assert set(glob.glob("/tmp/cp2_bench_rdv_*")) == before
+    assert glob.glob(str(tmp_path / "cp2_bench_rdv_*")) == []

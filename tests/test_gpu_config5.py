@@ -30,12 +30,14 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-@pytest.mark.parametrize("name,world", [("cheap", 1), ("cheap", 2), ("cheap", 3), ("odd", 2)])
-def test_config5_dataset_scale_sharded_ranks_vs_oracle_fixture(golden, tmp_path, name, world):
-    """32 768 (and 32 767: every dataset-tree layer odd) slots over 1, 2 and 3 rank processes (3: 10 923 + 10 923 + 10 922)."""
+@pytest.mark.parametrize("name,world,gather", [("cheap", 1, "dev"), ("cheap", 2, "dev"), ("cheap", 3, "dev"), ("odd", 2, "dev"), ("odd", 3, "host")])
+def test_config5_dataset_scale_sharded_ranks_vs_oracle_fixture(golden, tmp_path, name, world, gather):
+    """32 768 (and 32 767: every dataset-tree layer odd) slots over 1, 2 and 3 rank processes (3: 10 923 + 10 923 + 10 922).
+    "dev": the slot roots never leave HBM on either side of the exchange (cp2_dataset_copy_local_roots_dev ->
+    collective -> cp2_dataset_set_roots_dev); "host": host arrays on both sides (cp2_dataset_local_roots / _set_roots)."""
     g = golden("config5.json")[name]
     c, n = g["config"], g["config"]["nSlots"]
-    res = run_ranks(world, c, g["entropy"], tmp_path)
+    res = run_ranks(world, c, g["entropy"], tmp_path, gather=gather)
     covered, checked = [], 0
     for r in res:
         assert r["native_so_loaded"] and not r["oracle_loaded"]            # the product path, not the checker
@@ -72,7 +74,7 @@ def test_config5_scaled_world1_in_process(pkg, ctx, oracle, golden, entry, tmp_p
     c = SCALED
     cfg = pkg.make_config(**c)
     backend = d.HipBackend(pkg, ctx)
-    root, all_roots, (first, count) = d.dataset_root_sharded(backend, cfg, 0, 1)
+    root, all_roots, (first, count) = d.dataset_root_sharded(backend, cfg, 0, 1, None, "cuda:0")
     assert (first, count) == (0, c["nSlots"]) and all_roots.shape == (c["nSlots"], 32)
     rng = np.random.default_rng(5)
     _check_roots_against_oracle(C, c, all_roots, [0, 16383, 16384, 32767] + list(rng.integers(0, c["nSlots"], size=60)))
@@ -101,7 +103,8 @@ def test_config5_scaled_world1_in_process(pkg, ctx, oracle, golden, entry, tmp_p
     ctx.set_body_budget(64 << 20, str(spill))
     try:
         sd = ctx.dataset_streamed(cfg, ENTROPY, s0, sn, threads=_threads())
-        n_parts = len([f for f in os.listdir(spill) if f.endswith(".part")])
+        (private,) = os.listdir(spill)                                 # one mkdtemp directory, mode 0700
+        n_parts = len([f for f in os.listdir(spill / private) if f.endswith(".part")])
         assert 850 < n_parts < 1000                                    # 0.7 MB each: about 90 stay resident
         assert np.array_equal(sd.local_roots(), all_roots[s0:s0 + sn])
         sd.set_roots(all_roots)

@@ -1,0 +1,258 @@
+"""GPU suite, round 4 (-m gpu): several GPUs of one node behind ONE handle of the C ABI (cp2_multi_*, include/codex_p2.h section e):
+one process, one host thread + one context per device, contiguous slot ranges, ONE exchange of slot roots, the dataset tree on
+every device, proof inputs routed to the owning device (reference/nim/proof_input/src/gen_input/bn254.nim:41-51,72;
+workflow/prove.sh:26).
+
+A one-GPU box cannot hold two distinct devices, so the two branches of the exchange are exercised like this:
+  devices [0]        RCCL asked for by name: a communicator of one rank, in-place ncclAllGather, cp2_dataset_set_roots_dev
+  devices [0, 0]     two (three) contexts on device 0: the host-gather branch ("a device holds more than one shard")
+Everything is compared with oracle-only fixtures (tests/golden/config5.json, proof_inputs.json, bigslots.json) or with the
+C oracle + Python restatement directly."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle_helpers import expected_proof_input_fast
+from rank_helpers import run_ranks
+
+pytestmark = pytest.mark.gpu
+
+
+def hexroot(a):
+    return np.asarray(a, dtype=np.uint8).tobytes()[::-1].hex()
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def tsha(text):
+    return hashlib.sha256(text.encode()).hexdigest()
+
+
+def _threads():
+    return max(1, min(16, len(os.sched_getaffinity(0))))
+
+
+@pytest.mark.parametrize("name,devices,gather", [("cheap", [0], "rccl"), ("cheap", [0, 0], "auto"), ("odd", [0, 0], "auto"),
+                                                  ("odd", [0, 0, 0], "host"), ("cheap", [0], "auto")])
+def test_multi_dataset_at_config5_scale_vs_oracle_fixture(pkg, golden, name, devices, gather):
+    """32 768 / 32 767 slots (maxLog2NSlots = 15) through cp2_multi_dataset_build: sha256 over all slot roots, the dataset
+    root as EVERY shard's device computed it, input.json byte-exact (sha256 of the oracle's text) on every shard edge."""
+    g = golden("config5.json")[name]
+    c, n = g["config"], g["config"]["nSlots"]
+    cfg = pkg.make_config(**c)
+    m = pkg.Multi(devices)
+    assert m.count == len(devices) and m.devices() == devices
+    m.set_policy({"auto": pkg.GATHER_AUTO, "rccl": pkg.GATHER_RCCL, "host": pkg.GATHER_HOST}[gather], 0)
+    ds = m.dataset(cfg)
+    shards = ds.shards()
+    world = len(devices)
+    assert [(f, k) for _, f, k in shards] == [pkg.shard_range(n, r, world) for r in range(world)]
+    mode = m.gather_mode()
+    if gather == "rccl":
+        assert mode.startswith("rccl"), mode                     # a one-rank communicator: the RCCL code path itself ran
+    elif world == 1:
+        assert mode.startswith("none"), mode
+    else:
+        assert mode.startswith("host") and ("more than one shard" in mode or "requested" in mode), mode
+    assert sha(ds.slot_roots()) == g["slot_roots_sha256"]
+    assert hexroot(ds.root()) == g["dataset_root_hex"]
+    for i in range(world):
+        assert hexroot(ds.shard_root(i)) == g["dataset_root_hex"], i
+    edges = sorted({e for _, f, k in shards for e in (f, f + k - 1)})
+    for slot in edges:
+        if str(slot) in g["inputs"]:
+            text = ds.proof_input(slot, g["entropy"]).json()
+            assert tsha(text) == g["inputs"][str(slot)]["json_sha256"] and len(text) == g["inputs"][str(slot)]["json_bytes"], slot
+    assert {0, n - 1} <= set(edges) and all(str(e) in g["inputs"] for e in (0, n - 1))
+    with pytest.raises(pkg.CodexP2Error):
+        ds.proof_input(n, g["entropy"])                          # no shard holds it: slot index out of range
+    ds.free()
+    m.close()
+
+
+def test_forced_rccl_on_a_repeated_device_is_refused_with_a_reason(pkg, golden):
+    c = golden("config5.json")["cheap"]["config"]
+    m = pkg.Multi([0, 0])
+    m.set_policy(pkg.GATHER_RCCL, 0)
+    with pytest.raises(pkg.CodexP2Error) as e:
+        m.dataset(pkg.make_config(**c))
+    assert e.value.status == -1 and "more than one shard" in str(e.value)
+    m.close()
+
+
+def test_small_datasets_stay_on_one_device_unless_told_otherwise(pkg, golden):
+    """workflow/params.sh's default run (11 slots x 512 cells = 5632 cells, far below one hash-kernel residency): one shard,
+    one context, no exchange -- and the same input.json when it is spread over three contexts anyway (uneven 4 + 4 + 3)."""
+    m0 = golden("proof_inputs.json")["inputs"]["params_default"]
+    cfg = pkg.make_config(**m0["config"])
+    want = golden("input_params_default.json")
+    m = pkg.Multi([0, 0, 0])
+    ds = m.dataset(cfg)
+    assert len(ds.shards()) == 1 and m.gather_mode().startswith("none")
+    assert ds.proof_input(m0["slotIndex"], m0["entropy"]).json() == want
+    ds.free()
+    m.set_policy(pkg.GATHER_AUTO, 1)
+    ds = m.dataset(cfg)
+    assert [(f, k) for _, f, k in ds.shards()] == [(0, 4), (4, 4), (8, 3)] and m.gather_mode().startswith("host")
+    assert ds.proof_input(m0["slotIndex"], m0["entropy"]).json() == want
+    ds.free()
+    m.close()
+
+
+def test_multi_streamed_and_batched_exports_equal_the_object_path(pkg, oracle, tmp_path):
+    """cp2_multi_dataset_build_streamed + _export_streamed and cp2_multi_dataset_export_proof_inputs over three shards
+    (7 slots: 3 + 2 + 2): every file byte-identical to the single-context object path and, for the edges, to the oracle."""
+    C, P = oracle
+    c = dict(maxDepth=14, maxLog2NSlots=3, cellSize=256, blockSize=2048, nSlots=7, nCells=128, nSamples=9, seed=777)
+    entropy = 424242
+    cfg = pkg.make_config(**c)
+    single = pkg.Context(0)
+    ref = single.dataset(cfg)
+    want = {s: ref.proof_input(s, entropy).json() for s in range(7)}
+    for s in (0, 2, 3, 6):
+        assert want[s] == P.export_json(expected_proof_input_fast(C, P, c, s, entropy, threads=4))
+    m = pkg.Multi([0, 0, 0])
+    m.set_policy(pkg.GATHER_AUTO, 1)
+    sd = m.dataset_streamed(cfg, entropy, threads=4, group_slots=1)
+    assert [(f, k) for _, f, k in sd.shards()] == [(0, 3), (3, 2), (5, 2)]
+    out1, out2 = tmp_path / "streamed", tmp_path / "batched"
+    out1.mkdir()
+    out2.mkdir()
+    total = sd.export_streamed(str(out1), threads=3)
+    assert total == sum(len(t) for t in want.values())
+    for s in range(7):
+        assert sd.streamed_json(s) == want[s] and open(out1 / ("input_%d.json" % s)).read() == want[s]
+    ds = m.dataset(cfg)
+    total2 = ds.export_proof_inputs([6, 0, 3, 4, 1], entropy, str(out2), threads=3, batch=2)
+    assert sorted(os.listdir(out2)) == ["input_%d.json" % s for s in (0, 1, 3, 4, 6)]
+    assert total2 == sum(len(want[s]) for s in (0, 1, 3, 4, 6))
+    for s in (0, 1, 3, 4, 6):
+        assert open(out2 / ("input_%d.json" % s)).read() == want[s]
+    sd.free()
+    ds.free()
+    ref.free()
+    m.close()
+    single.close()
+
+
+def test_multi_cached_build_writes_one_file_per_shard(pkg, tmp_path):
+    c = dict(maxDepth=12, maxLog2NSlots=3, cellSize=128, blockSize=1024, nSlots=5, nCells=64, nSamples=4, seed=31)
+    cfg = pkg.make_config(**c)
+    m = pkg.Multi([0, 0])
+    m.set_policy(pkg.GATHER_AUTO, 1)
+    cache = str(tmp_path / "trees.cp2")
+    a = m.dataset(cfg, cache=cache)
+    text = a.proof_input(4, 5).json()
+    assert sorted(os.listdir(tmp_path)) == ["trees.cp2.shard0of2", "trees.cp2.shard1of2"]
+    b = m.dataset(cfg, cache=cache)                              # loaded: no cell is hashed again
+    assert b.proof_input(4, 5).json() == text and hexroot(b.root()) == hexroot(a.root())
+    single = pkg.Context(0)
+    assert single.dataset(cfg).proof_input(4, 5).json() == text
+    single.close()
+    a.free()
+    b.free()
+    m.close()
+
+
+def test_multi_slot_files_missing_file_names_device_and_file(pkg, oracle, tmp_path):
+    C, _ = oracle
+    base = str(tmp_path / "slot")
+    for k in (0, 1, 3):
+        C.gen_fake_cells(C.slot_seed(1, k), 0, 64, 128).tofile("%s%d.dat" % (base, k))
+    cfg = pkg.make_config(maxDepth=10, maxLog2NSlots=2, cellSize=128, blockSize=1024, nSlots=4, nCells=64, nSamples=4, file=base)
+    m = pkg.Multi([0, 0])
+    m.set_policy(pkg.GATHER_AUTO, 1)
+    with pytest.raises(pkg.CodexP2Error) as e:
+        m.dataset(cfg)
+    assert e.value.status == -5 and "slot2.dat" in str(e.value) and "slots 2..4" in str(e.value)
+    C.gen_fake_cells(C.slot_seed(1, 2), 0, 64, 128).tofile(base + "2.dat")
+    ds = m.dataset(cfg)                                          # the handle keeps working after a failed build
+    single = pkg.Context(0)
+    assert ds.proof_input(2, 9).json() == single.dataset(cfg).proof_input(2, 9).json()
+    single.close()
+    ds.free()
+    m.close()
+
+
+def test_cli_twin_spreads_over_contexts_without_a_new_flag(pkg, golden, tmp_path):
+    """The drop-in itself: CODEX_P2_GPUS picks the devices (here two contexts on device 0), CODEX_P2_MIN_CELLS=1 makes even
+    params.sh's small default spread; the flag set and the output stay the reference's."""
+    args = ["--depth=32", "--maxslots=256", "--cellsize=2048", "--blocksize=65536", "--nsamples=5", "--entropy=1234567",
+            "--seed=12345", "--nslots=11", "--ncells=512", "--index=3", "--field=bn254", "--hash=poseidon2"]
+    want = golden("input_params_default.json")
+    for env_extra, marker in (({}, "none"), ({"CODEX_P2_GPUS": "0,0", "CODEX_P2_MIN_CELLS": "1"}, "host"), ({"CODEX_P2_GPUS": "1"}, "none")):
+        out = str(tmp_path / ("input_%s.json" % marker))
+        r = subprocess.run([pkg.CLI_PATH] + args + ["-v", "--output=" + out], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, CP2_TRACE="1", **env_extra))
+        assert r.returncode == 0, r.stderr
+        assert open(out).read() == want
+        assert "[cp2 trace] slot roots exchanged: %s" % marker in r.stderr, r.stderr
+    r = subprocess.run([pkg.CLI_PATH] + args + ["--output=" + str(tmp_path / "x.json")], capture_output=True, text=True, timeout=60,
+                       env=dict(os.environ, CODEX_P2_GPUS="7,"))
+    assert r.returncode != 0 and "no usable gfx950 HIP device" in r.stderr      # a device that is not there: loud, no fallback
+
+
+# ---- SURVEY.md 8(d), config 5's other stated scale-down: several slots at the nominal 8 GiB slot size ------------------
+def _big(golden):
+    try:
+        return golden("bigslots.json")
+    except FileNotFoundError:
+        pytest.skip("tests/golden/bigslots.json not generated (tests/golden/make_bigslots_golden.py)")
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0]])
+def test_bigslots_multi_vs_oracle_fixture(pkg, golden, devices):
+    """8 slots x 2^22 cells x 2048 B (64 GiB generated and hashed on the device, 1.17e9 permutations) through cp2_multi: the
+    2 GiB staging chunk is a quarter of a slot, so every slot crosses four chunk boundaries (slot_trees.cpp, trees_build_fake)."""
+    g = _big(golden)
+    c = g["config"]
+    cfg = pkg.make_config(**c)
+    m = pkg.Multi(devices)
+    ds = m.dataset(cfg)
+    assert len(ds.shards()) == len(devices)
+    roots = ds.slot_roots()
+    assert [hexroot(r) for r in roots] == g["slot_roots_hex"] and sha(roots) == g["slot_roots_sha256"]
+    assert hexroot(ds.root()) == g["dataset_root_hex"]
+    for slot in (0, 3, 4, 7):
+        pi = ds.proof_input(slot, g["entropy"])
+        assert [int(v) for v in pi.cell_indices()[:8]] == g["cell_indices_first8"][slot]
+        text = pi.json()
+        assert tsha(text) == g["inputs"][str(slot)]["json_sha256"] and len(text) == g["inputs"][str(slot)]["json_bytes"], slot
+    ds.free()
+    m.close()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_bigslots_sharded_rank_processes_vs_oracle_fixture(golden, tmp_path, world):
+    """The same through distributed.dataset_root_sharded(HipBackend) as 1 and 2 rank processes (4 + 4 slots of 8 GiB)."""
+    g = _big(golden)
+    res = run_ranks(world, g["config"], g["entropy"], tmp_path, timeout=1100)
+    for r in res:
+        assert r["native_so_loaded"] and not r["oracle_loaded"]
+        assert r["dataset_root_hex"] == g["dataset_root_hex"] and r["all_roots_sha256"] == g["slot_roots_sha256"]
+        assert r["count"] == 8 // world
+        for slot, digest in r["inputs"].items():
+            assert digest == g["inputs"][slot]["json_sha256"], (r["rank"], slot)
+
+
+def test_bigslots_streamed_one_slot_per_group_and_prefix_datasets(pkg, ctx, golden, tmp_path):
+    """A streamed build with group_slots = 1 (sampling / gathers / bodies of slot k overlap the hashing of slot k + 1) at the
+    full slot size, and the 5- and 4-slot prefixes of the same slots (an odd dataset tree; the 2 + 2 split's tree)."""
+    g = _big(golden)
+    c = g["config"]
+    for n_slots in (5, 4):
+        p = g["prefixes"][str(n_slots)]
+        cfg = pkg.make_config(**dict(c, nSlots=n_slots))
+        sd = ctx.dataset_streamed(cfg, g["entropy"], threads=_threads(), group_slots=1)
+        sd.export_streamed(None, threads=2)
+        assert hexroot(sd.root()) == p["dataset_root_hex"]
+        for slot, want in p["inputs"].items():
+            text = sd.streamed_json(int(slot))
+            assert tsha(text) == want["json_sha256"] and len(text) == want["json_bytes"], (n_slots, slot)
+        sd.free()
+    ctx.trim()

@@ -20,11 +20,23 @@ def test_streamed_bodies_spill_beyond_the_budget(pkg, ctx, oracle, tmp_path):
     body = len(want[0])                                  # a little more than one body
     spill = tmp_path / "spill"
     spill.mkdir()
+    def spilled():
+        """the spill files, all inside ONE private directory (mkdtemp: mode 0700) and readable by the owner only"""
+        dirs = os.listdir(spill)
+        assert len(dirs) <= 1 and all(d.startswith("cp2_bodies_") for d in dirs)
+        if not dirs:
+            return []
+        d = spill / dirs[0]
+        assert os.stat(d).st_mode & 0o777 == 0o700
+        files = os.listdir(d)
+        assert all(os.stat(d / f).st_mode & 0o777 == 0o600 for f in files)
+        return files
+
     try:
         for budget, lo, hi in ((1, 11, 11), (3 * body, 7, 10), (1 << 30, 0, 0)):
             ctx.set_body_budget(budget, str(spill))
             ds = ctx.dataset_streamed(cfg, 55555, threads=3, group_slots=2)
-            assert lo <= len(os.listdir(spill)) <= hi, (budget, os.listdir(spill))
+            assert lo <= len(spilled()) <= hi, (budget, os.listdir(spill))
             out = tmp_path / ("out%d" % budget)
             out.mkdir()
             total = ds.export_streamed(str(out), threads=2)
@@ -32,11 +44,20 @@ def test_streamed_bodies_spill_beyond_the_budget(pkg, ctx, oracle, tmp_path):
             for s, t in want.items():
                 assert ds.streamed_json(s) == t and open(out / ("input_%d.json" % s)).read() == t
             ds.free()
-            assert os.listdir(spill) == []
+            assert os.listdir(spill) == []               # files and the private directory go with the dataset
+        # names the old layout used, planted as symlinks to a victim file: nothing follows or overwrites them
+        victim = tmp_path / "victim"
+        victim.write_text("untouched")
+        for s in range(11):
+            os.symlink(victim, spill / ("cp2_body_%d_0_%d.part" % (os.getpid(), s)))
+        ctx.set_body_budget(1, str(spill))
+        ds = ctx.dataset_streamed(cfg, 55555, threads=3, group_slots=2)
+        assert ds.streamed_json(3) == want[3] and victim.read_text() == "untouched"
+        ds.free()
         ctx.set_body_budget(1, str(tmp_path / "does" / "not" / "exist"))
         with pytest.raises(pkg.CodexP2Error) as e:
             ctx.dataset_streamed(cfg, 55555, threads=2, group_slots=2)
-        assert e.value.status == -5 and "cp2_body_" in str(e.value)
+        assert e.value.status == -5 and "private spill directory" in str(e.value) and "not/exist" in str(e.value)
     finally:
         ctx.set_body_budget(4 << 30, None)
 

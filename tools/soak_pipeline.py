@@ -67,7 +67,7 @@ while time.time() - t0 < budget:
             print("MISMATCH sharded", c, flush=True)
         a.free(); b.free()
     ref.free(); sd.free()
-    if any(f.endswith(".part") for f in os.listdir(tmp)):
+    if any(f.endswith(".part") or f.startswith("cp2_bodies_") for _, ds_, fs in os.walk(tmp) for f in fs + ds_):
         bad += 1
         print("spill files left behind", os.listdir(tmp)[:4], flush=True)
     if it % 50 == 0:
