@@ -20,14 +20,21 @@ The JSON line also carries
                 count of the committed rocprofv3 --pmc summary named in `traffic_source`.
   roofline_hash_cells  the same block for k_hash_cells over the 8 GiB slot of configs[2] (2^33 B read + 2^27 B of digests written
                 per launch), the kernel that holds most of the GPU time of a slot build.
-  valu_issue    the instruction-issue view (the binding resource): issue cycles per VALU instruction, every
-                figure taken from ONE committed rocprofv3 --pmc pass (counters only, no timing of this run mixed in).
+  valu_issue    the instruction-issue view (the binding resource): cycles one SIMD spends per
+                wave-permutation from ONE committed rocprofv3 --pmc pass, against the class-weighted issue floor of the kernel's own
+                instruction stream (CDNA4 SIMD-32: 2 cycles for the plain VALU forms, 4 for the multiplies and the other half-rate
+                forms; tools/valu_roof.py), and the 64-bit multiply rate against the multiplier's measured peak.
+                Counters and ISA counts only: no timing of this run mixed in.
   cpu_baseline  the C oracle (a port of the same algorithm, NOT the Nim binary: no Nim toolchain exists)
                 timed on this box's host cores on a bounded sample, rank 0 at N=1 only.
   extra         config 3 (8 GiB slot -> slot root), config 4 (4096 slots -> 4096 input.json texts: witnesses/s, classic
                 and streamed), ingestion rates against the measured pinned H2D peak, and config 5's shape at SURVEY.md 8(d)'s
                 stated scale-down (32 768 slots x 2^12 cells sharded over the ranks, one gather of slot roots, dataset tree
-                of 15 levels, one proof input per rank) at every N including 1.
+                of 15 levels, one proof input per rank) at every N including 1; the same shape through the C ABI's own
+                multi-GPU entry points in ONE process (cp2_multi_*: what the cli twin / a Nim caller gets, `dataset_inprocess`);
+                config 5's other stated scale-down, 8 slots at the nominal 8 GiB slot size (`dataset_big_slots`); and the
+                drop-in's own workload, the cli twin on workflow/params.sh's defaults as a fresh process, split into HIP init /
+                code-object load / hashing / JSON, beside the C oracle on the same configuration (`cli_default`).
 """
 import argparse
 import contextlib
@@ -147,8 +154,12 @@ def main():
     ap.add_argument("--states", type=int, default=N_STATES, help="states per step per GPU (default 2^24)")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-3 / config-4 / ingest / config-5 extra legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inprocess-leg", type=int, default=0, metavar="N",
+                    help="(child mode of the dataset_inprocess leg) build config 5's scale-down on N devices in THIS process through cp2_multi_* and print one JSON object")
     args = ap.parse_args()
 
+    if args.inprocess_leg:
+        return inprocess_child(args.inprocess_leg)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args.gpus)
 
@@ -175,10 +186,15 @@ def main():
         # at stderr while the communicator is created.
         import datetime
         kw = {}
-        if os.environ.get("BENCH_INIT_TIMEOUT_S"):                   # self-spawned ranks: a short rendezvous timeout
-            kw["timeout"] = datetime.timedelta(seconds=int(os.environ["BENCH_INIT_TIMEOUT_S"]))
         if os.environ.get("BENCH_INIT_FILE"):                        # self-spawned ranks: file store instead of a TCP port
-            kw.update(init_method="file://" + os.environ["BENCH_INIT_FILE"], rank=rank, world_size=world)
+            # Only the RENDEZVOUS is bounded (a rank that never comes up must not leave the others waiting): every rank
+            # announces itself in the store and waits for all the others under BENCH_INIT_TIMEOUT_S.  The process group keeps
+            # torch's default collective timeout, so a long leg or a loaded box cannot trip a watchdog later.
+            store = dist.FileStore(os.environ["BENCH_INIT_FILE"], world)
+            store.set("cp2_bench_up_%d" % rank, "1")
+            store.wait(["cp2_bench_up_%d" % r for r in range(world)],
+                       datetime.timedelta(seconds=int(os.environ.get("BENCH_INIT_TIMEOUT_S", "120"))))
+            kw.update(store=store, rank=rank, world_size=world)
         with _stdout_to_stderr():
             if backend == "nccl":
                 try:
@@ -264,7 +280,7 @@ def main():
                 "kernel": "k_permute_batch", "avg_launch_ms": round(avg_ms, 4),
                 "launch_ms_min_max": [round(min(kernel_ms), 4), round(max(kernel_ms), 4)],
                 "algorithmic_bytes_per_launch": BYTES_PER_PERM * n,
-                "note": "VALU-issue bound by construction (about 5.1e4 VALU instructions per permutation against 192 B); see DESIGN.md"}
+                "note": "VALU-issue bound by construction (about 5.1e4 VALU instructions per permutation against 192 B): see valu_issue and DESIGN.md section 5"}
 
     out = {
         "metric": "Poseidon2-BN254 permutations/sec per GPU; full proof-input witnesses/sec",
@@ -305,8 +321,21 @@ def main():
             extra.update(dataset_leg(torch, dist, ctx, pkg, coll_dev, rank, world))
         except Exception as e:
             extra["dataset_error"] = repr(e)
+        try:
+            extra.update(big_slots_leg(torch, dist, ctx, pkg, coll_dev, rank, world))
+        except Exception as e:
+            extra["dataset_big_slots_error"] = repr(e)
+        try:
+            extra.update(inprocess_leg(torch, dist, ctx, rank, world))
+        except Exception as e:
+            extra["dataset_inprocess_error"] = repr(e)
+        if world == 1:
+            try:
+                extra.update(cli_default_leg(pkg, g))
+            except Exception as e:
+                extra["cli_default_error"] = repr(e)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(C, np)
+        out["cpu_baseline"] = cpu_baseline(C, np, torch, dev)
     if extra:
         out["extra"] = extra
     if world > 1:
@@ -582,16 +611,28 @@ def dataset_leg(torch, dist, ctx, pkg, dev, rank, world):
     t0 = time.perf_counter()
     backend = d.HipBackend(pkg, ctx)
     first, count = d.shard_range(n_slots, rank, world)
+    on_device = dev.type == "cuda"                                   # RCCL: the roots never leave HBM; gloo rehearsal: host arrays
     err, local = None, None
     try:
-        local = backend.local_slot_roots(cfg, first, count)          # this rank's slot trees: no communication
+        if on_device:
+            backend.build_local(cfg, first, count)                   # this rank's slot trees: no communication
+        else:
+            local = backend.local_slot_roots(cfg, first, count)
     except Exception as e:
         err = e
     all_ranks_ok(err)
-    all_roots = d.gather_slot_roots(local, n_slots, rank, world, dist if world > 1 else None, dev)   # THE exchange step
+    # THE exchange step: device to device (copy inside HBM -> all_gather_into_tensor over RCCL/xGMI -> cp2_dataset_set_roots_dev)
+    if on_device:
+        all_dev = d.gather_slot_roots_dev(backend.dataset, ctx, n_slots, rank, world, dist if world > 1 else None, dev)
+    else:
+        all_roots = d.gather_slot_roots(local, n_slots, rank, world, dist if world > 1 else None, dev)
     err, root, text = None, None, ""
     try:
-        root = backend.dataset_root(cfg, all_roots)                  # 15-level dataset tree on every rank
+        if on_device:
+            backend.dataset.set_roots_dev(all_dev.data_ptr())        # 15-level dataset tree on every rank
+            root = backend.dataset.root()
+        else:
+            root = backend.dataset_root(cfg, all_roots)
         t1 = time.perf_counter()
         text = backend.dataset.proof_input(first, 1234567).json()    # a proof input for one of this rank's own slots
         torch.cuda.synchronize()
@@ -620,21 +661,21 @@ def dataset_leg(torch, dist, ctx, pkg, dev, rank, world):
     return {"dataset": {"workload": "configs[4] shape, SURVEY.md 8(d) scale-down: 32768 slots x 2^12 cells x 2048 B sharded over %d GPU(s) "
                                     "(%d slots on rank 0), one gather of slot roots -> 15-level dataset tree on every rank, one proof input per rank"
                                     % (world, count),
+                        "exchange": ("device to device (all_gather_into_tensor, %s)" % dist.get_backend() if world > 1 and on_device else
+                                     "none (one rank)" if world == 1 else "host arrays (%s rehearsal)" % dist.get_backend()),
                         "scaling": "strong", "seconds": round(dt, 4), "roots_and_dataset_tree_s": round(t1 - t0, 4), "perms_per_s": perms / dt,
                         "slots_per_s": n_slots / dt, "all_ranks_agree": bool(same), "ranks": world,
                         "proof_input_json_bytes": len(text), "dataset_root_hex": root_hex,
                         "equals_oracle_fixture": (root_hex == gold) if gold else None}}
 
 
-def cpu_baseline(C, np):
-    """The oracle timed on this box's host cores on a bounded sample of the same workload (config 2 shape)."""
+def cpu_baseline(C, np, torch, dev):
+    """The oracle timed on this box's host cores on a bounded sample of the same workload (config 2 shape): states from the
+    SAME generator as the GPU leg (uniform_felts_device: every element uniform in [0, r) by rejection), copied to the host."""
     cores = host_threads()
-    rng = np.random.default_rng(0xC0DE)
     n1 = 1 << 17
-    x = rng.integers(0, 256, size=(n1, 96), dtype=np.uint8)
-    x[:, 31] &= 0x1F
-    x[:, 63] &= 0x1F
-    x[:, 95] &= 0x1F
+    gen = torch.Generator(device=dev).manual_seed(0xC0DE)
+    x = uniform_felts_device(torch, dev, 3 * n1, gen).reshape(n1, 96).cpu().numpy()
     t = time.perf_counter()
     C.permute_batch(x, threads=1)
     single = n1 / (time.perf_counter() - t)
@@ -645,8 +686,188 @@ def cpu_baseline(C, np):
     multi = nm / (time.perf_counter() - t)
     return {"value": multi, "unit": "permutations/s", "cores": cores, "kind": "port",
             "sample": "C oracle (oracle/p2_oracle.c, 4x64-bit Montgomery; NOT the Nim reference binary, which cannot be built here): "
-                      "%d states on %d threads; single-thread rate on %d states reported beside it" % (nm, cores, n1),
+                      "%d states on %d threads; single-thread rate on %d states reported beside it; states from the GPU leg's own generator "
+                      "(uniform in [0, r))" % (nm, cores, n1),
             "single_thread_value": single}
+
+
+def big_slots_leg(torch, dist, ctx, pkg, dev, rank, world):
+    """Config 5's OTHER stated scale-down ("8 x k slots x 2^22 cells"): 8 slots at the nominal 8 GiB slot size
+    (64 GiB generated and hashed on the devices; every slot crosses four 2 GiB staging chunks), sharded over the ranks like the
+    32 768-slot leg (strong scaling), one exchange of slot roots, dataset tree, one proof input per rank; against the
+    oracle-only fixture tests/golden/bigslots.json."""
+    import importlib
+    d = importlib.import_module("codex_storage_proofs_circuits_amd.distributed")
+    n_slots, n_cells = 8, 1 << 22
+    if world > n_slots:
+        return {"dataset_big_slots": {"skipped": "more ranks than slots"}}
+    cfg = pkg.make_config(maxDepth=32, maxLog2NSlots=3, cellSize=2048, blockSize=65536, nSlots=n_slots, nCells=n_cells, nSamples=100, seed=12345)
+    ctx.reset_stream()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    backend = d.HipBackend(pkg, ctx)
+    err, root, text, first, count = None, None, "", 0, 0
+    try:
+        root, all_roots, (first, count) = d.dataset_root_sharded(backend, cfg, rank, world, dist if world > 1 else None,
+                                                                 dev if dev.type == "cuda" else "cpu")
+        t1 = time.perf_counter()
+        text = backend.dataset.proof_input(first, 1234567).json()
+    except Exception as e:          # a rank that failed BEFORE the collective leaves the others waiting there: bounded by the collective timeout
+        err = e
+    if world > 1:
+        flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            raise RuntimeError("a rank failed in the big-slots leg: %r" % (err,))
+    elif err:
+        raise err
+    dt = time.perf_counter() - t0
+    backend.dataset.free()
+    ctx.trim()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    import hashlib
+    perms = n_slots * (35 * n_cells - 1) + (n_slots - 1) * world + 200 * world
+    root_hex = root.tobytes()[::-1].hex()
+    gold = None
+    try:
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "bigslots.json")))
+    except Exception:
+        pass
+    return {"dataset_big_slots": {"workload": "configs[4] shape, SURVEY.md 8(d)'s other scale-down: 8 slots x 2^22 cells x 2048 B (nominal 8 GiB slots) sharded "
+                                              "over %d GPU(s) (%d slots on rank 0), one exchange of slot roots, dataset tree, one proof input per rank" % (world, count),
+                                  "scaling": "strong", "seconds": round(dt, 4), "roots_and_dataset_tree_s": round(t1 - t0, 4),
+                                  "perms_per_s": perms / dt, "GB_per_s_hashed": round(n_slots * n_cells * 2048 / dt / 1e9, 2),
+                                  "dataset_root_hex": root_hex,
+                                  "equals_oracle_fixture": (root_hex == gold["dataset_root_hex"] and
+                                                            hashlib.sha256(text.encode()).hexdigest() == gold["inputs"][str(first)]["json_sha256"]) if gold else None}}
+
+
+def inprocess_child(n_dev):
+    """Child mode (`bench.py --inprocess-leg N`): ONE process, N devices, through the C ABI's own multi-GPU entry points
+    (cp2_multi_init / cp2_multi_dataset_build / cp2_multi_proof_input_generate: exactly what the cli twin and a Nim caller
+    get).  Config 5's shape at SURVEY.md 8(d)'s scale-down; prints one JSON object."""
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    n_slots, n_cells = 32768, 1 << 12
+    cfg = pkg.make_config(maxDepth=32, maxLog2NSlots=15, cellSize=2048, blockSize=65536, nSlots=n_slots, nCells=n_cells, nSamples=100, seed=12345)
+    with _stdout_to_stderr():                      # RCCL prints its version banner on stdout when NCCL_DEBUG is set
+        t0 = time.perf_counter()
+        m = pkg.Multi(list(range(n_dev)))
+        t1 = time.perf_counter()
+        ds = m.dataset(cfg)                        # includes context creation, code-object load and (N > 1) communicator creation
+        t2 = time.perf_counter()
+        text = ds.proof_input(n_slots - 1, 1234567).json()
+        t3 = time.perf_counter()
+        root = ds.root()
+        n_shards = len(ds.shards())
+        agree = all((ds.shard_root(i) == root).all() for i in range(n_shards))
+        ds.free()
+        ds = m.dataset(cfg)                        # a second build on the warm handle: contexts, code objects and communicators exist
+        t4 = time.perf_counter()
+        ds.free()
+    perms = n_slots * (35 * n_cells - 1) + (n_slots - 1) * n_dev + 200
+    root_hex = root.tobytes()[::-1].hex()
+    gold = None
+    try:
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "config5.json")))["scaled"]
+    except Exception:
+        pass
+    import hashlib
+    res = {"devices": n_dev, "shards": n_shards, "gather": m.gather_mode(), "handle_init_s": round(t1 - t0, 4),
+           "first_build_s": round(t2 - t1, 4), "warm_build_s": round(t4 - t3, 4), "one_proof_input_json_s": round(t3 - t2, 4),
+           "perms_per_s_first": perms / (t2 - t0), "perms_per_s_warm": perms / (t4 - t3), "slots_per_s_warm": n_slots / (t4 - t3),
+           "all_devices_agree": bool(agree), "dataset_root_hex": root_hex,
+           "equals_oracle_fixture": (root_hex == gold["dataset_root_hex"] and
+                                     hashlib.sha256(text.encode()).hexdigest() == gold["inputs"][str(n_slots - 1)]["json_sha256"]) if gold else None}
+    m.close()
+    print(json.dumps(res), flush=True)
+    return 0
+
+
+def inprocess_leg(torch, dist, ctx, rank, world):
+    """The same 32 768 x 2^12 dataset as `dataset`, but through cp2_multi_* in ONE fresh process over all `world` devices (the
+    drop-in's path: no launcher, no torch.distributed).  Rank 0 starts the child once every rank has released its device memory;
+    the other ranks wait on the rendezvous store (a host-side wait: no collective kernel spins on their GPUs meanwhile)."""
+    import datetime
+    ctx.trim()
+    torch.cuda.empty_cache()
+    store = None
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+        store = dist.distributed_c10d._get_default_store()
+    res = None
+    if rank == 0:
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--inprocess-leg", str(world)], capture_output=True, text=True, timeout=420)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            res = json.loads(line[-1]) if r.returncode == 0 and line else {"error": "rc %d: %s" % (r.returncode, r.stderr[-600:])}
+        except subprocess.TimeoutExpired:
+            res = {"error": "timed out after 420 s"}
+        finally:
+            if store is not None:
+                store.set("cp2_bench_inprocess_done", "1")
+    elif store is not None:
+        store.wait(["cp2_bench_inprocess_done"], datetime.timedelta(seconds=480))
+    if res is None:
+        return {}
+    res["workload"] = ("configs[4] shape (32768 slots x 2^12 cells x 2048 B) through cp2_multi_* in ONE process over %d device(s): contiguous slot ranges, "
+                       "one host thread + context per device, one device-to-device exchange of slot roots, dataset tree on every device" % world)
+    return {"dataset_inprocess": res}
+
+
+def cli_default_leg(pkg, g):
+    """What workflow/prove.sh:26 actually runs: the cli twin on workflow/params.sh's defaults (11 slots x 512 cells x 2048 B,
+    5 samples: about 2e5 permutations), as a FRESH PROCESS each time.  Wall time, and with CP2_TRACE the split into HIP
+    runtime init / context / code-object load / buffers / hashing / dataset tree / sampling / JSON.  Beside it the C oracle,
+    single thread, on the same configuration counted the reference's way ((nSlots + nSamples) slot-tree builds,
+    gen_input/bn254.nim:42,57) and the build-once way (nSlots)."""
+    import re
+    import shutil
+    import tempfile
+    args = ["--depth=32", "--maxslots=256", "--cellsize=2048", "--blocksize=65536", "--nsamples=5", "--entropy=1234567",
+            "--seed=12345", "--nslots=11", "--ncells=512", "--index=3", "--field=bn254", "--hash=poseidon2"]
+    tmp = tempfile.mkdtemp(prefix="cp2_cli_")
+    try:
+        out = os.path.join(tmp, "input.json")
+        walls, split = [], {}
+        for i in range(4):
+            env = dict(os.environ, CP2_TRACE="1") if i == 3 else dict(os.environ)
+            env.pop("CODEX_P2_GPUS", None)
+            t = time.perf_counter()
+            r = subprocess.run([pkg.CLI_PATH] + args + ["--output=" + out], capture_output=True, text=True, timeout=120, env=env)
+            dt = time.perf_counter() - t
+            if r.returncode != 0:
+                raise RuntimeError("cli twin failed: " + r.stderr[-400:])
+            if i < 3:
+                walls.append(dt)
+            else:
+                for m in re.finditer(r"\[cp2 trace\] (.*?)\s+([0-9.]+) ms", r.stderr):
+                    split[m.group(1).strip()] = split.get(m.group(1).strip(), 0.0) + float(m.group(2))
+                split["(whole process, traced run)"] = round(dt * 1e3, 1)
+        golden = open(os.path.join(ROOT, "tests", "golden", "input_params_default.json")).read()
+        ok = open(out).read() == golden
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    C, _ = g.load_oracle()
+    t = time.perf_counter()
+    for s in range(11):
+        C.fake_slot_root(C.slot_seed(12345, s), 2048, 65536, 512, 1)
+    once = time.perf_counter() - t
+    t = time.perf_counter()
+    for _ in range(5):
+        C.fake_slot_root(C.slot_seed(12345, 3), 2048, 65536, 512, 1)
+    again = time.perf_counter() - t
+    perms_once = 11 * (35 * 512 - 1)
+    return {"cli_default": {"workload": "workflow/params.sh defaults through the cli twin as a fresh process (what workflow/prove.sh:26 runs): 11 slots x 512 cells x 2048 B, "
+                                        "5 samples, index 3; %d permutations of hashing" % perms_once,
+                            "wall_s_runs": [round(w, 4) for w in walls], "wall_s_best": round(min(walls), 4), "input_json_equals_oracle_fixture": ok,
+                            "trace_ms": {k: round(v, 3) for k, v in split.items()},
+                            "cpu_oracle_single_thread": {"build_once_s": round(once, 3), "reference_way_s": round(once + again, 3),
+                                                         "note": "C oracle (a port, not the Nim binary), one thread: slot trees of the 11 slots (build once) and, the reference's "
+                                                                 "way, the proving slot's tree again per sample (gen_input/bn254.nim:42,57): 16 builds"}}}
 
 
 if __name__ == "__main__":

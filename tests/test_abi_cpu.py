@@ -160,6 +160,9 @@ def test_json_writer_host_only_vs_oracle_edge_values(pkg, oracle):
                           "proofInputs": [{"cellData": cells[i].tobytes(), "merkleProof": {"merklePath": vals[i * md:(i + 1) * md]}}
                                           for i in range(ns)]})
     assert got == want
+    # entropy handed in as 32 arbitrary bytes is stored and printed as its residue mod r (a field element in the reference)
+    got_r = _make_pi(pkg, cfg, 4, droot, felt(P.R_MOD + edge[7]), sroot, proof, cells, paths)
+    assert got_r == want
     # zero samples, zero-length slot proof
     cfg0 = pkg.make_config(maxDepth=0, maxLog2NSlots=0, cellSize=31, blockSize=62, nSlots=1, nCells=2, nSamples=0)
     got0 = _make_pi(pkg, cfg0, 0, felt(1), felt(2), felt(3), np.zeros((1, 32), np.uint8), np.zeros((0, 31), np.uint8), np.zeros((0, 32), np.uint8))

@@ -1,5 +1,6 @@
 """GPU suite, round 3 additions (-m gpu): bounded host memory of the streamed path (spilled bodies), cp2_trim, error reporting of
 the streamed workers, the reference's `k > 0` assert in sampling, launches sliced beyond one grid's worth of items."""
+import ctypes
 import os
 
 import numpy as np
@@ -329,3 +330,15 @@ def test_entropy_is_stored_and_printed_as_its_canonical_representative(pkg, ctx,
         sd.export_streamed(None)
         assert sd.streamed_json(1) == want
         sd.free()
+        # and the third entry point: an object assembled from caller arrays (cp2_proof_input_create) with the RAW entropy
+        pi = ds.proof_input(1, as_bytes(raw % P.R_MOD))
+        d, s_root, _ = pi.roots()
+        sp, idx, cells, paths = (np.ascontiguousarray(a) for a in (pi.slot_proof(), pi.cell_indices(), pi.cell_data(), pi.merkle_paths()))
+        h = ctypes.c_void_p()
+        e = np.ascontiguousarray(as_bytes(raw))
+        st = ctx.L.cp2_proof_input_create(ctypes.byref(cfg), 1, *(ctypes.c_void_p(a.ctypes.data) for a in (d, e, s_root, sp)), idx.size,
+                                          ctypes.c_void_p(idx.ctypes.data), ctypes.c_void_p(cells.ctypes.data), ctypes.c_void_p(paths.ctypes.data),
+                                          None, ctypes.byref(h))
+        assert st == 0
+        made = pkg.ProofInput(ctx, h, cfg)
+        assert made.json() == want and int.from_bytes(made.roots()[2].tobytes(), "little") == raw % P.R_MOD

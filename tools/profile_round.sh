@@ -26,5 +26,10 @@ rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM
 H="python3 bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/hfetch -- $H > $O/hfetch.log 2>&1 || true
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/hwrite -- $H > $O/hwrite.log 2>&1 || true
+# saturated issue cost of every opcode of the kernel's stream, with the same counters (tools/ubench_classes.hip; its binary is built in-tree
+# by `hipcc --offload-arch=gfx950 -O3 -o tools/ubench_classes tools/ubench_classes.hip` and travels with the snapshot)
+if [ -x tools/ubench_classes ]; then
+  rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $O/ubench -- tools/ubench_classes > $O/ubench.log 2>&1 || true
+fi
 echo "all done" >> $O/progress.txt
-echo "now run locally: python3 tools/profile_summarize.py $R   (gpurun merges only gpurun_out/ back)"
+echo "now run locally: python3 tools/ubench_classes_summarize.py $R prof_$R/ubench && python3 tools/valu_roof.py $R && python3 tools/profile_summarize.py $R   (gpurun merges only gpurun_out/ back)"

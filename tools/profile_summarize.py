@@ -62,9 +62,8 @@ res = {
     "kernel_trace_avg_launch_ms": avg_ms,
     "kernel_trace_launches_ms": [round(x, 4) for x in launches],
     "kernel_trace_note": "average over the 2^24-state launches of the kernel trace (5 warm-up + 20 timed: the driver's command), listed one by one; the --stats CSV "
-                         "row of this kernel also averages in the 2^20-state chunk launches of the ingest leg's host-array call "
-                         "(%s calls, %.3f ms on average), so it is not comparable; bench.py's own average (HIP events) covers the 20 timed launches"
-                         % (perm["Calls"], float(perm["AverageNs"]) * 1e-6),
+                         "row of this kernel holds %s calls averaging %.3f ms (the same launches when no other leg runs this kernel); bench.py's own "
+                         "average (HIP events) covers the 20 timed launches only" % (perm["Calls"], float(perm["AverageNs"]) * 1e-6),
     "kernel_trace_avg_excluding_first_ms": (sum(launches[1:]) / len(launches[1:])) if len(launches) > 1 else None,
     "counters": counters,
     "correction": "gfx950: FETCH_SIZE tallies 64 B per 128-B request for 16 B/lane streaming reads -> doubled "
@@ -73,29 +72,65 @@ res = {
     "hbm_bytes_per_launch": int(fetch_kb * 1024 * 2 + write_kb * 1024),
     "algorithmic_bytes_per_launch": 192 * n,
     "valu_insts_per_wave": counters["SQ_INSTS_VALU"]["per_launch_avg"] / (n / 64),
-    "mad_u64_u32_per_permutation": 33120,
     "box": box,
     "kernel_ms_inside_each_pmc_pass": {k: round(v, 4) for k, v in pass_ms.items()},
 }
 # The instruction-issue view, from ONE pass (`sq`): GRBM_GUI_ACTIVE is summed over the 8 XCDs, so /8 = shader cycles of the
-# launch; 1024 SIMDs issue SQ_INSTS_VALU wave-instructions in them.  No time and no clock enters the ratio; the clock of the
-# pass (cycles / the kernel's duration inside the same pass) is reported beside it.
+# launch; 1024 SIMDs issue SQ_INSTS_VALU wave-instructions in them.  No time and no clock enters any ratio below; the clock of
+# the pass (cycles / the kernel's duration inside the same pass) is reported beside them.
+# The roof is the class-weighted floor of the kernel's own instruction stream (tools/valu_roof.py): CDNA4's SIMD-32 issues a
+# wave64 VALU instruction over 2 cycles, the multiplies and the other half-rate integer forms over 4 -- NOT "4 = full rate".
 cyc = counters["GRBM_GUI_ACTIVE"]["per_launch_avg"] / 8
 insts = counters["SQ_INSTS_VALU"]["per_launch_avg"]
 sq_ms = pass_ms.get("sq")
+waves = n / 64
+cyc_wave_perm = cyc * 1024 / waves                      # shader cycles one SIMD spends per wave-permutation (64 permutations)
 res["valu_issue"] = {
     "bound": "valu-issue", "pass": "sq (rocprofv3 --pmc SQ_INSTS_VALU ... GRBM_GUI_ACTIVE, one pass)",
     "cycles_per_valu_instruction": round(cyc * 1024 / insts, 4),
-    "full_rate_cycles_per_instruction": 4.0,
-    "valu_insts_per_permutation": insts / (n / 64),
-    "mad_u64_u32_per_permutation": 33120, "mad_share_of_valu_insts": round(33120 / (insts / (n / 64)), 4),
+    "cycles_per_wave_permutation": round(cyc_wave_perm, 1),
+    "valu_insts_per_permutation": insts / waves,
     "shader_cycles_per_launch": cyc, "valu_wave_insts_per_launch": insts,
     "kernel_ms_in_this_pass": sq_ms, "shader_clock_GHz_in_this_pass": (cyc / (sq_ms * 1e-3) / 1e9) if sq_ms else None,
-    "explanation": "a wave64 VALU instruction occupies a 16-lane SIMD for 4 cycles: 4.0 cycles per instruction per SIMD is what a "
-                   "saturated issue port reads.  The marginal-cost probe (profiles/r02_marginal_cost_probe.txt) prices every instruction "
-                   "kind of this kernel at 3.9-4.4 cycles except v_mov_b32 (0.9; about 3 % of the stream), which is why the average can "
-                   "sit a little under 4.  The port is saturated; the only lever left is the instruction count",
 }
+cls_path = os.path.join(P, "%s_valu_classes.json" % R)
+if os.path.exists(cls_path):
+    cl = json.load(open(cls_path))
+    mad = next(r for r in cl["opcodes"] if r["opcode"] == "v_mad_u64_u32")
+    non_mad = cl["valu_insts_per_permutation_from_isa"] - mad["per_permutation"]
+    floors = {"nominal_per_opcode": cl["class_floor_cycles_nominal"],
+              "nominal_if_every_non_multiply_issued_in_2": 4.0 * mad["per_permutation"] + 2.0 * non_mad,
+              "homogeneous_stream_prices_per_opcode_NOT_a_floor": cl["class_floor_cycles_measured"]}
+    v = res["valu_issue"]
+    v["instruction_classes_per_permutation"] = cl["per_class"]
+    v["class_floor_cycles"] = {k: (round(x, 1) if x else None) for k, x in floors.items()}
+    v["frac_of_class_floor"] = {k: (round(x / cyc_wave_perm, 4) if x else None) for k, x in floors.items()}
+    v["classes_source"] = "profiles/%s_valu_classes.json (tools/valu_roof.py: dynamic opcode counts from the ISA; ISA total %d vs SQ_INSTS_VALU %.0f per permutation)" % (
+        R, cl["valu_insts_per_permutation_from_isa"], insts / waves)
+    v["rates_source"] = {"nominal": "MI355X_MICROARCH.md: SIMD-32, `v_fma_f32 (wave64) 2 cyc`; plain 32-bit add/logic/shift-right/move 2 cycles, every other form 4",
+                         "measured": cl["measured_rates_source"]}
+    # int_mul_ops/s against the measured peak of the multiplier, inside this pass (counts / this pass's cycles)
+    mad_rate = mad["measured_saturated_cycles"] or 4.0
+    lane_mul_per_cycle = mad["per_permutation"] * n / cyc                   # 64-bit multiply-accumulates per shader cycle, whole chip
+    peak_per_cycle = 1024 * 64 / mad_rate
+    v["int_mul"] = {"v_mad_u64_u32_per_permutation": mad["per_permutation"], "of_which_in_the_80_sboxes": 33120,
+                    "lane_multiplies_per_cycle_chip": round(lane_mul_per_cycle, 1),
+                    "ubench_peak_per_cycle_chip": round(peak_per_cycle, 1), "saturated_cycles_per_v_mad_u64_u32": mad_rate,
+                    "frac_of_ubench_peak": round(lane_mul_per_cycle / peak_per_cycle, 4),
+                    "int_mul_ops_per_s_at_this_pass_clock": (lane_mul_per_cycle * cyc / (sq_ms * 1e-3)) if sq_ms else None,
+                    "share_of_issue_cycles": round(mad["per_permutation"] * mad_rate / cyc_wave_perm, 4)}
+    v["explanation"] = ("CDNA4 SIMD-32: a wave64 VALU instruction issues over 2 cycles, the multiplies and the other half-rate integer forms over 4. "
+                        "The kernel's stream is %d %% v_mad_u64_u32, %d %% other half-rate forms and %d %% plain 2-cycle forms; priced opcode by opcode at those "
+                        "nominal rates its floor is class_floor_cycles.nominal_per_opcode, and the measured cycles per wave-permutation are that floor / "
+                        "frac_of_class_floor.nominal_per_opcode (the looser bound `..._issued_in_2` pretends every non-multiply were a 2-cycle form). "
+                        "Priced instead at what each opcode costs in a saturated stream of ITSELF (tools/ubench_classes.hip, same counters) the sum lies ABOVE "
+                        "the kernel's measured cycles: the mixed stream issues faster than its opcodes do alone (a v_mad_u64_u32 costs at most %.2f cycles "
+                        "inside the kernel against %.2f alone), so that sum is no floor; it prices SURVEY.md 8(d)'s int-mul peak. "
+                        "The issue port is nearly saturated by THIS stream; what is left is the instruction count, above all the multiplies"
+                        % (round(100 * mad["share"]), round(100 * cl["per_class"].get("half-rate", 0) / cl["valu_insts_per_permutation_from_isa"]),
+                           round(100 * cl["per_class"].get("simple", 0) / cl["valu_insts_per_permutation_from_isa"]),
+                           (cyc_wave_perm - sum(r["per_permutation"] * r["priced_at"] for r in cl["opcodes"] if r["opcode"] != "v_mad_u64_u32")) / mad["per_permutation"],
+                           mad_rate))
 json.dump(res, open(os.path.join(P, "%s_permute_batch_traffic.json" % R), "w"), indent=1)
 print(json.dumps({k: res[k] for k in ("kernel_trace_avg_launch_ms", "kernel_trace_avg_excluding_first_ms", "hbm_bytes_per_launch",
                                       "algorithmic_bytes_per_launch", "valu_insts_per_wave", "valu_issue")}))
