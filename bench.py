@@ -762,7 +762,7 @@ def inprocess_child(n_dev):
         t3 = time.perf_counter()
         root = ds.root()
         n_shards = len(ds.shards())
-        agree = all((ds.shard_root(i) == root).all() for i in range(n_shards))
+        agree = all((ds.shard_root(i) == root).all() for i in range(n_shards)) if ds.units_per_slot == 1 else True
         ds.free()
         ds = m.dataset(cfg)                        # a second build on the warm handle: contexts, code objects and communicators exist
         t4 = time.perf_counter()

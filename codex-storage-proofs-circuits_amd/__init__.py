@@ -109,6 +109,8 @@ def load_library():
         "cp2_gen_fake_cells_dev": (i32, [vp, u64, u64, sz, sz, vp]),
         "cp2_cell_indices": (i32, [vp, vp, vp, u64, sz, vp]),
         "cp2_slot_trees_build_fake": (i32, [vp, u64, u64, sz, sz, sz, sz, pvp]),
+        "cp2_slot_trees_build_fake_units": (i32, [vp, u64, u64, u64, sz, sz, sz, sz, pvp]),
+        "cp2_slot_trees_build_file_units": (i32, [vp, cp, u64, u64, sz, sz, sz, sz, pvp]),
         "cp2_slot_trees_build_dev": (i32, [vp, vp, sz, sz, sz, sz, pvp]),
         "cp2_slot_trees_build_host": (i32, [vp, vp, sz, sz, sz, sz, pvp]),
         "cp2_slot_trees_free": (None, [vp]),
@@ -139,6 +141,8 @@ def load_library():
         "cp2_multi_last_error": (cp, [vp]),
         "cp2_multi_gather_mode": (cp, [vp]),
         "cp2_multi_set_policy": (i32, [vp, i32, u64]),
+        "cp2_multi_set_split": (i32, [vp, ctypes.c_int64]),
+        "cp2_multi_dataset_units_per_slot": (u64, [vp]),
         "cp2_shard_range": (None, [u64, i32, i32, ctypes.POINTER(u64), ctypes.POINTER(u64)]),
         "cp2_multi_dataset_build": (i32, [vp, ctypes.POINTER(Config), pvp]),
         "cp2_multi_dataset_build_cached": (i32, [vp, ctypes.POINTER(Config), cp, pvp]),
@@ -372,6 +376,18 @@ class Context:
         h = ctypes.c_void_p()
         self._ck(self.L.cp2_slot_trees_build_fake(self.h, dataset_seed, first_slot, n_slots, cell_size, block_size, n_cells,
                                                   ctypes.byref(h)), "cp2_slot_trees_build_fake")
+        return SlotTrees(self, h)
+
+    def slot_trees_fake_units(self, dataset_seed, units_per_slot, first_unit, n_units, cell_size, block_size, cells_per_unit):
+        h = ctypes.c_void_p()
+        self._ck(self.L.cp2_slot_trees_build_fake_units(self.h, dataset_seed, units_per_slot, first_unit, n_units, cell_size, block_size,
+                                                        cells_per_unit, ctypes.byref(h)), "cp2_slot_trees_build_fake_units")
+        return SlotTrees(self, h)
+
+    def slot_trees_file_units(self, file_base, units_per_slot, first_unit, n_units, cell_size, block_size, cells_per_unit):
+        h = ctypes.c_void_p()
+        self._ck(self.L.cp2_slot_trees_build_file_units(self.h, file_base.encode(), units_per_slot, first_unit, n_units, cell_size, block_size,
+                                                        cells_per_unit, ctypes.byref(h)), "cp2_slot_trees_build_file_units")
         return SlotTrees(self, h)
 
     def slot_trees_dev(self, d_cells, n_slots, cell_size, block_size, n_cells):
@@ -632,6 +648,10 @@ class Multi:
     def set_policy(self, gather=GATHER_AUTO, min_cells_per_device=0):
         self._ck(self.L.cp2_multi_set_policy(self.h, gather, min_cells_per_device), "cp2_multi_set_policy")
 
+    def set_split(self, units_per_slot=0):
+        """units every slot is cut into by Multi.dataset: 0 = choose, 1 = whole slots only, 2^k = exactly that"""
+        self._ck(self.L.cp2_multi_set_split(self.h, units_per_slot), "cp2_multi_set_split")
+
     def dataset(self, cfg, cache=None):
         return MultiDataset(self, cfg, cache=cache)
 
@@ -668,8 +688,12 @@ class MultiDataset:
         except Exception:
             pass
 
+    @property
+    def units_per_slot(self):
+        return self.multi.L.cp2_multi_dataset_units_per_slot(self.h)
+
     def shards(self):
-        """[(device, first_slot, n_local)] of every shard"""
+        """[(device, first, count)] of every shard: slots, or units when units_per_slot > 1"""
         L, out = self.multi.L, []
         for i in range(L.cp2_multi_dataset_shards(self.h)):
             d, a, b = ctypes.c_int(), ctypes.c_uint64(), ctypes.c_uint64()

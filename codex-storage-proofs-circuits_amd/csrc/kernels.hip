@@ -282,16 +282,25 @@ __global__ void __launch_bounds__(BT, CP2_HASH_WAVES) __attribute__((amdgpu_wave
 // Thread t makes "global cell" g = list ? list[t] : first + t.  With cells_per_slot != 0 the global
 // index spans several slots: slot = g / cells_per_slot uses seed0 + 1001*slot (dataset.nim:32, seed0
 // already holding the "+72" of the first slot) and the cell index inside the slot is g % cells_per_slot.
+// Slots cut into units (units_per_slot > 1: a slot's cells spread over several devices, `cells_per_slot` then counts
+// the cells of ONE unit): unit = first_unit + g / cells_per_slot, slot = unit / units_per_slot (seed0 = the seed of
+// slot 0 of the dataset) and the cell index inside the slot is (unit % units_per_slot) * cells_per_slot + g % cells_per_slot.
 __global__ void __launch_bounds__(TPB) k_gen_fake_cells(uint64_t seed0, uint64_t cells_per_slot, uint64_t first,
                                                           const uint64_t* __restrict__ list, size_t n_cells,
-                                                          size_t cell_size, uint8_t* __restrict__ out) {
+                                                          size_t cell_size, uint8_t* __restrict__ out,
+                                                          uint64_t units_per_slot, uint64_t first_unit) {
   __shared__ uint4 gen_stage[TPB / 64][64 * 9];
   size_t t = (size_t)blockIdx.x * TPB + threadIdx.x;
   const bool active = t < n_cells;
   if (!active && ((cell_size & 127) != 0 || (reinterpret_cast<uintptr_t>(out) & 15) != 0)) return;
   const uint64_t g = active ? (list ? list[t] : first + t) : 0;   // idle tail lanes only take part in the write-out
-  const uint64_t slot = cells_per_slot ? g / cells_per_slot : 0;
-  const uint64_t idx = cells_per_slot ? g - slot * cells_per_slot : g;
+  uint64_t slot = cells_per_slot ? g / cells_per_slot : 0;
+  uint64_t idx = cells_per_slot ? g - slot * cells_per_slot : g;
+  if (units_per_slot > 1) {          // `slot` so far is the unit's index inside this batch
+    const uint64_t unit = first_unit + slot;
+    slot = unit / units_per_slot;
+    idx += (unit - slot * units_per_slot) * cells_per_slot;
+  }
   const uint64_t seed1 = (seed0 + 1001 * slot) + 0xdeadcafeULL;
   const uint64_t seed2 = idx + 0x98765432ULL;
   uint64_t state = 1;
@@ -496,11 +505,11 @@ hipError_t launch_hash_cells(const void* cells, size_t cell_size, size_t n_cells
 }
 
 hipError_t launch_gen_fake_cells(uint64_t seed0, uint64_t cells_per_slot, uint64_t first, const uint64_t* list,
-                                 size_t n_cells, size_t cell_size, void* out, hipStream_t st) {
+                                 size_t n_cells, size_t cell_size, void* out, hipStream_t st, uint64_t units_per_slot, uint64_t first_unit) {
   if (n_cells == 0 || cell_size == 0) return hipSuccess;
   if (!fits_one_grid(n_cells)) return hipErrorInvalidValue;
   CP2K_LAUNCH(k_gen_fake_cells, dim3(grid_for(n_cells)), dim3(TPB), 0, st, seed0, cells_per_slot, first, list,
-                     n_cells, cell_size, (uint8_t*)out);
+                     n_cells, cell_size, (uint8_t*)out, units_per_slot, first_unit);
   return hipGetLastError();
 }
 

@@ -31,8 +31,11 @@ hipError_t launch_hash_cells(const void* cells, size_t cell_size, size_t n_cells
 hipError_t launch_hash_cells_block(int block, const void* cells, size_t cell_size, size_t n_cells, void* out, hipStream_t st);
 // cells_per_slot == 0: one slot with seed `seed0`; otherwise global cell g belongs to slot g / cells_per_slot
 // whose seed is seed0 + 1001 * slot.  list (device, may be NULL) selects explicit global cells.
+// units_per_slot > 1: slots cut into units of `cells_per_slot` cells each (batch-local unit g / cells_per_slot is unit
+// first_unit + that of the dataset, unit u lies in slot u / units_per_slot; seed0 = the seed of slot 0 of the dataset).
 hipError_t launch_gen_fake_cells(uint64_t seed0, uint64_t cells_per_slot, uint64_t first, const uint64_t* list,
-                                 size_t n_cells, size_t cell_size, void* out, hipStream_t st);
+                                 size_t n_cells, size_t cell_size, void* out, hipStream_t st, uint64_t units_per_slot = 1,
+                                 uint64_t first_unit = 0);
 // Sampling + path lookup for proof inputs, all on the device (sample/bn254.nim:16-27, merkle.nim:21-42,86-100,
 // types.nim:27-37): for item i < n_items (slot = slots ? slots[i] : slot0 + i, an index INSIDE the batch) and
 // counter c = 1..ns:  cell = low bits of sponge2[entropy, slotRoot, c];  indices[i*ns+c-1] = cell;

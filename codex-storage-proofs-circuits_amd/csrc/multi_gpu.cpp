@@ -14,6 +14,8 @@
 #include <rccl/rccl.h>   // types and prototypes only: the entry points are resolved with dlsym
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstdlib>
@@ -90,6 +92,7 @@ struct cp2_multi {
   int comm_world = 0;
   int gather = CP2_GATHER_AUTO;
   uint64_t min_cells = 0;                     // 0: RESIDENCY_CELLS
+  int64_t split = 0;                          // units per slot: 0 = choose, 1 = whole slots only, 2^k = exactly that (cp2_multi_set_split)
   std::string err, gather_note = "none yet";
   std::mutex mu;
 
@@ -157,6 +160,7 @@ extern "C" int cp2_multi_init(const int* devices, int n_dev, cp2_multi** out) tr
     if (d < 0 || d >= visible) return CP2_ERR_NO_DEVICE;
   m->ctxs.assign(m->devices.size(), nullptr);
   if (const char* e = std::getenv("CODEX_P2_MIN_CELLS")) m->min_cells = std::strtoull(e, nullptr, 10);   // see cp2_multi_set_policy
+  if (const char* e = std::getenv("CODEX_P2_SPLIT")) m->split = std::strtoll(e, nullptr, 10);              // see cp2_multi_set_split
   *out = m.release();
   return CP2_OK;
 } catch (const std::bad_alloc&) {
@@ -188,21 +192,46 @@ extern "C" int cp2_multi_set_policy(cp2_multi* m, int gather, uint64_t min_cells
   return CP2_OK;
 }
 
+extern "C" int cp2_multi_set_split(cp2_multi* m, int64_t units_per_slot) {
+  if (!m || units_per_slot < 0 || (units_per_slot > 1 && !is_pow2((uint64_t)units_per_slot))) return CP2_ERR_INVALID;
+  m->split = units_per_slot;
+  return CP2_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // sharded dataset
 // ---------------------------------------------------------------------------------------------
+// Two ways to cut a dataset over the devices (same contiguous-range rule, cp2_shard_range):
+//   by SLOTS  every device holds whole slots as a cp2_dataset of its own: everything the single-context API offers works per
+//             shard (streamed builds, caches, batched exports), and each device serves its own slots' proof inputs.
+//   by UNITS  every slot is cut into S = 2^s units of n_cells / S cells (whole blocks, at least two), the n_slots * S units are
+//             dealt out contiguously: what SURVEY.md 8(e) calls "the same scheme one level down" -- for datasets of FEW, LARGE
+//             slots (one 128 GiB slot over eight GPUs; 11 slots over 8 GPUs, where whole slots would leave the busiest device
+//             with 2 and the others with 1).  A unit's root is a node of its slot's tree; after the exchange of unit roots the
+//             log2 S upper layers of every slot tree and the dataset tree are built once, and a proof input is put together
+//             from the unit paths of whichever devices hold the sampled cells plus the upper path.
 struct cp2_multi_dataset {
   cp2_multi* m = nullptr;
   cp2_config cfg{};
   std::string file_base;
-  struct Shard { int dev = 0; uint64_t first = 0, count = 0; cp2_dataset* ds = nullptr; };
-  std::vector<Shard> shards;
-  ~cp2_multi_dataset() { for (auto& s : shards) cp2_dataset_free(s.ds); }
-  Shard* owner(uint64_t slot) {
+  struct Shard { int dev = 0; uint64_t first = 0, count = 0; cp2_dataset* ds = nullptr; cp2_slot_trees* units = nullptr; };
+  std::vector<Shard> shards;                 // ranges count slots (by slots) or units (by units)
+  uint64_t units_per_slot = 1;               // S; 1 = by slots
+  // by units: host copies of the upper layers (layer k of ALL slots contiguous: n_slots * (S >> k) elements) and the dataset tree
+  std::vector<uint8_t> upper;
+  std::vector<size_t> upper_off;
+  std::vector<uint8_t> dlayers;
+  std::vector<size_t> dsizes;
+  ~cp2_multi_dataset() {
+    for (auto& s : shards) { cp2_dataset_free(s.ds); cp2_slot_trees_free(s.units); }
+  }
+  bool by_units() const { return units_per_slot > 1; }
+  Shard* owner(uint64_t item) {              // the shard holding slot `item` (by slots) or unit `item` (by units)
     for (auto& s : shards)
-      if (slot >= s.first && slot < s.first + s.count) return &s;
+      if (item >= s.first && item < s.first + s.count) return &s;
     return nullptr;
   }
+  const uint8_t* slot_root(uint64_t slot) const { return &upper[(upper_off.back() + slot) * 32]; }
 };
 
 namespace {
@@ -225,21 +254,32 @@ struct DeviceRestore {   // the caller's current device is left as it was found
   ~DeviceRestore() { if (dev >= 0) (void)hipSetDevice(dev); }
 };
 
-// The exchange step: every shard's slot roots to every device, then the dataset tree everywhere.
-int gather_roots_and_build_trees(cp2_multi_dataset* mds) {
-  cp2_multi* m = mds->m;
-  const size_t world = mds->shards.size();
-  const uint64_t n = mds->cfg.n_slots;
+// One shard's contribution to the exchange: `count` roots in device memory of `ctx`, rows [first, first + count) of the whole.
+struct RootsPart { cp2_ctx* ctx; const void* d_roots; uint64_t first, count; };
+// What the exchange leaves behind: all n roots on EVERY device (dev[i], in memory owned by this object), or in host memory.
+struct Exchanged {
+  std::vector<DevBuf> gath, all;
+  std::vector<const void*> dev;
+  std::vector<uint8_t> host;
+  bool on_device = false;
+};
+
+// THE exchange step: every shard's roots to every device.  RCCL (device to device) when every shard sits on its own device and
+// librccl loads; host memory otherwise.  One shard and no RCCL by name: nothing moves.
+int exchange_roots(cp2_multi* m, const std::vector<RootsPart>& parts, uint64_t n, Exchanged& ex) {
+  const size_t world = parts.size();
+  ex.dev.assign(world, nullptr);
   if (world == 1 && m->gather != CP2_GATHER_RCCL) {   // (RCCL asked for by name: a communicator of one rank, as a self-test of the path)
     m->gather_note = "none (one shard: nothing to exchange)";
-    return cp2_dataset_set_roots(mds->shards[0].ds, nullptr);
+    ex.dev[0] = parts[0].d_roots;
+    ex.on_device = true;
+    return CP2_OK;
   }
   DeviceRestore restore;
-  // RCCL needs one rank per DISTINCT device
-  bool distinct = true;
+  bool distinct = true;                        // RCCL needs one rank per DISTINCT device
   for (size_t i = 0; i < world; ++i)
     for (size_t j = 0; j < i; ++j)
-      if (m->devices[mds->shards[i].dev] == m->devices[mds->shards[j].dev]) distinct = false;
+      if (parts[i].ctx->device == parts[j].ctx->device) distinct = false;
   std::string why;
   bool use_rccl = m->gather != CP2_GATHER_HOST;
   if (use_rccl && !distinct) { use_rccl = false; why = "a device holds more than one shard"; }
@@ -265,20 +305,20 @@ int gather_roots_and_build_trees(cp2_multi_dataset* mds) {
   }
   if (use_rccl) {
     Rccl& r = Rccl::get();
-    const uint64_t max_rows = (n + world - 1) / world;
-    const bool even = n % world == 0;
-    std::vector<DevBuf> gath(world), all(world);
+    uint64_t max_rows = 0;
+    bool even = true;
+    for (auto& p : parts) { max_rows = std::max(max_rows, p.count); even = even && p.count == parts[0].count; }
+    ex.gath = std::vector<DevBuf>(world);
+    ex.all = std::vector<DevBuf>(world);
     for (size_t i = 0; i < world; ++i) {        // this shard's roots into its own row block of its gather buffer
-      cp2_ctx* ctx = cp2_dataset_ctx(mds->shards[i].ds);
+      cp2_ctx* ctx = parts[i].ctx;
       CP2_HIP(ctx, hipSetDevice(ctx->device));
-      CP2_TRY(gath[i].scratch(ctx, world * max_rows * 32));
-      CP2_TRY(cp2_dataset_copy_local_roots_dev(mds->shards[i].ds, gath[i].u8() + i * max_rows * 32));
+      CP2_TRY(ex.gath[i].scratch(ctx, world * max_rows * 32));
+      CP2_HIP(ctx, hipMemcpyAsync(ex.gath[i].u8() + i * max_rows * 32, parts[i].d_roots, parts[i].count * 32, hipMemcpyDeviceToDevice, ctx->stream));
     }
     ncclResult_t e = r.GroupStart();
-    for (size_t i = 0; i < world && e == ncclSuccess; ++i) {
-      cp2_ctx* ctx = cp2_dataset_ctx(mds->shards[i].ds);
-      e = r.AllGather(gath[i].u8() + i * max_rows * 32, gath[i].p, max_rows * 32, ncclUint8, m->comms[i], ctx->stream);   // in place
-    }
+    for (size_t i = 0; i < world && e == ncclSuccess; ++i)
+      e = r.AllGather(ex.gath[i].u8() + i * max_rows * 32, ex.gath[i].p, max_rows * 32, ncclUint8, m->comms[i], parts[i].ctx->stream);   // in place
     ncclResult_t e2 = r.GroupEnd();
     if (e == ncclSuccess) e = e2;
     if (e != ncclSuccess) {
@@ -286,25 +326,103 @@ int gather_roots_and_build_trees(cp2_multi_dataset* mds) {
       return CP2_ERR_HIP;
     }
     m->gather_note = "rccl (in-place ncclAllGather of " + std::to_string(max_rows * 32) + " bytes per rank over " + std::to_string(world) + " devices)";
-    return for_each_shard(world, [&](size_t i) -> int {
-      cp2_ctx* ctx = cp2_dataset_ctx(mds->shards[i].ds);
-      CP2_HIP(ctx, hipSetDevice(ctx->device));
-      const void* roots = gath[i].p;
-      if (!even) {                               // shards differ by one row: close the gaps of the padded layout
-        CP2_TRY(all[i].scratch(ctx, n * 32));
-        for (size_t r2 = 0; r2 < world; ++r2)
-          CP2_HIP(ctx, hipMemcpyAsync(all[i].u8() + mds->shards[r2].first * 32, gath[i].u8() + r2 * max_rows * 32, mds->shards[r2].count * 32,
-                                      hipMemcpyDeviceToDevice, ctx->stream));
-        roots = all[i].p;
-      }
-      return cp2_dataset_set_roots_dev(mds->shards[i].ds, roots);
-    });
+    for (size_t i = 0; i < world; ++i) {
+      cp2_ctx* ctx = parts[i].ctx;
+      ex.dev[i] = ex.gath[i].p;
+      if (even) continue;
+      CP2_HIP(ctx, hipSetDevice(ctx->device));   // shards differ by one row: close the gaps of the padded layout
+      CP2_TRY(ex.all[i].scratch(ctx, n * 32));
+      for (size_t r2 = 0; r2 < world; ++r2)
+        CP2_HIP(ctx, hipMemcpyAsync(ex.all[i].u8() + parts[r2].first * 32, ex.gath[i].u8() + r2 * max_rows * 32, parts[r2].count * 32,
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+      ex.dev[i] = ex.all[i].p;
+    }
+    ex.on_device = true;
+    return CP2_OK;
   }
-  // host gather: one download per shard, one upload per device
+  // host gather: one download per shard (and one upload per device by whoever consumes ex.host)
   m->gather_note = "host (" + (why.empty() ? std::string("requested") : why) + ")";
-  std::vector<uint8_t> roots(n * 32);
-  for (auto& s : mds->shards) CP2_TRY(cp2_dataset_local_roots(s.ds, roots.data() + s.first * 32));
-  return for_each_shard(world, [&](size_t i) { return cp2_dataset_set_roots(mds->shards[i].ds, roots.data()); });
+  ex.host.assign(n * 32, 0);
+  for (auto& p : parts) {
+    CP2_HIP(p.ctx, hipSetDevice(p.ctx->device));
+    CP2_HIP(p.ctx, hipMemcpyAsync(ex.host.data() + p.first * 32, p.d_roots, p.count * 32, hipMemcpyDeviceToHost, p.ctx->stream));
+    CP2_HIP(p.ctx, hipStreamSynchronize(p.ctx->stream));
+  }
+  return CP2_OK;
+}
+
+// by slots: the exchange, then the dataset tree on every device
+int gather_roots_and_build_trees(cp2_multi_dataset* mds) {
+  cp2_multi* m = mds->m;
+  const size_t world = mds->shards.size();
+  std::vector<RootsPart> parts;
+  for (auto& s : mds->shards) parts.push_back({cp2_dataset_ctx(s.ds), cp2_dataset_local_roots_dev(s.ds), s.first, s.count});
+  Exchanged ex;
+  CP2_TRY(exchange_roots(m, parts, mds->cfg.n_slots, ex));
+  return for_each_shard(world, [&](size_t i) -> int {
+    return ex.on_device ? cp2_dataset_set_roots_dev(mds->shards[i].ds, ex.dev[i]) : cp2_dataset_set_roots(mds->shards[i].ds, ex.host.data());
+  });
+}
+
+// by units: the exchange of unit roots, then -- once, on the first device -- the log2 S upper layers of every slot tree
+// (inner layers of gen_input/bn254.nim:29's tree: keys 0, never the bottom rule) and the dataset tree over the slot roots.
+int gather_unit_roots_and_build_upper(cp2_multi_dataset* mds) {
+  cp2_multi* m = mds->m;
+  const uint64_t S = mds->units_per_slot, n_slots = mds->cfg.n_slots, n_units = n_slots * S;
+  std::vector<RootsPart> parts;
+  for (auto& s : mds->shards) parts.push_back({s.units->ctx, cp2_slot_trees_roots_dev(s.units), s.first, s.count});
+  for (auto& p : parts) {                          // the unit trees are complete before their roots travel
+    CP2_HIP(p.ctx, hipSetDevice(p.ctx->device));
+    CP2_HIP(p.ctx, hipStreamSynchronize(p.ctx->stream));
+  }
+  Exchanged ex;
+  CP2_TRY(exchange_roots(m, parts, n_units, ex));
+  DeviceRestore restore;
+  cp2_ctx* ctx = parts[0].ctx;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  size_t levels = 0;
+  while (((uint64_t)1 << levels) < S) ++levels;
+  size_t total = 0;
+  mds->upper_off.clear();
+  for (size_t k = 0; k <= levels; ++k) { mds->upper_off.push_back(total); total += n_slots * (S >> k); }
+  DevBuf up, dtree;
+  CP2_TRY(up.scratch(ctx, total * 32));
+  if (ex.on_device) CP2_HIP(ctx, hipMemcpyAsync(up.p, ex.dev[0], n_units * 32, hipMemcpyDeviceToDevice, ctx->stream));
+  else CP2_HIP(ctx, hipMemcpyAsync(up.p, ex.host.data(), n_units * 32, hipMemcpyHostToDevice, ctx->stream));
+  for (size_t k = 0; k < levels; ++k)
+    CP2_HIP(ctx, cp2k::launch_compress_layer(up.u8() + mds->upper_off[k] * 32, up.u8() + mds->upper_off[k + 1] * 32, S >> k, n_slots, false,
+                                             S >> k, S >> (k + 1), ctx->stream));
+  mds->dsizes = layer_sizes_of(n_slots);
+  const size_t dtotal = cp2_merkle_total(n_slots);
+  CP2_TRY(dtree.scratch(ctx, dtotal * 32));
+  CP2_TRY(merkle_trees_dev(ctx, up.u8() + mds->upper_off[levels] * 32, n_slots, 1, dtree.p, false));   // gen_input/bn254.nim:49-50
+  mds->upper.assign(total * 32, 0);
+  mds->dlayers.assign(dtotal * 32, 0);
+  CP2_HIP(ctx, hipMemcpyAsync(mds->upper.data(), up.p, total * 32, hipMemcpyDeviceToHost, ctx->stream));
+  CP2_HIP(ctx, hipMemcpyAsync(mds->dlayers.data(), dtree.p, dtotal * 32, hipMemcpyDeviceToHost, ctx->stream));
+  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return CP2_OK;
+}
+
+double imbalance(uint64_t items, uint64_t world) { return (double)((items + world - 1) / world * world) / (double)items; }
+
+// How many units to cut every slot into: 1 (whole slots) while the busiest device holds at most 6 % more than its share,
+// else the smallest power of two that gets there (units are at least two whole blocks).
+uint64_t choose_units_per_slot(const cp2_config& c, uint64_t world, int64_t forced) {
+  if (c.cell_size == 0 || c.block_size % c.cell_size) return 1;
+  const uint64_t cpb = c.block_size / c.cell_size;
+  if (!is_pow2(c.n_cells) || !is_pow2(cpb) || c.n_cells / cpb < 4) return 1;
+  const uint64_t max_s = c.n_cells / cpb / 2;
+  if (forced >= 1) return (is_pow2((uint64_t)forced) && (uint64_t)forced <= max_s) ? (uint64_t)forced : 1;
+  if (world <= 1 || imbalance(c.n_slots, world) <= 1.06) return 1;
+  uint64_t best = 1;
+  double best_imb = imbalance(c.n_slots, world);
+  for (uint64_t S = 2; S <= max_s && S <= 4096; S <<= 1) {
+    const double imb = imbalance(c.n_slots * S, world);
+    if (imb < best_imb - 0.03) { best = S; best_imb = imb; }
+    if (imb <= 1.06) break;
+  }
+  return best;
 }
 
 enum class BuildKind { Plain, Streamed, Cached };
@@ -314,20 +432,25 @@ int multi_build(cp2_multi* m, const cp2_config* cfg, BuildKind kind, const uint8
   if (!m || !cfg || !out) return CP2_ERR_INVALID;
   *out = nullptr;
   m->err.clear();
-  if (cfg->n_slots == 0) return CP2_ERR_INVALID;
+  if (cfg->n_slots == 0 || cfg->max_depth < 0 || cfg->max_log2_nslots < 0) return CP2_ERR_INVALID;
   // how many devices get a shard: every device when there is a residency of hashing for each, fewer for small datasets
   const uint64_t min_cells = m->min_cells ? m->min_cells : RESIDENCY_CELLS;
   const unsigned __int128 total_cells = (unsigned __int128)cfg->n_slots * cfg->n_cells;
   uint64_t world = (uint64_t)std::min<unsigned __int128>((total_cells + min_cells - 1) / min_cells, m->devices.size());
-  world = std::max<uint64_t>(1, std::min<uint64_t>(world, cfg->n_slots));
+  world = std::max<uint64_t>(1, world);
+  // whole slots or units: streamed and cached builds keep whole slots (their per-slot state lives in a cp2_dataset)
+  uint64_t S = 1;
+  if (kind == BuildKind::Plain && m->split != 1) S = choose_units_per_slot(*cfg, world, m->split);
+  world = std::min<uint64_t>(world, cfg->n_slots * S);
   std::unique_ptr<cp2_multi_dataset> mds(new cp2_multi_dataset());
   mds->m = m;
   mds->cfg = *cfg;
   if (cfg->file_base) { mds->file_base = cfg->file_base; mds->cfg.file_base = mds->file_base.c_str(); }
+  mds->units_per_slot = S;
   mds->shards.resize(world);
   for (uint64_t r = 0; r < world; ++r) {
     mds->shards[r].dev = (int)r;
-    cp2_shard_range(cfg->n_slots, (int)r, (int)world, &mds->shards[r].first, &mds->shards[r].count);
+    cp2_shard_range(cfg->n_slots * S, (int)r, (int)world, &mds->shards[r].first, &mds->shards[r].count);
   }
   const int per = std::max(1, threads / (int)world);
   std::vector<std::string> errs(world);
@@ -338,32 +461,106 @@ int multi_build(cp2_multi* m, const cp2_config* cfg, BuildKind kind, const uint8
     cp2_ctx* ctx = m->ctx_of(s.dev, &cst);
     if (!ctx) { errs[i] = "device " + std::to_string(m->devices[s.dev]) + ": " + cp2_strerror(cst); return cst; }
     int r = CP2_OK;
-    if (kind == BuildKind::Streamed) r = cp2_dataset_build_streamed(ctx, &mds->cfg, s.first, s.count, entropy, per, group_slots, &s.ds);
-    else if (kind == BuildKind::Cached) {
+    if (S > 1) {
+      r = cfg->file_base ? cp2_slot_trees_build_file_units(ctx, mds->file_base.c_str(), S, s.first, s.count, cfg->cell_size, cfg->block_size, cfg->n_cells / S, &s.units)
+                         : cp2_slot_trees_build_fake_units(ctx, cfg->seed, S, s.first, s.count, cfg->cell_size, cfg->block_size, cfg->n_cells / S, &s.units);
+    } else if (kind == BuildKind::Streamed) {
+      r = cp2_dataset_build_streamed(ctx, &mds->cfg, s.first, s.count, entropy, per, group_slots, &s.ds);
+    } else if (kind == BuildKind::Cached) {
       const std::string path = world == 1 ? std::string(cache_path) : std::string(cache_path) + ".shard" + std::to_string(i) + "of" + std::to_string(world);
       r = cp2_dataset_build_cached(ctx, &mds->cfg, s.first, s.count, path.c_str(), &s.ds);
-    } else r = cp2_dataset_build(ctx, &mds->cfg, s.first, s.count, &s.ds);
-    if (r != CP2_OK) errs[i] = "device " + std::to_string(m->devices[s.dev]) + ", slots " + std::to_string(s.first) + ".." + std::to_string(s.first + s.count) +
-                               ": " + (*cp2_last_error(ctx) ? cp2_last_error(ctx) : cp2_strerror(r));
+    } else {
+      r = cp2_dataset_build(ctx, &mds->cfg, s.first, s.count, &s.ds);
+    }
+    if (r != CP2_OK) errs[i] = "device " + std::to_string(m->devices[s.dev]) + (S > 1 ? ", units " : ", slots ") + std::to_string(s.first) + ".." +
+                               std::to_string(s.first + s.count) + ": " + (*cp2_last_error(ctx) ? cp2_last_error(ctx) : cp2_strerror(r));
     return r;
   });
   if (st != CP2_OK) {
     for (auto& e : errs) if (!e.empty()) { m->err = e; break; }
     return st;
   }
-  trace.lap(("slot trees on " + std::to_string(world) + " device context(s)").c_str());
-  st = gather_roots_and_build_trees(mds.get());
+  trace.lap((std::string(S > 1 ? "unit trees on " : "slot trees on ") + std::to_string(world) + " device context(s)").c_str());
+  st = S > 1 ? gather_unit_roots_and_build_upper(mds.get()) : gather_roots_and_build_trees(mds.get());
   trace.lap(("slot roots exchanged: " + m->gather_note).c_str());
   if (st != CP2_OK) {
     if (m->err.empty())
       for (auto& s : mds->shards) {
-        const char* e = cp2_last_error(cp2_dataset_ctx(s.ds));
+        const char* e = cp2_last_error(s.ds ? cp2_dataset_ctx(s.ds) : s.units->ctx);
         if (e && *e) { m->err = e; break; }
       }
     return st;
   }
   *out = mds.release();
   return CP2_OK;
+}
+
+// generateProofInput (gen_input/bn254.nim:35-79) for a dataset cut by units: the cell indices from the slot root, the bottom
+// part of every path from the unit that holds the sampled cell (on whichever device that is), the top part from the upper
+// layers, the cells regenerated / read, all of it handed to the byte-exact writer's object (cp2_proof_input_create).
+int units_proof_input(cp2_multi_dataset* mds, uint64_t slot, const uint8_t entropy[32], cp2_proof_input** out) {
+  const cp2_config& c = mds->cfg;
+  cp2_multi* m = mds->m;
+  if (slot >= c.n_slots) return CP2_ERR_INVALID;
+  if (c.n_samples && c.n_cells < 2) return CP2_ERR_INVALID;                        // extractLowBits asserts k > 0, types/bn254.nim:48
+  const uint64_t S = mds->units_per_slot, P = c.n_cells / S, cpb = c.block_size / c.cell_size;
+  const size_t ns = c.n_samples, md = (size_t)c.max_depth, cs = c.cell_size;
+  size_t levels = 0;
+  while (((uint64_t)1 << levels) < S) ++levels;
+  const size_t depth_unit = (layer_sizes_of(cpb).size() - 1) + (layer_sizes_of(P / cpb).size() - 1);
+  if (depth_unit + levels > md) return CP2_ERR_INVALID;                            // padMerkleProof assert, types.nim:29
+  if (mds->dsizes.size() - 1 > (size_t)c.max_log2_nslots) return CP2_ERR_INVALID;  // the same for slotProof
+  cp2_ctx* ctx0 = mds->shards[0].units->ctx;
+  std::vector<uint64_t> idx(ns);
+  if (ns) CP2_TRY(cp2_cell_indices(ctx0, entropy, mds->slot_root(slot), c.n_cells, ns, idx.data()));   // sample/bn254.nim:16-27
+  std::vector<uint8_t> paths(ns * md * 32, 0), leaves(ns * 32), cells(ns * cs);
+  // samples grouped by the unit that holds them
+  std::vector<std::vector<size_t>> by_unit(S);
+  for (size_t i = 0; i < ns; ++i) by_unit[idx[i] / P].push_back(i);
+  for (uint64_t q = 0; q < S; ++q) {
+    if (by_unit[q].empty()) continue;
+    auto* sh = mds->owner(slot * S + q);
+    if (!sh) return CP2_ERR_INVALID;
+    const size_t k = by_unit[q].size();
+    std::vector<uint64_t> local(k);
+    for (size_t j = 0; j < k; ++j) local[j] = idx[by_unit[q][j]] % P;
+    std::vector<uint8_t> up(k * depth_unit * 32), lf(k * 32);
+    int st = cp2_slot_trees_paths(sh->units, (size_t)(slot * S + q - sh->first), local.data(), k, depth_unit, up.data(), lf.data());
+    if (st != CP2_OK) { m->err = cp2_last_error(sh->units->ctx); return st; }
+    for (size_t j = 0; j < k; ++j) {
+      const size_t i = by_unit[q][j];
+      std::memcpy(&paths[i * md * 32], &up[j * depth_unit * 32], depth_unit * 32);                        // merkleProof inside the unit
+      for (size_t lv = 0; lv < levels; ++lv) {                                                            // ... and above it
+        const uint64_t sib = (q >> lv) ^ 1;
+        std::memcpy(&paths[(i * md + depth_unit + lv) * 32], &mds->upper[(mds->upper_off[lv] + slot * (S >> lv) + sib) * 32], 32);
+      }
+      std::memcpy(&leaves[i * 32], &lf[j * 32], 32);
+    }
+  }
+  // the sampled cells (slot.nim:57-73)
+  if (c.file_base) {
+    const std::string fname = slot_file_name(mds->file_base, slot);
+    const int fd = open(fname.c_str(), O_RDONLY);
+    if (fd < 0) { m->err = "cannot open " + fname; return CP2_ERR_IO; }
+    for (size_t i = 0; i < ns; ++i) read_file_cell(fd, cs, idx[i], &cells[i * cs]);
+    close(fd);
+  } else {
+    for (size_t i = 0; i < ns; ++i) CP2_TRY(cp2_gen_fake_cells(ctx0, cp2_slot_seed(c.seed, slot), idx[i], 1, cs, &cells[i * cs]));
+  }
+  // slotProof = padMerkleProof(merkleProof(dsetTree, slotIdx), maxLog2NSlots), gen_input/bn254.nim:51,72
+  std::vector<uint8_t> proof((size_t)c.max_log2_nslots * 32, 0);
+  {
+    size_t k = slot, mm = c.n_slots, off = 0;
+    for (size_t i = 0; i + 1 < mds->dsizes.size(); ++i) {
+      const size_t j = k ^ 1;
+      if (j < mm) std::memcpy(&proof[i * 32], &mds->dlayers[(off + j) * 32], 32);
+      off += mds->dsizes[i];
+      k >>= 1;
+      mm = (mm + 1) >> 1;
+    }
+  }
+  return cp2_proof_input_create(&c, slot, &mds->dlayers[mds->dlayers.size() - 32], entropy, mds->slot_root(slot), proof.data(), ns, idx.data(),
+                                cells.data(), paths.data(), leaves.data(), out);
 }
 
 }  // namespace
@@ -398,18 +595,20 @@ extern "C" int cp2_multi_dataset_build_streamed(cp2_multi* m, const cp2_config* 
 extern "C" void cp2_multi_dataset_free(cp2_multi_dataset* mds) { delete mds; }
 
 extern "C" int cp2_multi_dataset_shards(const cp2_multi_dataset* mds) { return mds ? (int)mds->shards.size() : 0; }
+extern "C" uint64_t cp2_multi_dataset_units_per_slot(const cp2_multi_dataset* mds) { return mds ? mds->units_per_slot : 0; }
 
-extern "C" cp2_dataset* cp2_multi_dataset_shard(cp2_multi_dataset* mds, int i, int* device, uint64_t* first_slot, uint64_t* n_local) {
+extern "C" cp2_dataset* cp2_multi_dataset_shard(cp2_multi_dataset* mds, int i, int* device, uint64_t* first, uint64_t* count) {
   if (!mds || i < 0 || i >= (int)mds->shards.size()) return nullptr;
   const auto& s = mds->shards[i];
   if (device) *device = mds->m->devices[s.dev];
-  if (first_slot) *first_slot = s.first;
-  if (n_local) *n_local = s.count;
+  if (first) *first = s.first;
+  if (count) *count = s.count;
   return s.ds;
 }
 
 extern "C" int cp2_multi_dataset_root(cp2_multi_dataset* mds, uint8_t out[32]) try {
   if (!mds || !out || mds->shards.empty()) return CP2_ERR_INVALID;
+  if (mds->by_units()) { std::memcpy(out, &mds->dlayers[mds->dlayers.size() - 32], 32); return CP2_OK; }
   return cp2_dataset_root(mds->shards[0].ds, out);
 } catch (...) {
   return CP2_ERR_INVALID;
@@ -417,16 +616,19 @@ extern "C" int cp2_multi_dataset_root(cp2_multi_dataset* mds, uint8_t out[32]) t
 
 extern "C" int cp2_multi_dataset_slot_roots(cp2_multi_dataset* mds, uint8_t* out) try {
   if (!mds || !out) return CP2_ERR_INVALID;
+  if (mds->by_units()) { std::memcpy(out, mds->slot_root(0), mds->cfg.n_slots * 32); return CP2_OK; }
   for (auto& s : mds->shards) CP2_TRY(cp2_dataset_local_roots(s.ds, out + s.first * 32));
   return CP2_OK;
 } catch (...) {
   return CP2_ERR_INVALID;
 }
 
-// generateProofInputBN254 (gen_input/bn254.nim:35-79) on the device that holds the slot
+// generateProofInputBN254 (gen_input/bn254.nim:35-79) on the device that holds the slot (or, by units, from every device that
+// holds one of its sampled cells)
 extern "C" int cp2_multi_proof_input_generate(cp2_multi_dataset* mds, uint64_t slot_idx, const uint8_t entropy[32], cp2_proof_input** out) try {
-  if (!mds || !out) return CP2_ERR_INVALID;
+  if (!mds || !out || !entropy) return CP2_ERR_INVALID;
   *out = nullptr;
+  if (mds->by_units()) return units_proof_input(mds, slot_idx, entropy, out);
   auto* s = mds->owner(slot_idx);
   if (!s) return CP2_ERR_INVALID;                                  // slot index out of range
   int st = cp2_proof_input_generate(s->ds, slot_idx, entropy, out);
@@ -442,6 +644,25 @@ extern "C" int cp2_multi_proof_input_generate(cp2_multi_dataset* mds, uint64_t s
 extern "C" int cp2_multi_dataset_export_proof_inputs(cp2_multi_dataset* mds, const uint64_t* slot_idx, size_t n, const uint8_t entropy[32],
                                                      const char* dir, int threads, size_t batch, uint64_t* total_bytes) try {
   if (!mds || !entropy || (n && !slot_idx)) return CP2_ERR_INVALID;
+  if (mds->by_units()) {                                           // few, large slots: one proof input after the other
+    uint64_t tot = 0;
+    for (size_t i = 0; i < n; ++i) {
+      cp2_proof_input* p = nullptr;
+      CP2_TRY(units_proof_input(mds, slot_idx[i], entropy, &p));
+      std::unique_ptr<cp2_proof_input, void (*)(cp2_proof_input*)> guard(p, cp2_proof_input_free);
+      char* text = nullptr;
+      size_t len = 0;
+      if (dir) {
+        const std::string name = std::string(dir) + "/input_" + std::to_string(slot_idx[i]) + ".json";
+        CP2_TRY(cp2_proof_input_write_json(p, name.c_str()));
+      }
+      CP2_TRY(cp2_proof_input_json(p, &text, &len));
+      cp2_free_buffer(text);
+      tot += len;
+    }
+    if (total_bytes) *total_bytes = tot;
+    return CP2_OK;
+  }
   const size_t world = mds->shards.size();
   std::vector<std::vector<uint64_t>> part(world);
   for (size_t i = 0; i < n; ++i) {
@@ -466,7 +687,7 @@ extern "C" int cp2_multi_dataset_export_proof_inputs(cp2_multi_dataset* mds, con
 }
 
 extern "C" int cp2_multi_dataset_export_streamed(cp2_multi_dataset* mds, const char* dir, int threads, uint64_t* total_bytes) try {
-  if (!mds) return CP2_ERR_INVALID;
+  if (!mds || mds->by_units()) return CP2_ERR_INVALID;
   const size_t world = mds->shards.size();
   const int per = std::max(1, threads / (int)world);
   std::vector<uint64_t> bytes(world, 0);
@@ -482,7 +703,7 @@ extern "C" int cp2_multi_dataset_export_streamed(cp2_multi_dataset* mds, const c
 }
 
 extern "C" int cp2_multi_dataset_streamed_json(cp2_multi_dataset* mds, uint64_t slot_idx, char** text, size_t* len) try {
-  if (!mds || !text) return CP2_ERR_INVALID;
+  if (!mds || !text || mds->by_units()) return CP2_ERR_INVALID;
   auto* s = mds->owner(slot_idx);
   if (!s) return CP2_ERR_INVALID;
   return cp2_dataset_streamed_json(s->ds, slot_idx, text, len);

@@ -433,7 +433,8 @@ int enqueue_sampling(cp2_slot_trees* t, const cp2k::TreeGeom& g, SampleDev& d, S
   CP2_HIP(ctx, hipMemcpyAsync(host.leaves.p, d.leaves.p, total * 32, hipMemcpyDeviceToHost, st));
   if (!fetch_cells) return CP2_OK;   // host-side sources: the caller reads the sampled cells itself
   if (t->src == CellSrc::Fake) {
-    CP2_HIP(ctx, cp2k::launch_gen_fake_cells(cp2_slot_seed(t->dataset_seed, t->first_slot), t->n_cells, 0, gcell, total, cs, d.cells.p, st));
+    CP2_HIP(ctx, cp2k::launch_gen_fake_cells(cp2_slot_seed(t->dataset_seed, t->units_per_slot > 1 ? 0 : t->first_slot), t->n_cells, 0, gcell, total, cs,
+                                             d.cells.p, st, t->units_per_slot, t->first_slot));
   } else if (t->src == CellSrc::Dev && t->d_cells) {
     CP2_HIP(ctx, cp2k::launch_gather_rows(t->d_cells, gcell, total, cs, d.cells.p, st));
   } else {
@@ -503,12 +504,12 @@ static int host_cells_global(cp2_slot_trees* t, const uint64_t* g, size_t n, uin
         size_t slot = g[i] / t->n_cells, cell = g[i] % t->n_cells;
         if (slot != open_slot) {
           if (fd >= 0) close(fd);
-          std::string fname = slot_file_name(t->file_base, t->first_slot + slot);
+          std::string fname = slot_file_name(t->file_base, (t->first_slot + slot) / t->units_per_slot);
           fd = open(fname.c_str(), O_RDONLY);
           if (fd < 0) { failed[w] = fname; return; }
           open_slot = slot;
         }
-        read_file_cell(fd, cs, cell, out + i * cs);
+        read_file_cell(fd, cs, ((t->first_slot + slot) % t->units_per_slot) * t->n_cells + cell, out + i * cs);
       }
       if (fd >= 0) close(fd);
     };

@@ -199,8 +199,10 @@ struct LayerScheduler {
 }  // namespace
 
 int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_slot, size_t n_slots, size_t cell_size,
-                           size_t block_size, size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out) {
+                           size_t block_size, size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out,
+                           uint64_t units_per_slot) {
   *out = nullptr;
+  if (units_per_slot == 0) return CP2_ERR_INVALID;
   CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   std::unique_ptr<cp2_slot_trees> t(trees_new(ctx, n_slots, cell_size, block_size, n_cells));
@@ -208,6 +210,7 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
   t->src = CellSrc::Fake;
   t->dataset_seed = dataset_seed;
   t->first_slot = first_slot;
+  t->units_per_slot = units_per_slot;
   StageTimer trace;
   CP2_TRY(trees_layout(t.get()));
   const size_t total_cells = n_slots * n_cells;
@@ -220,7 +223,9 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
   CP2_TRY(stage[0].scratch(ctx, chunk * cell_size));
   if (two) CP2_TRY(stage[1].scratch(ctx, chunk * cell_size));
   trace.lap("fake slots: node + staging buffers");
-  const uint64_t seed0 = cp2_slot_seed(dataset_seed, first_slot);
+  // whole slots: the seed of the batch's first slot, the generator counts slots from there; units: the seed of slot 0 of the
+  // dataset, the generator places unit first_slot + i inside slot (first_slot + i) / units_per_slot
+  const uint64_t seed0 = cp2_slot_seed(dataset_seed, units_per_slot > 1 ? 0 : first_slot);
   LayerScheduler sched{t.get(), group, done};
   // Groups (the streamed proof-input path): what follows a group on the host -- the JSON bodies of its slots -- overlaps the
   // hashing of the NEXT group, so the last group's formatting overlaps nothing.  When a chunk is a whole number of slots the
@@ -239,7 +244,7 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
       n = (left >= 2 * g_slots ? g_slots : (left > g_min ? std::max(g_min, (left + 1) / 2) : left)) * n_cells;
     }
     const int s = group ? 0 : (int)(turn & 1);                 // generation + hashing of this chunk on stream s, in its own staging buffer
-    hipError_t e = cp2k::launch_gen_fake_cells(seed0, n_cells, c0, nullptr, n, cell_size, stage[s].p, sched.hs[s]);
+    hipError_t e = cp2k::launch_gen_fake_cells(seed0, n_cells, c0, nullptr, n, cell_size, stage[s].p, sched.hs[s], units_per_slot, first_slot);
     if (e == hipSuccess) e = cp2k::launch_hash_cells(stage[s].p, cell_size, n, t->nodes.u8() + c0 * 32, sched.hs[s]);
     if (e != hipSuccess) { ctx->err = hipGetErrorString(e); st = CP2_ERR_HIP; break; }
     st = sched.hashed_on(s);
@@ -257,6 +262,37 @@ extern "C" int cp2_slot_trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, ui
                                          size_t cell_size, size_t block_size, size_t n_cells, cp2_slot_trees** out) try {
   if (!ctx || !out) return CP2_ERR_INVALID;
   return trees_build_fake(ctx, dataset_seed, first_slot, n_slots, cell_size, block_size, n_cells, 0, nullptr, out);
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
+}
+
+// Units: `n_units` consecutive pieces of `cells_per_unit` cells, unit u = cells [(u % units_per_slot) * cells_per_unit, ...) of
+// slot u / units_per_slot.  The root of a unit is the node of that slot's tree (gen_input/bn254.nim:21-30) above its cells
+// (cells_per_unit / cellsPerBlock >= 2 blocks, a power of two, so that the unit's layers ARE layers of the slot tree).
+extern "C" int cp2_slot_trees_build_fake_units(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t units_per_slot, uint64_t first_unit,
+                                               size_t n_units, size_t cell_size, size_t block_size, size_t cells_per_unit,
+                                               cp2_slot_trees** out) try {
+  if (!ctx || !out || units_per_slot == 0) return CP2_ERR_INVALID;
+  CP2_TRY(trees_check_geometry(cell_size, block_size, cells_per_unit, n_units));
+  const size_t nb = cells_per_unit / (block_size / cell_size);
+  if (units_per_slot > 1 && (nb < 2 || !is_pow2(nb))) return CP2_ERR_INVALID;
+  return trees_build_fake(ctx, dataset_seed, first_unit, n_units, cell_size, block_size, cells_per_unit, 0, nullptr, out, units_per_slot);
+} catch (const std::bad_alloc&) {
+  return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
+} catch (...) {
+  return CP2_ERR_INVALID;
+}
+
+extern "C" int cp2_slot_trees_build_file_units(cp2_ctx* ctx, const char* file_base, uint64_t units_per_slot, uint64_t first_unit,
+                                               size_t n_units, size_t cell_size, size_t block_size, size_t cells_per_unit,
+                                               cp2_slot_trees** out) try {
+  if (!ctx || !out || !file_base || units_per_slot == 0) return CP2_ERR_INVALID;
+  CP2_TRY(trees_check_geometry(cell_size, block_size, cells_per_unit, n_units));
+  const size_t nb = cells_per_unit / (block_size / cell_size);
+  if (units_per_slot > 1 && (nb < 2 || !is_pow2(nb))) return CP2_ERR_INVALID;
+  return trees_build_files(ctx, file_base, first_unit, n_units, cell_size, block_size, cells_per_unit, 0, nullptr, out, units_per_slot);
 } catch (const std::bad_alloc&) {
   return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
 } catch (...) {
@@ -450,8 +486,10 @@ extern "C" int cp2_slot_trees_build_host(cp2_ctx* ctx, const uint8_t* cells, siz
 
 // slot files "<base><k>.dat" (dataset.nim:34) streamed through the ingestion pipe; short files read as zeros
 int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t first_slot, size_t n_slots, size_t cell_size,
-                            size_t block_size, size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out) {
+                            size_t block_size, size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out,
+                            uint64_t units_per_slot) {
   *out = nullptr;
+  if (units_per_slot == 0) return CP2_ERR_INVALID;
   CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   std::unique_ptr<cp2_slot_trees> t(trees_new(ctx, n_slots, cell_size, block_size, n_cells));
@@ -459,6 +497,7 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
   t->src = CellSrc::File;
   t->file_base = base;
   t->first_slot = first_slot;
+  t->units_per_slot = units_per_slot;
   CP2_TRY(trees_layout(t.get()));
   int st = CP2_OK;
   {
@@ -476,7 +515,10 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
       pipe.cell_multiple = IngestPipe::DIRECT_ALIGN / g;
     }
     for (size_t s = 0; st == CP2_OK && s < n_slots; ++s) {
-      std::string fname = slot_file_name(base, first_slot + s);
+      // unit s of the batch = cells [unit_off, unit_off + n_cells) of the file of slot (first_slot + s) / units_per_slot
+      const uint64_t unit = first_slot + s;
+      const size_t unit_off = (size_t)(unit % units_per_slot) * n_cells * cell_size;
+      std::string fname = slot_file_name(base, unit / units_per_slot);
       int fd = open(fname.c_str(), O_RDONLY);
       if (fd < 0) { ctx->err = "cannot open " + fname; st = CP2_ERR_IO; break; }
       const int dfd = want_direct ? open(fname.c_str(), O_RDONLY | O_DIRECT) : -1;
@@ -485,7 +527,7 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
         uint8_t* buf = nullptr;
         st = pipe.acquire(&buf);
         if (st != CP2_OK) break;
-        const size_t off = c0 * cell_size;
+        const size_t off = unit_off + c0 * cell_size;
         const bool direct = dfd >= 0 && off % IngestPipe::DIRECT_ALIGN == 0;
         // bytes [off, off+n) of the file into the pinned buffer, zero-filled past EOF (slot.nim:61-66)
         pipe.parallel_ranges(m * cell_size, (size_t)2 << 20, [=](size_t a, size_t b) {
@@ -644,6 +686,7 @@ std::vector<uint64_t> file_stamps(const std::string& base, uint64_t first_slot, 
 // write of chunk i-1 overlap, and no host copy of the whole node buffer exists (8 GiB for 32 768 slots of 2^12 cells).
 extern "C" int cp2_slot_trees_save(cp2_slot_trees* t, const char* path) try {
   if (!t || !path) return CP2_ERR_INVALID;
+  if (t->units_per_slot != 1) return CP2_ERR_INVALID;   // the file format describes whole slots
   cp2_ctx* ctx = t->ctx;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   TreeFileHeader h{};

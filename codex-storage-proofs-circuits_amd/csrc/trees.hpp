@@ -18,6 +18,10 @@ struct cp2_slot_trees {
   // where sampled cells come from
   CellSrc src = CellSrc::Fake;
   uint64_t dataset_seed = 0, first_slot = 0;
+  // Slots cut into units (several devices sharing ONE slot, multi_gpu.cpp): this batch then holds `n_slots` UNITS of `n_cells`
+  // cells each, unit i being unit first_slot + i of the dataset, unit u = cells [(u % units_per_slot) * n_cells, +n_cells) of
+  // slot u / units_per_slot.  1: a unit is a whole slot (everything outside multi_gpu.cpp).
+  uint64_t units_per_slot = 1;
   const uint8_t* d_cells = nullptr;     // not owned
   const uint8_t* h_cells = nullptr;     // not owned
   std::string file_base;
@@ -34,10 +38,12 @@ using SlotsDone = std::function<int(cp2_slot_trees* t, size_t s0, size_t s1, hip
 
 int trees_check_geometry(size_t cell_size, size_t block_size, size_t n_cells, size_t n_slots);
 // fake-data or slot-file trees; `group` = how many finished slots to batch per layer pass / callback (0: all at the end)
+// units_per_slot > 1: first_slot / n_slots / n_cells count UNITS and the cells of one unit (cp2_slot_trees above)
 int trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_slot, size_t n_slots, size_t cell_size, size_t block_size,
-                     size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out);
+                     size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out, uint64_t units_per_slot = 1);
 int trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t first_slot, size_t n_slots, size_t cell_size,
-                      size_t block_size, size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out);
+                      size_t block_size, size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out,
+                      uint64_t units_per_slot = 1);
 void trees_geom(const cp2_slot_trees* t, cp2k::TreeGeom* g);
 // node-row indices of the merged path of `cell` in slot `slot` (host twin of k_sample_paths' row arithmetic)
 void path_rows(const cp2_slot_trees* t, size_t slot, uint64_t cell, size_t max_depth, uint64_t* rows);

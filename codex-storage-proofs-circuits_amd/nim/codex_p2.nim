@@ -74,6 +74,7 @@ proc cp2_multi_ctx(m: Cp2Multi, i: cint): Cp2Ctx {.importc.}
 proc cp2_multi_last_error(m: Cp2Multi): cstring {.importc.}
 proc cp2_multi_gather_mode(m: Cp2Multi): cstring {.importc.}
 proc cp2_multi_set_policy(m: Cp2Multi, gather: cint, minCellsPerDevice: uint64): cint {.importc.}
+proc cp2_multi_set_split(m: Cp2Multi, unitsPerSlot: int64): cint {.importc.}
 proc cp2_multi_dataset_build(m: Cp2Multi, cfg: ptr Cp2Config, ds: ptr Cp2MultiDataset): cint {.importc.}
 proc cp2_multi_dataset_build_streamed(m: Cp2Multi, cfg: ptr Cp2Config, entropy: ptr byte, threads: cint, groupSlots: csize_t,
                                       ds: ptr Cp2MultiDataset): cint {.importc.}
@@ -286,6 +287,10 @@ proc engineDevices*(): int =
 proc engineGatherMode*(): string =
   ## what the last build's exchange of slot roots went through: "rccl (...)", "host (<why>)", "none (one shard ...)"
   $cp2_multi_gather_mode(multi())
+
+proc engineSetSplit*(unitsPerSlot: int) =
+  ## units every slot is cut into when a dataset of few, large slots is spread over several GPUs: 0 choose, 1 whole slots only
+  check(cp2_multi_set_split(multi(), int64(unitsPerSlot)), "cp2_multi_set_split")
 
 proc engineSetPolicy*(gather: int, minCellsPerDevice: uint64) =
   ## 0 auto / 1 RCCL / 2 host gather; cells of hashing a device must have to get a shard (0: one hash-kernel residency)

@@ -151,6 +151,18 @@ typedef struct cp2_slot_trees cp2_slot_trees;
 /* slots first_slot..first_slot+n_slots-1 of a fake-data dataset (cells generated on the device) */
 int cp2_slot_trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_slot, size_t n_slots,
                               size_t cell_size, size_t block_size, size_t n_cells, cp2_slot_trees** out);
+/* The same for UNITS: every slot cut into `units_per_slot` (a power of two) pieces of `cells_per_unit` cells -- whole blocks,
+ * at least two, a power of two of them -- and this batch holding units first_unit .. first_unit + n_units - 1 of the dataset
+ * (unit u = cells [(u mod units_per_slot) x cells_per_unit, + cells_per_unit) of slot u / units_per_slot).  The root of a unit is
+ * the node of its slot's tree above those cells, so several devices can share ONE slot (section e, "by units"; SURVEY.md 8e:
+ * "within one very large slot the same scheme applies one level down").  cp2_slot_trees_roots / _paths address units as
+ * slots of cells_per_unit cells.  Unit batches are not cached (cp2_slot_trees_save refuses them). */
+int cp2_slot_trees_build_fake_units(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t units_per_slot, uint64_t first_unit, size_t n_units,
+                                    size_t cell_size, size_t block_size, size_t cells_per_unit, cp2_slot_trees** out);
+/* units of slot files "<file_base><slot>.dat" (dataset.nim:34): unit u is read at byte offset (u mod units_per_slot) x
+ * cells_per_unit x cell_size of the file of slot u / units_per_slot */
+int cp2_slot_trees_build_file_units(cp2_ctx* ctx, const char* file_base, uint64_t units_per_slot, uint64_t first_unit, size_t n_units,
+                                    size_t cell_size, size_t block_size, size_t cells_per_unit, cp2_slot_trees** out);
 /* n_slots slots whose cells are already in device memory, slot-major (n_slots x n_cells x cell_size bytes).
  * A `_dev`-style call: the hashing is ENQUEUED on the context's stream and the call returns without synchronising
  * (the cells must stay valid until then).  cp2_sync, cp2_slot_trees_roots and cp2_slot_trees_paths synchronise;
@@ -296,7 +308,13 @@ int cp2_write_circom_main(const cp2_config* cfg, const char* path);
  *   - Small datasets use fewer devices: a device gets a shard only when there is at least `min_cells_per_device` cells of
  *     hashing for it (default: one residency of the hash kernel, 768 x 256 cells -- a device with less finishes no sooner),
  *     so the reference's default run (11 slots x 512 cells, workflow/params.sh) stays on one GPU and pays one context.
- *   - Contexts are created on first use; cp2_multi_ctx(m, i) hands one out for the seam calls and the tuning knobs. */
+ *   - Contexts are created on first use; cp2_multi_ctx(m, i) hands one out for the seam calls and the tuning knobs.
+ *   - Datasets of FEW, LARGE slots are cut BY UNITS instead of by whole slots: when whole slots would leave the busiest device
+ *     more than 6 % above its share (11 slots on 8 GPUs: 2 against 1.375; ONE 128 GiB slot on 8 GPUs), every slot is cut into
+ *     S = 2^s units of nCells / S cells (cp2_slot_trees_build_*_units), the nSlots x S units are dealt out contiguously, the
+ *     unit roots exchanged, and the log2 S upper layers of every slot tree plus the dataset tree built once; a proof input then
+ *     takes the bottom of each path from whichever device holds the sampled cell.  cp2_multi_dataset_build only (streamed and
+ *     cached builds keep whole slots); cp2_multi_set_split / CODEX_P2_SPLIT override (1 = whole slots only). */
 typedef struct cp2_multi cp2_multi;
 typedef struct cp2_multi_dataset cp2_multi_dataset;
 enum { CP2_GATHER_AUTO = 0, CP2_GATHER_RCCL = 1, CP2_GATHER_HOST = 2 };
@@ -314,6 +332,9 @@ const char* cp2_multi_gather_mode(const cp2_multi* m);
  * CP2_GATHER_HOST.  min_cells_per_device: 0 = the default above (or the environment variable CODEX_P2_MIN_CELLS, read by
  * cp2_multi_init); 1 = always spread over every device. */
 int cp2_multi_set_policy(cp2_multi* m, int gather, uint64_t min_cells_per_device);
+/* units per slot for cp2_multi_dataset_build: 0 = choose (above; or the environment variable CODEX_P2_SPLIT), 1 = whole slots
+ * only, a power of two = exactly that many (ignored where the geometry does not allow it: units are >= 2 whole blocks). */
+int cp2_multi_set_split(cp2_multi* m, int64_t units_per_slot);
 /* the split rule: contiguous ranges, the first (n_items mod world) ranks hold one item more */
 void cp2_shard_range(uint64_t n_items, int rank, int world, uint64_t* first, uint64_t* count);
 /* cp2_dataset_build / _build_cached / _build_streamed for ALL cfg->n_slots slots over the devices of `m`, including the
@@ -325,8 +346,11 @@ int cp2_multi_dataset_build_streamed(cp2_multi* m, const cp2_config* cfg, const 
                                      cp2_multi_dataset** out);
 void cp2_multi_dataset_free(cp2_multi_dataset* mds);
 int cp2_multi_dataset_shards(const cp2_multi_dataset* mds);
-/* shard i: its dataset (owned by mds; every single-dataset call works on it), device index and slot range */
-cp2_dataset* cp2_multi_dataset_shard(cp2_multi_dataset* mds, int i, int* device, uint64_t* first_slot, uint64_t* n_local);
+/* 1 when the dataset is cut by whole slots, else the number of units every slot was cut into */
+uint64_t cp2_multi_dataset_units_per_slot(const cp2_multi_dataset* mds);
+/* shard i: device index and its range of slots (or of units); by whole slots also its dataset (owned by mds; every
+ * single-dataset call works on it), by units NULL */
+cp2_dataset* cp2_multi_dataset_shard(cp2_multi_dataset* mds, int i, int* device, uint64_t* first, uint64_t* count);
 int cp2_multi_dataset_root(cp2_multi_dataset* mds, uint8_t out[32]);
 int cp2_multi_dataset_slot_roots(cp2_multi_dataset* mds, uint8_t* out /* n_slots x 32 */);
 /* replaces `generateProofInputBN254`, gen_input/bn254.nim:35-79, on whichever device holds `slot_idx` */

@@ -56,7 +56,7 @@ def c_type_class(t, array=False):
     t = re.sub(r"\s+", " ", t).replace(" *", "*")
     stars = t.count("*") + (1 if array else 0)
     base = t.replace("*", "").strip()
-    scalar = {"int": "i32", "int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "void": "void",
+    scalar = {"int": "i32", "int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "int64_t": "i64", "size_t": "usize", "void": "void",
               "uint8_t": "u8", "char": "char"}
     if base in HANDLES:
         return ("handle:" + HANDLES[base],) * 1 if stars == 1 else "ptr(handle:%s)" % HANDLES[base] if stars == 2 else "?"
@@ -120,7 +120,7 @@ NIM_HANDLES = {"Cp2Ctx": "ctx", "Cp2Dataset": "dataset", "Cp2ProofInput": "proof
 
 def nim_type_class(t):
     t = re.sub(r"\s+", " ", t.strip())
-    scalar = {"cint": "i32", "int32": "i32", "uint32": "u32", "uint64": "u64", "csize_t": "usize", "byte": "u8", "uint8": "u8"}
+    scalar = {"cint": "i32", "int32": "i32", "uint32": "u32", "uint64": "u64", "int64": "i64", "csize_t": "usize", "byte": "u8", "uint8": "u8"}
     if t in scalar:
         return scalar[t]
     if t in NIM_HANDLES:

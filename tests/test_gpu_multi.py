@@ -97,6 +97,7 @@ def test_small_datasets_stay_on_one_device_unless_told_otherwise(pkg, golden):
     assert ds.proof_input(m0["slotIndex"], m0["entropy"]).json() == want
     ds.free()
     m.set_policy(pkg.GATHER_AUTO, 1)
+    m.set_split(1)                                               # whole slots only (left to itself it would cut these 11 slots by units)
     ds = m.dataset(cfg)
     assert [(f, k) for _, f, k in ds.shards()] == [(0, 4), (4, 4), (8, 3)] and m.gather_mode().startswith("host")
     assert ds.proof_input(m0["slotIndex"], m0["entropy"]).json() == want
@@ -197,12 +198,132 @@ def test_cli_twin_spreads_over_contexts_without_a_new_flag(pkg, golden, tmp_path
     assert r.returncode != 0 and "no usable gfx950 HIP device" in r.stderr      # a device that is not there: loud, no fallback
 
 
+# ---- by units: several devices sharing ONE slot ("within one very large slot the same scheme one level down") ----
+def test_unit_roots_and_paths_are_pieces_of_the_slot_tree(pkg, ctx, oracle, tmp_path):
+    """cp2_slot_trees_build_fake_units / _file_units: the root of a unit is the node of its slot's tree above the unit's cells,
+    and a path inside a unit is the bottom of the merged path of the same cell (merkle.nim:21-42,86-100) -- against the oracle's
+    full slot trees; a batch that starts and ends in the middle of slots."""
+    C, P = oracle
+    cs, bs, nc, S, seed = 256, 2048, 256, 4, 4711                    # 8 cells per block, 32 blocks per slot, units of 8 blocks
+    cpb, P_cells = bs // cs, nc // S
+    first, n_units = 3, 6                                            # units 3 .. 8: the tail of slot 0, all of slot 1, the head of slot 2
+    t = ctx.slot_trees_fake_units(seed, S, first, n_units, cs, bs, P_cells)
+    assert t.count == n_units and t.depth == 3 + 3
+    roots = t.roots()
+    big = {}
+    for slot in (0, 1, 2):
+        big[slot] = C.merkle_tree(C.fake_slot_block_roots(C.slot_seed(seed, slot), cs, bs, nc, 4))
+    for i in range(n_units):
+        u = first + i
+        assert np.array_equal(roots[i], big[u // S][3][u % S]), u     # layer 3 of the slot's tree: one node per 8 blocks
+    # paths of a few cells of unit 5 (= second unit of slot 1), against merkleProof on the oracle's block tree + slot tree
+    u, local = 5, [0, 7, 8, 63]
+    got, leaves = t.paths(u - first, local, 6)
+    cells1 = C.gen_fake_cells(C.slot_seed(seed, 1), 0, nc, cs)
+    hashes = C.hash_cells(cells1, cs, threads=4)
+    to_int = lambda layers: [C.array_to_felts(l) for l in layers]    # noqa: E731
+    for j, c_local in enumerate(local):
+        c_slot = (u % S) * P_cells + c_local
+        b = c_slot // cpb
+        mini = to_int(C.merkle_tree(hashes[b * cpb:(b + 1) * cpb]))
+        full = P.merge_merkle_proofs(P.merkle_proof(mini, c_slot % cpb), P.merkle_proof(to_int(big[1]), b))
+        assert pkg.array_to_felts(got[j]) == full["merklePath"][:6], c_local
+        assert np.array_equal(leaves[j], hashes[c_slot])
+    t.free()
+    # the same units read from slot files at their byte offsets
+    base = str(tmp_path / "slot")
+    for slot in (0, 1, 2):
+        C.gen_fake_cells(C.slot_seed(seed, slot), 0, nc, cs).tofile("%s%d.dat" % (base, slot))
+    tf = ctx.slot_trees_file_units(base, S, first, n_units, cs, bs, P_cells)
+    assert np.array_equal(tf.roots(), roots)
+    tf.free()
+    with pytest.raises(pkg.CodexP2Error):
+        ctx.slot_trees_fake_units(seed, 32, 0, 4, cs, bs, cpb)       # a unit must hold at least two whole blocks
+
+
+@pytest.mark.parametrize("name,devices,want_units,want_counts", [("params_default", [0, 0, 0], 4, [15, 15, 14]),
+                                                                  ("testmain_small", [0, 0], 2, [5, 5]),
+                                                                  ("odd_slots_one_block", [0, 0], 1, [2, 1])])
+def test_few_large_slots_are_cut_by_units(pkg, golden, tmp_path, name, devices, want_units, want_counts):
+    """The reference's own configurations over 2-3 contexts: 11 slots over 3 would leave 4 / 4 / 3 (9 % over the busiest
+    device's share), so every slot is cut into 4 units (44 units: 15 / 15 / 14); one block per slot cannot be cut (whole
+    slots).  input.json equals the committed oracle text either way, and cp2_multi_dataset_export_proof_inputs writes it."""
+    m0 = golden("proof_inputs.json")["inputs"][name]
+    cfg = pkg.make_config(**m0["config"])
+    want = golden("input_%s.json" % name)
+    m = pkg.Multi(devices)
+    m.set_policy(pkg.GATHER_AUTO, 1)
+    ds = m.dataset(cfg)
+    assert ds.units_per_slot == want_units and [k for _, _, k in ds.shards()] == want_counts
+    assert ds.proof_input(m0["slotIndex"], m0["entropy"]).json() == want
+    out = tmp_path / "out"
+    out.mkdir()
+    total = ds.export_proof_inputs([m0["slotIndex"], 0], m0["entropy"], str(out), threads=2)
+    assert open(out / ("input_%d.json" % m0["slotIndex"])).read() == want
+    assert total == len(want) + os.path.getsize(out / "input_0.json")
+    single = pkg.Context(0)
+    ref = single.dataset(cfg)
+    assert np.array_equal(ds.slot_roots(), ref.local_roots()) and np.array_equal(ds.root(), ref.root())
+    assert open(out / "input_0.json").read() == ref.proof_input(0, m0["entropy"]).json()
+    ref.free()
+    single.close()
+    ds.free()
+    m.set_split(1)                                                   # whole slots only, by request
+    ds = m.dataset(cfg)
+    assert ds.units_per_slot == 1 and ds.proof_input(m0["slotIndex"], m0["entropy"]).json() == want
+    ds.free()
+    m.close()
+
+
+def test_units_from_slot_files_and_one_slot_over_several_contexts(pkg, oracle, tmp_path):
+    """SlotFile source by units (every context reads ITS byte range of the slot files), and the extreme of the scheme: a dataset
+    of ONE slot over four contexts -- against the oracle directly."""
+    C, P = oracle
+    c = dict(maxDepth=12, maxLog2NSlots=2, cellSize=128, blockSize=1024, nSlots=1, nCells=512, nSamples=11)
+    base = str(tmp_path / "slot")
+    C.gen_fake_cells(C.slot_seed(99, 0), 0, 512, 128).tofile(base + "0.dat")
+    m = pkg.Multi([0, 0, 0, 0])
+    m.set_policy(pkg.GATHER_AUTO, 1)
+    for src in (dict(seed=99), dict(file=base)):
+        ds = m.dataset(pkg.make_config(**c, **src))
+        assert ds.units_per_slot == 4 and [(f, k) for _, f, k in ds.shards()] == [(0, 1), (1, 1), (2, 1), (3, 1)]
+        want = P.export_json(expected_proof_input_fast(C, P, dict(c, seed=99), 0, 31337, threads=4))
+        assert ds.proof_input(0, 31337).json() == want
+        ds.free()
+    m.close()
+
+
 # ---- SURVEY.md 8(d), config 5's other stated scale-down: several slots at the nominal 8 GiB slot size ------------------
 def _big(golden):
     try:
         return golden("bigslots.json")
     except FileNotFoundError:
         pytest.skip("tests/golden/bigslots.json not generated (tests/golden/make_bigslots_golden.py)")
+
+
+def test_bigslots_by_units_over_three_contexts_and_one_8gib_slot_over_two(pkg, golden):
+    """8 slots of 8 GiB over three contexts: whole slots would be 3 / 3 / 2, so every slot is cut into 4 units of 2^20 cells
+    (32 units: 11 / 11 / 10) and slots 2 and 5 are shared by two contexts each; then ONE 8 GiB slot over two contexts (config 3's
+    slot, two units of 4 GiB).  Slot roots, dataset root and input.json against the oracle-only fixtures."""
+    g = _big(golden)
+    c = g["config"]
+    m = pkg.Multi([0, 0, 0])
+    ds = m.dataset(pkg.make_config(**c))
+    assert ds.units_per_slot == 4 and [k for _, _, k in ds.shards()] == [11, 11, 10]
+    assert [hexroot(r) for r in ds.slot_roots()] == g["slot_roots_hex"] and hexroot(ds.root()) == g["dataset_root_hex"]
+    for slot in (0, 2, 5, 7):
+        text = ds.proof_input(slot, g["entropy"]).json()
+        assert tsha(text) == g["inputs"][str(slot)]["json_sha256"] and len(text) == g["inputs"][str(slot)]["json_bytes"], slot
+    ds.free()
+    m.close()
+    m = pkg.Multi([0, 0])
+    ds = m.dataset(pkg.make_config(**dict(c, nSlots=1, maxLog2NSlots=1)))
+    assert ds.units_per_slot == 2 and [k for _, _, k in ds.shards()] == [1, 1]
+    assert hexroot(ds.slot_roots()[0]) == golden("fullsize.json")["config3"]["slot_root_hex"] == g["slot_roots_hex"][0]
+    pi = ds.proof_input(0, g["entropy"])
+    assert [int(v) for v in pi.cell_indices()[:8]] == g["cell_indices_first8"][0]
+    ds.free()
+    m.close()
 
 
 @pytest.mark.parametrize("devices", [[0], [0, 0]])

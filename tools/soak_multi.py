@@ -18,7 +18,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20261004)
 single = pkg.Context(0)
 handles = {n: pkg.Multi([0] * n) for n in (2, 3, 4)}          # long-lived handles: contexts and their scratch pools are reused
 t0 = time.time()
-it = bad = checked_roots = checked_json = 0
+it = bad = checked_roots = checked_json = by_units = 0
 free0 = None
 tmp = tempfile.mkdtemp(prefix="cp2soakm")
 modes = Counter()
@@ -40,6 +40,8 @@ while time.time() - t0 < budget:
     # min cells per device 1: every context gets a shard (as many as there are slots); a random larger value: fewer shards
     min_cells = int(rng.choice([1, 1, 1, nc * max(1, n_slots // 2), 1 << 30]))
     m.set_policy(int(rng.choice([pkg.GATHER_AUTO, pkg.GATHER_HOST])), min_cells)
+    split = int(rng.choice([0, 0, 1, 2, 4]))                   # choose / whole slots only / every slot cut into 2 or 4 units
+    m.set_split(split)
     use_file = (it % 5 == 0) and (cs & 3) == 0 and not big
     cc = dict(c)
     if use_file:
@@ -61,10 +63,12 @@ while time.time() - t0 < budget:
         ds = m.dataset(cfg, cache=cache)                       # ... and loaded
     shards = ds.shards()
     modes[m.gather_mode().split(" ")[0]] += 1
-    want_world = min(n_ctx, n_slots, max(1, -(-n_slots * nc // max(1, min_cells))))
-    if len(shards) != want_world or [(f, k) for _, f, k in shards] != [pkg.shard_range(n_slots, r, len(shards)) for r in range(len(shards))]:
+    S = ds.units_per_slot
+    by_units += S > 1
+    want_world = min(n_ctx, n_slots * S, max(1, -(-n_slots * nc // max(1, min_cells))))
+    if (kind != 0 and S != 1) or len(shards) != want_world or [(f, k) for _, f, k in shards] != [pkg.shard_range(n_slots * S, r, len(shards)) for r in range(len(shards))]:
         bad += 1
-        print("WRONG SPLIT", c, n_ctx, min_cells, shards, flush=True)
+        print("WRONG SPLIT", c, n_ctx, min_cells, split, S, shards, flush=True)
     # every slot root and the dataset root against the C oracle (as EVERY shard's device computed the latter)
     want_roots = np.stack([C.fake_slot_root(C.slot_seed(c["seed"], s), cs, cs * cpb, nc, 8) for s in range(n_slots)])
     want_root = C.merkle_root(want_roots)
@@ -73,12 +77,15 @@ while time.time() - t0 < budget:
     if not np.array_equal(got_roots, want_roots):
         bad += 1
         print("MISMATCH slot roots", c, shards, flush=True)
-    for i in range(len(shards)):
+    if not np.array_equal(ds.root(), want_root):
+        bad += 1
+        print("MISMATCH dataset root", c, shards, flush=True)
+    for i in range(len(shards) if S == 1 else 0):              # by whole slots every device builds the dataset tree itself
         if not np.array_equal(ds.shard_root(i), want_root):
             bad += 1
             print("MISMATCH dataset root on shard", i, c, shards, flush=True)
     # proof inputs: an edge slot against the oracle, a random slot against the single-context object path
-    edge = int(rng.choice([f for _, f, k in shards] + [f + k - 1 for _, f, k in shards]))
+    edge = int(rng.choice([f // S for _, f, k in shards] + [(f + k - 1) // S for _, f, k in shards]))   # a slot on a shard edge
     s_rand = int(rng.integers(0, n_slots))
     if kind == 1:
         ds.export_streamed(None, threads=threads)
@@ -108,10 +115,10 @@ while time.time() - t0 < budget:
         free, total = torch.cuda.mem_get_info()
         if free0 is None:
             free0 = free
-        print("iteration %d  bad=%d  roots checked %d  json vs oracle %d  gather %s  maxrss %.0f MB  device free %.2f GiB (first reading %.2f)  %.0f s" %
-              (it, bad, checked_roots, checked_json, dict(modes), resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024, free / 2**30, free0 / 2**30,
+        print("iteration %d  bad=%d  roots checked %d  json vs oracle %d  by units %d  gather %s  maxrss %.0f MB  device free %.2f GiB (first reading %.2f)  %.0f s" %
+              (it, bad, checked_roots, checked_json, by_units, dict(modes), resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024, free / 2**30, free0 / 2**30,
                time.time() - t0), flush=True)
 shutil.rmtree(tmp, ignore_errors=True)
-print("multi-context soak done: %d iterations, %d roots and %d input.json texts checked against the oracle, gather modes %s, mismatches: %d, %.0f s" %
-      (it, checked_roots, checked_json, dict(modes), bad, time.time() - t0))
+print("multi-context soak done: %d iterations (%d of them cut by units), %d roots and %d input.json texts checked against the oracle, gather modes %s, mismatches: %d, %.0f s" %
+      (it, by_units, checked_roots, checked_json, dict(modes), bad, time.time() - t0))
 sys.exit(1 if bad else 0)
