@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--states", type=int, default=N_STATES, help="states per step per GPU (default 2^24)")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-3 / config-4 / ingest / config-5 extra legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-child-legs", action="store_true",
+                    help="skip the legs that start child processes (dataset_inprocess, cli_default): for runs under a counter-collecting profiler")
     ap.add_argument("--inprocess-leg", type=int, default=0, metavar="N",
                     help="(child mode of the dataset_inprocess leg) build config 5's scale-down on N devices in THIS process through cp2_multi_* and print one JSON object")
     args = ap.parse_args()
@@ -326,10 +328,11 @@ def main():
         except Exception as e:
             extra["dataset_big_slots_error"] = repr(e)
         try:
-            extra.update(inprocess_leg(torch, dist, ctx, rank, world))
+            if not args.no_child_legs:
+                extra.update(inprocess_leg(torch, dist, ctx, rank, world))
         except Exception as e:
             extra["dataset_inprocess_error"] = repr(e)
-        if world == 1:
+        if world == 1 and not args.no_child_legs:
             try:
                 extra.update(cli_default_leg(pkg, g))
             except Exception as e:

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence bench.py's roofline refers to.  Run ON THE GPU BOX from the repo root:
-#   bash tools/profile_round.sh r03
+#   bash tools/profile_round.sh r04
 # kernel-trace/stats and every --pmc group are separate runs (gpurun refuses --pmc combined with trace domains).
 # The program after `--` is python3 itself (no env / bash -c hop: the profiler's preload initialises the GPU first).
 set -e
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/prof_$R
 cd $GRAFT_REPO_ROOT
@@ -23,7 +23,7 @@ echo "traffic done" >> $O/progress.txt
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/sq -- $B > $O/sq.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/sq2 -- $B > $O/sq2.log 2>&1 || true
 # config 3's kernel (k_hash_cells over the 8 GiB slot): HBM bytes against the algorithmic 8 GiB + leaves
-H="python3 bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline"
+H="python3 bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline --no-child-legs"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/hfetch -- $H > $O/hfetch.log 2>&1 || true
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/hwrite -- $H > $O/hwrite.log 2>&1 || true
 # saturated issue cost of every opcode of the kernel's stream, with the same counters (tools/ubench_classes.hip; its binary is built in-tree

@@ -7,7 +7,20 @@ O = os.path.join(ROOT, "gpurun_out", "prof_" + R)
 P = os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 newest = lambda pattern: sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]   # gpurun_out/ accumulates runs
-stats = newest(os.path.join(O, "kt", "*", "*_kernel_stats.csv"))[0]
+def main_process_file(pattern, key_col):
+    """The kernel-trace directory holds one set of files per PROCESS (bench.py's child legs are traced too): the bench process
+    itself is the one with the most k_permute_batch launches."""
+    best, best_n = None, -1
+    for f in glob.glob(pattern):
+        n = sum(1 for r in csv.DictReader(open(f)) if "cp2k::k_permute_batch" in r.get(key_col, "") and
+                (key_col != "Name" or int(r["Calls"]) >= 1)) if key_col != "Name" else \
+            sum(int(r["Calls"]) for r in csv.DictReader(open(f)) if "cp2k::k_permute_batch" in r["Name"])
+        if n > best_n:
+            best, best_n = f, n
+    return best
+
+
+stats = main_process_file(os.path.join(O, "kt", "*", "*_kernel_stats.csv"), "Name")
 rows = [r for r in csv.DictReader(open(stats)) if "cp2k::" in r["Name"]]   # templates print as "void cp2k::k<..>(..)"
 with open(os.path.join(P, "%s_bench_kernel_stats.csv" % R), "w") as f:
     w = csv.writer(f)
@@ -16,7 +29,7 @@ with open(os.path.join(P, "%s_bench_kernel_stats.csv" % R), "w") as f:
         name = r["Name"] if "cp2k::" in r["Name"] or len(r["Name"]) < 100 else r["Name"][:96] + "..."   # torch's input generators
         w.writerow([name] + [r[k] for k in ("Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")])
 # per-launch durations of the headline kernel from the trace itself (the --stats average includes the first launch)
-trace = newest(os.path.join(O, "kt", "*", "*_kernel_trace.csv"))
+trace = [stats.replace("_kernel_stats.csv", "_kernel_trace.csv")] if os.path.exists(stats.replace("_kernel_stats.csv", "_kernel_trace.csv")) else []
 launches = []
 if trace:
     for r in csv.DictReader(open(trace[0])):
