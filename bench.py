@@ -757,7 +757,8 @@ def inprocess_child(n_dev):
     cfg = pkg.make_config(maxDepth=32, maxLog2NSlots=15, cellSize=2048, blockSize=65536, nSlots=n_slots, nCells=n_cells, nSamples=100, seed=12345)
     with _stdout_to_stderr():                      # RCCL prints its version banner on stdout when NCCL_DEBUG is set
         t0 = time.perf_counter()
-        m = pkg.Multi(list(range(n_dev)))
+        # rehearsal on a one-GPU box (BENCH_SHARE_GPU, as for the ranks): n_dev contexts on device 0, the host-gather branch
+        m = pkg.Multi([0] * n_dev if os.environ.get("BENCH_SHARE_GPU") else list(range(n_dev)))
         t1 = time.perf_counter()
         ds = m.dataset(cfg)                        # includes context creation, code-object load and (N > 1) communicator creation
         t2 = time.perf_counter()
