@@ -322,6 +322,7 @@ enum { CP2_GATHER_AUTO = 0, CP2_GATHER_RCCL = 1, CP2_GATHER_HOST = 2 };
  * variable CODEX_P2_GPUS ("<count>" = the first <count> visible devices, or a comma-separated index list), else every
  * visible gfx950 device. */
 int cp2_multi_init(const int* devices, int n_dev, cp2_multi** out);
+/* frees the handle, its contexts and communicators: free every cp2_multi_dataset (and proof input) made through it first */
 void cp2_multi_free(cp2_multi* m);
 int cp2_multi_count(const cp2_multi* m);
 int cp2_multi_device(const cp2_multi* m, int i);          /* HIP device index of entry i, -1 out of range */

@@ -75,6 +75,31 @@ def test_multi_dataset_at_config5_scale_vs_oracle_fixture(pkg, golden, name, dev
     m.close()
 
 
+def test_multi_argument_checks(pkg, ctx):
+    """bad knobs and pointers are refused, not dereferenced"""
+    import ctypes
+    m = pkg.Multi([0])
+    for bad in (3, 6, -1):
+        with pytest.raises(pkg.CodexP2Error):
+            m.set_split(bad)                                     # not a power of two / negative
+    with pytest.raises(pkg.CodexP2Error):
+        m.set_policy(7, 0)
+    with pytest.raises(pkg.CodexP2Error):
+        pkg.Multi([5])                                           # no such device on a one-GPU box: loud, no fallback
+    cfg = pkg.make_config(maxDepth=8, maxLog2NSlots=2, cellSize=128, blockSize=512, nSlots=3, nCells=16, nSamples=3, seed=7)
+    ds = ctx.dataset(cfg)
+    assert ctx.L.cp2_dataset_set_roots_dev(ds.h, ctypes.c_void_p(ds.local_roots_dev() + 8)) == -6    # CP2_ERR_ALIGN
+    assert ctx.L.cp2_dataset_set_roots_dev(ds.h, None) == -1
+    first, count = ctypes.c_uint64(), ctypes.c_uint64()
+    assert ctx.L.cp2_dataset_range(ds.h, ctypes.byref(first), ctypes.byref(count)) == 0 and (first.value, count.value) == (0, 3)
+    ds.set_roots_dev(ds.local_roots_dev())                       # all three roots are local: the tree over the device buffer itself
+    want = ds.root().copy()
+    ds.set_roots(ds.local_roots())
+    assert np.array_equal(ds.root(), want)
+    ds.free()
+    m.close()
+
+
 def test_forced_rccl_on_a_repeated_device_is_refused_with_a_reason(pkg, golden):
     c = golden("config5.json")["cheap"]["config"]
     m = pkg.Multi([0, 0])
