@@ -544,8 +544,16 @@ int units_proof_input(cp2_multi_dataset* mds, uint64_t slot, const uint8_t entro
     if (fd < 0) { m->err = "cannot open " + fname; return CP2_ERR_IO; }
     for (size_t i = 0; i < ns; ++i) read_file_cell(fd, cs, idx[i], &cells[i * cs]);
     close(fd);
-  } else {
-    for (size_t i = 0; i < ns; ++i) CP2_TRY(cp2_gen_fake_cells(ctx0, cp2_slot_seed(c.seed, slot), idx[i], 1, cs, &cells[i * cs]));
+  } else if (ns) {   // genFakeCell for the sampled indices in one launch (the list form of the generator), one download
+    DeviceRestore restore;
+    CP2_HIP(ctx0, hipSetDevice(ctx0->device));
+    DevBuf d_idx, d_cells;
+    CP2_TRY(d_idx.scratch(ctx0, ns * 8));
+    CP2_TRY(d_cells.scratch(ctx0, ns * cs));
+    CP2_HIP(ctx0, hipMemcpyAsync(d_idx.p, idx.data(), ns * 8, hipMemcpyHostToDevice, ctx0->stream));
+    CP2_HIP(ctx0, cp2k::launch_gen_fake_cells(cp2_slot_seed(c.seed, slot), 0, 0, static_cast<const uint64_t*>(d_idx.p), ns, cs, d_cells.p, ctx0->stream));
+    CP2_HIP(ctx0, hipMemcpyAsync(cells.data(), d_cells.p, ns * cs, hipMemcpyDeviceToHost, ctx0->stream));
+    CP2_HIP(ctx0, hipStreamSynchronize(ctx0->stream));
   }
   // slotProof = padMerkleProof(merkleProof(dsetTree, slotIdx), maxLog2NSlots), gen_input/bn254.nim:51,72
   std::vector<uint8_t> proof((size_t)c.max_log2_nslots * 32, 0);

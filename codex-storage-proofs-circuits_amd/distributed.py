@@ -72,6 +72,7 @@ def gather_slot_roots_dev(dataset, ctx, n_slots, rank, world, dist, device):
     import torch
     max_rows = (n_slots + world - 1) // world
     gath = torch.zeros((world, max_rows, 32), dtype=torch.uint8, device=device)
+    torch.cuda.current_stream(device).synchronize()       # the zero fill ran on torch's stream; the copy below runs on the context's
     if dataset is not None:
         dataset.copy_local_roots_dev(gath[rank].data_ptr())
         ctx.sync()                                        # the copy ran on the context's stream; the collective runs on torch's
