@@ -223,6 +223,28 @@ def test_cli_twin_spreads_over_contexts_without_a_new_flag(pkg, golden, tmp_path
     assert r.returncode != 0 and "no usable gfx950 HIP device" in r.stderr      # a device that is not there: loud, no fallback
 
 
+def test_cli_twin_reads_slot_files_whole_and_by_units(pkg, oracle, golden, tmp_path):
+    """`--file=<base>` (slot k = <base>k.dat, dataset.nim:34; "untested" in the reference, proof_input/README.md:40): files that
+    hold testMain.hs's fake data must give the committed input.json -- on one context, and with the five slots cut by units over
+    two contexts (every context reads ITS byte range of the files)."""
+    C, _ = oracle
+    c = golden("proof_inputs.json")["inputs"]["testmain_small"]["config"]
+    base = str(tmp_path / "slotdata")
+    for k in range(c["nSlots"]):
+        C.gen_fake_cells(C.slot_seed(c["seed"], k), 0, c["nCells"], c["cellSize"]).tofile("%s%d.dat" % (base, k))
+    args = [pkg.CLI_PATH, "-d:16", "-N=32", "-c128", "-b:4096", "-n=10", "-e:1234567", "-f=" + base, "-s=5", "-K:256", "-i3", "-F:bn254", "-H=poseidon2"]
+    for env_extra, marker in (({}, "slot trees on 1"), ({"CODEX_P2_GPUS": "0,0", "CODEX_P2_MIN_CELLS": "1"}, "unit trees on 2")):
+        out = str(tmp_path / "file.json")
+        r = subprocess.run(args + ["-v", "-o=" + out], capture_output=True, text=True, timeout=300, env=dict(os.environ, CP2_TRACE="1", **env_extra))
+        assert r.returncode == 0, r.stderr
+        assert 'dataSource = (kind: SlotFile, filename: "%s")' % base in r.stdout
+        assert marker in r.stderr, r.stderr
+        assert open(out).read() == golden("input_testmain_small.json")
+    os.remove(base + "4.dat")                                        # a missing slot file: an error that names it, no partial output
+    r = subprocess.run(args + ["-o=" + str(tmp_path / "x.json")], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "slotdata4.dat" in r.stderr and not os.path.exists(tmp_path / "x.json")
+
+
 # ---- by units: several devices sharing ONE slot (SURVEY.md 8e: "within one very large slot the same scheme one level down") ----
 def test_unit_roots_and_paths_are_pieces_of_the_slot_tree(pkg, ctx, oracle, tmp_path):
     """cp2_slot_trees_build_fake_units / _file_units: the root of a unit is the node of its slot's tree above the unit's cells,
