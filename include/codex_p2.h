@@ -309,6 +309,8 @@ int cp2_write_circom_main(const cp2_config* cfg, const char* path);
  *     hashing for it (default: one residency of the hash kernel, 768 x 256 cells -- a device with less finishes no sooner),
  *     so the reference's default run (11 slots x 512 cells, workflow/params.sh) stays on one GPU and pays one context.
  *   - Contexts are created on first use; cp2_multi_ctx(m, i) hands one out for the seam calls and the tuning knobs.
+ *   - One handle per host thread (like a context): calls on one cp2_multi / cp2_multi_dataset are not to be made concurrently;
+ *     the library starts and joins its per-device threads inside each call.
  *   - Datasets of FEW, LARGE slots are cut BY UNITS instead of by whole slots: when whole slots would leave the busiest device
  *     more than 6 % above its share (11 slots on 8 GPUs: 2 against 1.375; ONE 128 GiB slot on 8 GPUs), every slot is cut into
  *     S = 2^s units of nCells / S cells (cp2_slot_trees_build_*_units), the nSlots x S units are dealt out contiguously, the

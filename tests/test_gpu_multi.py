@@ -75,6 +75,41 @@ def test_multi_dataset_at_config5_scale_vs_oracle_fixture(pkg, golden, name, dev
     m.close()
 
 
+def _n_devices():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_n_devices() < 2, reason="needs at least two GPUs: RCCL between REAL devices (a one-GPU box covers the one-rank communicator and the host gather)")
+@pytest.mark.parametrize("name", ["cheap", "odd"])
+def test_multi_over_every_real_device_rccl_vs_oracle_fixture(pkg, golden, name):
+    """On a multi-GPU node: every visible device, RCCL asked for by name (no silent host fallback), 32 768 / 32 767 slots against the
+    oracle-only fixture -- the device-to-device ncclAllGather itself, uneven shards included -- then the same dataset cut by units."""
+    g = golden("config5.json")[name]
+    c, n = g["config"], g["config"]["nSlots"]
+    m = pkg.Multi(None)
+    world = m.count
+    assert world == _n_devices() or os.environ.get("CODEX_P2_GPUS")
+    m.set_policy(pkg.GATHER_RCCL, 1)
+    m.set_split(1)
+    ds = m.dataset(pkg.make_config(**c))
+    assert m.gather_mode().startswith("rccl") and len(ds.shards()) == world
+    assert sha(ds.slot_roots()) == g["slot_roots_sha256"]
+    for i in range(world):
+        assert hexroot(ds.shard_root(i)) == g["dataset_root_hex"], i
+    for slot in (0, n - 1):
+        assert tsha(ds.proof_input(slot, g["entropy"]).json()) == g["inputs"][str(slot)]["json_sha256"]
+    ds.free()
+    # few, large slots over all devices: the reference's default run cut by units, RCCL carrying the unit roots
+    m0 = golden("proof_inputs.json")["inputs"]["params_default"]
+    m.set_split(0)
+    ds = m.dataset(pkg.make_config(**m0["config"]))
+    assert len(ds.shards()) == min(world, 11 * ds.units_per_slot) and m.gather_mode().startswith("rccl")
+    assert ds.proof_input(m0["slotIndex"], m0["entropy"]).json() == golden("input_params_default.json")
+    ds.free()
+    m.close()
+
+
 def test_multi_argument_checks(pkg, ctx):
     """bad knobs and pointers are refused, not dereferenced"""
     import ctypes
