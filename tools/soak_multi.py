@@ -2,7 +2,7 @@
 branch; a one-GPU box has no second device), random dataset shapes and shard splits, plain / streamed / cached builds, fake and
 slot-file sources -- EVERY dataset root and every slot root against the C oracle, proof-input JSON against the oracle on some
 slots and against the single-context object path on others, with resident host memory and free device memory watched.
-Usage: soak_multi.py [seconds] [seed]"""
+Usage: soak_multi.py [seconds] [seed] [units]"""
 import os, resource, shutil, sys, tempfile, time
 from collections import Counter
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,6 +14,7 @@ from oracle_helpers import expected_proof_input_fast
 pkg = g.load_package()
 C, P = g.load_oracle()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
+UNITS = len(sys.argv) > 3 and sys.argv[3] == "units"          # third argument "units": plain builds only, every slot cut into 2 / 4 / 8 units
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20261004)
 single = pkg.Context(0)
 handles = {n: pkg.Multi([0] * n) for n in (2, 3, 4)}          # long-lived handles: contexts and their scratch pools are reused
@@ -27,7 +28,7 @@ while time.time() - t0 < budget:
     big = it % 9 == 0                                          # now and then a shape that keeps several contexts' kernels in flight together
     cs = 2048 if big else int(rng.choice([64, 128, 256, 2048, 100, 31]))
     cpb = 32 if big else int(rng.choice([1, 2, 4, 32]))
-    nblocks = int(rng.choice([32, 128])) if big else int(rng.choice([1, 2, 8, 64]))
+    nblocks = int(rng.choice([32, 128])) if big else int(rng.choice([8, 16, 64, 256] if UNITS else [1, 2, 8, 64]))
     nc = cpb * nblocks
     if nc & (nc - 1) or nc < 2:
         continue
@@ -40,7 +41,7 @@ while time.time() - t0 < budget:
     # min cells per device 1: every context gets a shard (as many as there are slots); a random larger value: fewer shards
     min_cells = int(rng.choice([1, 1, 1, nc * max(1, n_slots // 2), 1 << 30]))
     m.set_policy(int(rng.choice([pkg.GATHER_AUTO, pkg.GATHER_HOST])), min_cells)
-    split = int(rng.choice([0, 0, 1, 2, 4]))                   # choose / whole slots only / every slot cut into 2 or 4 units
+    split = int(rng.choice([2, 4, 8] if UNITS else [0, 0, 1, 2, 4]))   # choose / whole slots only / every slot cut into 2, 4 (8) units
     m.set_split(split)
     use_file = (it % 5 == 0) and (cs & 3) == 0 and not big
     cc = dict(c)
@@ -51,7 +52,7 @@ while time.time() - t0 < budget:
         del cc["seed"]
         cc["file"] = base
     cfg = pkg.make_config(**cc)
-    kind = int(rng.integers(0, 3))
+    kind = 0 if UNITS else int(rng.integers(0, 3))
     threads = int(rng.choice([1, 3, 8]))
     if kind == 0:
         ds = m.dataset(cfg)
