@@ -196,3 +196,34 @@ def test_circom_side_specification_agrees_with_haskell_side(oracle, golden):
     # the cell hash the circuit computes (single_cell.circom:63-65) on the felts the JSON carries
     cell = P.gen_fake_cell(P.slot_seed(12345, 3), 17, 2048)
     assert Cm.Poseidon2_hash_rate2(P.bytes_to_felts(cell)) == P.hash_cell(cell, 2048)
+
+
+def test_reference_vector_printer_outputs_can_pin_the_fixtures(golden):
+    """tools/pin_with_reference_vectors.py: the day `reference/nim/testvectors` (or TestVectors.hs) can be built, its printed
+    output pins every fixture above the permutation.  Here: the parser reads both printers' line formats (rendered from the
+    fixtures themselves), accepts a faithful output and names a wrong line."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pin", os.path.join(root, "tools", "pin_with_reference_vectors.py"))
+    pin = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pin)
+    sp, hb, mr = golden("sponge_felts.json"), golden("hash_bytes.json"), golden("merkle_roots.json")
+    nim = ["", "NIM | test vectors for sponge of field elements with rate=1", "----"]
+    nim += ["hash of [1..%d] : seq[F] =  %s" % (n, v) for n, v in enumerate(sp["rate1"])]
+    nim += ["", "NIM | test vectors for sponge of field elements with rate=2", "----"]
+    nim += ["hash of [1..%d] : seq[F] =  %s" % (n, v) for n, v in enumerate(sp["rate2"])]
+    nim += ["", "NIM | test vectors for hash (padded sponge with rate=2) of bytes", "----"]
+    nim += ["hash of [1..%d] : seq[byte] =  %s" % (n, v) for n, v in enumerate(hb["hash"])]
+    nim += ["", "NIM | test vectors for Merkle roots of field elements", "----"]
+    nim += ["Merkle root of [1..%d] : seq[F] =  %s" % (n + 1, v) for n, v in enumerate(mr["felts"])]
+    nim += ["", "NIM | test vectors for Merkle roots of sequence of bytes", "----"]
+    nim += ["Merkle root of [1..%d] : seq[byte] =  %s" % (n, v) for n, v in enumerate(mr["bytes"])]
+    seen, bad = pin.compare(pin.parse("\n".join(nim)))
+    assert (seen, bad) == (9 + 9 + 81 + 40 + 81, [])
+    hs = "\n".join(nim).replace("NIM | ", "").replace(": seq[F]", ":: [Fr]").replace(": seq[byte] =", ":: [Byte]  =")     # TestVectors.hs:28-75
+    assert pin.compare(pin.parse(hs)) == (220, [])
+    wrong = "\n".join(nim).replace("hash of [1..3] : seq[byte] =  " + hb["hash"][3], "hash of [1..3] : seq[byte] =  12345")
+    seen, bad = pin.compare(pin.parse(wrong))
+    assert seen == 219 and len(bad) == 1 and "hash_bytes.json[hash] n=3" in bad[0]
+
