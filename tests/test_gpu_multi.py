@@ -280,6 +280,42 @@ def test_cli_twin_reads_slot_files_whole_and_by_units(pkg, oracle, golden, tmp_p
     assert r.returncode != 0 and "slotdata4.dat" in r.stderr and not os.path.exists(tmp_path / "x.json")
 
 
+def test_cli_twin_fuzz_against_the_oracle(pkg, oracle, tmp_path):
+    """The drop-in end to end on random flag sets (cli.nim:118-154): geometry, slot count, samples, index, entropy, seed --
+    one context, two or three contexts, whole slots or cut by units -- input.json byte for byte against the Python restatement
+    (gen_input/bn254.nim:35-79 + json/bn254.nim:57-78) and accepted by the circuit-side checker."""
+    C, P = oracle
+    rng = np.random.default_rng(20261004)
+    runs = 0
+    for it in range(24):
+        cs = int(rng.choice([64, 128, 256, 2048]))
+        cpb = int(rng.choice([1, 2, 8, 32]))
+        nblocks = int(rng.choice([1, 2, 4, 16, 64]))
+        nc = cpb * nblocks
+        if nc < 2:
+            continue
+        n_slots = int(rng.integers(1, 14))
+        c = dict(maxDepth=int(rng.integers(12, 33)), maxLog2NSlots=int(rng.integers(4, 9)), cellSize=cs, blockSize=cs * cpb, nSlots=n_slots, nCells=nc,
+                 nSamples=int(rng.integers(1, 25)), seed=int(rng.integers(0, 1 << 31)))
+        index, entropy = int(rng.integers(0, n_slots)), int(rng.integers(0, 1 << 62))
+        args = ["--depth=%d" % c["maxDepth"], "--maxslots=%d" % (1 << c["maxLog2NSlots"]), "--cellsize=%d" % cs, "--blocksize=%d" % (cs * cpb),
+                "--nsamples=%d" % c["nSamples"], "--entropy=%d" % entropy, "--seed=%d" % c["seed"], "--nslots=%d" % n_slots,
+                "-K:%d" % nc if it % 2 else "--log2ncells=%d" % (nc.bit_length() - 1), "--index=%d" % index, "--field=bn254", "--hash=poseidon2"]
+        env = dict(os.environ)
+        mode = it % 3
+        if mode:
+            env.update(CODEX_P2_GPUS=",".join(["0"] * (mode + 1)), CODEX_P2_MIN_CELLS="1", CODEX_P2_SPLIT=str(int(rng.choice([0, 1, 2, 4]))))
+        out = str(tmp_path / ("fuzz%d.json" % it))
+        r = subprocess.run([pkg.CLI_PATH] + args + ["--output=" + out], capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode == 0, (args, r.stderr)
+        prf = expected_proof_input_fast(C, P, c, index, entropy, threads=_threads())
+        assert open(out).read() == P.export_json(prf), (args, mode, env.get("CODEX_P2_SPLIT"))
+        if it % 4 == 0 and cpb > 1:
+            assert P.circuit_check(prf, c)
+        runs += 1
+    assert runs >= 20
+
+
 # ---- by units: several devices sharing ONE slot (SURVEY.md 8e: "within one very large slot the same scheme one level down") ----
 def test_unit_roots_and_paths_are_pieces_of_the_slot_tree(pkg, ctx, oracle, tmp_path):
     """cp2_slot_trees_build_fake_units / _file_units: the root of a unit is the node of its slot's tree above the unit's cells,
