@@ -161,6 +161,10 @@ extern "C" int cp2_multi_init(const int* devices, int n_dev, cp2_multi** out) tr
   m->ctxs.assign(m->devices.size(), nullptr);
   if (const char* e = std::getenv("CODEX_P2_MIN_CELLS")) m->min_cells = std::strtoull(e, nullptr, 10);   // see cp2_multi_set_policy
   if (const char* e = std::getenv("CODEX_P2_SPLIT")) m->split = std::strtoll(e, nullptr, 10);              // see cp2_multi_set_split
+  if (const char* e = std::getenv("CODEX_P2_GATHER")) {                                                      // "rccl" / "host" / anything else: auto
+    if (std::strcmp(e, "rccl") == 0) m->gather = CP2_GATHER_RCCL;
+    else if (std::strcmp(e, "host") == 0) m->gather = CP2_GATHER_HOST;
+  }
   *out = m.release();
   return CP2_OK;
 } catch (const std::bad_alloc&) {

@@ -332,7 +332,7 @@ cp2_ctx* cp2_multi_ctx(cp2_multi* m, int i);              /* NULL when the devic
 const char* cp2_multi_last_error(const cp2_multi* m);
 const char* cp2_multi_gather_mode(const cp2_multi* m);
 /* gather: CP2_GATHER_AUTO (RCCL when possible, else host), CP2_GATHER_RCCL (fail with CP2_ERR_INVALID when impossible),
- * CP2_GATHER_HOST.  min_cells_per_device: 0 = the default above (or the environment variable CODEX_P2_MIN_CELLS, read by
+ * CP2_GATHER_HOST; cp2_multi_init reads the environment variable CODEX_P2_GATHER ("rccl" / "host") as the initial value.  min_cells_per_device: 0 = the default above (or the environment variable CODEX_P2_MIN_CELLS, read by
  * cp2_multi_init); 1 = always spread over every device. */
 int cp2_multi_set_policy(cp2_multi* m, int gather, uint64_t min_cells_per_device);
 /* units per slot for cp2_multi_dataset_build: 0 = choose (above; or the environment variable CODEX_P2_SPLIT), 1 = whole slots

@@ -253,6 +253,11 @@ def test_cli_twin_spreads_over_contexts_without_a_new_flag(pkg, golden, tmp_path
         assert r.returncode == 0, r.stderr
         assert open(out).read() == want
         assert "[cp2 trace] slot roots exchanged: %s" % marker in r.stderr, r.stderr
+    # RCCL in a process that never loaded torch: librccl is found by dlopen and a one-rank communicator carries the exchange
+    out = str(tmp_path / "input_rccl.json")
+    r = subprocess.run([pkg.CLI_PATH] + args + ["--output=" + out], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, CP2_TRACE="1", CODEX_P2_GPUS="0,", CODEX_P2_GATHER="rccl"))
+    assert r.returncode == 0 and open(out).read() == want and "slot roots exchanged: rccl" in r.stderr, r.stderr
     r = subprocess.run([pkg.CLI_PATH] + args + ["--output=" + str(tmp_path / "x.json")], capture_output=True, text=True, timeout=60,
                        env=dict(os.environ, CODEX_P2_GPUS="7,"))
     assert r.returncode != 0 and "no usable gfx950 HIP device" in r.stderr      # a device that is not there: loud, no fallback
