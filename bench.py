@@ -687,11 +687,18 @@ def cpu_baseline(C, np, torch, dev):
     t = time.perf_counter()
     C.permute_batch(xm, threads=cores)
     multi = nm / (time.perf_counter() - t)
+    # config 3 scaled to 2^16 cells (a 128 MiB fake slot -> slot root: generation, sponge, block and slot trees)
+    nc3 = 1 << 16
+    t = time.perf_counter()
+    C.fake_slot_root(C.slot_seed(12345, 0), 2048, 65536, nc3, cores)
+    slot_s = time.perf_counter() - t
     return {"value": multi, "unit": "permutations/s", "cores": cores, "kind": "port",
             "sample": "C oracle (oracle/p2_oracle.c, 4x64-bit Montgomery; NOT the Nim reference binary, which cannot be built here): "
                       "%d states on %d threads; single-thread rate on %d states reported beside it; states from the GPU leg's own generator "
                       "(uniform in [0, r))" % (nm, cores, n1),
-            "single_thread_value": single}
+            "single_thread_value": single,
+            "slot_root_2p16_cells": {"seconds": round(slot_s, 3), "perms_per_s": (35 * nc3 - 1) / slot_s,
+                                     "note": "config 3 scaled to 2^16 cells of 2048 B (fake data generated, hashed and treed on %d threads)" % cores}}
 
 
 def big_slots_leg(torch, dist, ctx, pkg, dev, rank, world):
