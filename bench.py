@@ -446,6 +446,18 @@ def witness_leg(torch, ctx, pkg):
         root_hex = ds.root().tobytes()[::-1].hex()
         ds.free()
         classic.append((t1 - t0, t2 - t1))
+    # witnesses/s WITHOUT the JSON serialisation as well: all trees, then every SlotProofInput as an object
+    # (sampling, paths, cells downloaded into pinned memory; accessors only, no text)
+    torch.cuda.synchronize()
+    o0 = time.perf_counter()
+    ds = ctx.dataset(cfg)
+    ds.set_roots(None)
+    pis = ds.proof_inputs(list(range(n_slots)), 1234567)
+    o1 = time.perf_counter()
+    for p_ in pis:
+        p_.free()
+    del pis
+    ds.free()
     best_classic = min(classic, key=lambda c: c[0] + c[1])     # the components of ONE run: the one with the smallest total
     t0, t1, t2 = 0.0, best_classic[0], best_classic[0] + best_classic[1]
     # ---- streamed, twice: the first pass also pays for the pinned staging (hipHostMalloc), which the context keeps
@@ -476,6 +488,7 @@ def witness_leg(torch, ctx, pkg):
                                     "runs_trees_then_export_s": [[round(a, 4), round(b, 4)] for a, b in classic]},
                         "streamed_runs": runs,
                         "witnesses_per_s_with_json": n_slots / best,
+                        "witnesses_per_s_without_json": n_slots / (o1 - o0), "trees_and_objects_s": round(o1 - o0, 4),
                         "witnesses_per_s_with_json_first_run": n_slots / runs[0]["total_s"],
                         "perms": perms, "perms_per_s_build": (perms - 200 * n_slots) / (t1 - t0),
                         "dataset_root_hex": root_hex, "equals_oracle_fixture": (root_hex == gold) if gold else None}
