@@ -88,6 +88,8 @@ def load_library():
         "cp2_set_ingest_direct": (i32, [vp, i32]),
         "cp2_trim": (i32, [vp]),
         "cp2_set_body_budget": (i32, [vp, sz, cp]),
+        "cp2_set_keep_trees": (i32, [vp, i32]),
+        "cp2_dataset_keeps_trees": (i32, [vp]),
         "cp2_permute_batch": (i32, [vp, vp, vp, sz]),
         "cp2_permute_batch_dev": (i32, [vp, vp, vp, sz]),
         "cp2_compress_batch": (i32, [vp, vp, u32, vp, sz]),
@@ -266,6 +268,10 @@ class Context:
     def trim(self):
         """Give the context's cached device / pinned scratch back to the system (cp2_trim)."""
         self._ck(self.L.cp2_trim(self.h), "cp2_trim")
+
+    def set_keep_trees(self, mode=-1):
+        """cp2_dataset_build keeps every slot tree resident (1), only the roots (0), or decides by what fits (-1)"""
+        self._ck(self.L.cp2_set_keep_trees(self.h, mode), "cp2_set_keep_trees")
 
     def set_body_budget(self, max_resident_bytes=0, spill_dir=None):
         self._ck(self.L.cp2_set_body_budget(self.h, max_resident_bytes, spill_dir.encode() if spill_dir else None), "cp2_set_body_budget")
@@ -517,6 +523,10 @@ class Dataset:
             r = _u8(all_roots).reshape(-1, 32)
             assert r.shape[0] == self.cfg.n_slots
             self.ctx._ck(self.ctx.L.cp2_dataset_set_roots(self.h, _p(r)), "cp2_dataset_set_roots")
+
+    @property
+    def keeps_trees(self):
+        return bool(self.ctx.L.cp2_dataset_keeps_trees(self.h))
 
     def local_roots_dev(self):
         """device pointer to the n_local x 32 bytes of local slot roots"""

@@ -114,6 +114,14 @@ extern "C" int cp2_trim(cp2_ctx* ctx) try {
   return CP2_ERR_INVALID;
 }
 
+extern "C" int cp2_set_keep_trees(cp2_ctx* ctx, int mode) try {
+  if (!ctx || mode < -1 || mode > 1) return CP2_ERR_INVALID;
+  ctx->keep_trees = mode;
+  return CP2_OK;
+} catch (...) {
+  return CP2_ERR_INVALID;
+}
+
 extern "C" int cp2_set_body_budget(cp2_ctx* ctx, size_t max_resident_bytes, const char* spill_dir) try {
   if (!ctx) return CP2_ERR_INVALID;
   if (max_resident_bytes) ctx->body_budget = max_resident_bytes;

@@ -166,7 +166,12 @@ struct cp2_dataset {
   std::string file_base;
   bool from_file = false;
   uint64_t first_slot = 0, n_local = 0;
-  cp2_slot_trees* trees = nullptr;
+  cp2_slot_trees* trees = nullptr;            // every local slot tree (null for a roots-only dataset)
+  // Roots-only dataset: the slot trees of a dataset whose nodes do not fit the device (3.1 % of the data: 256 MiB per 8 GiB
+  // slot, 8 TiB for config 5's nominal 32 768 slots) are built batch by batch in pooled scratch and dropped again, only the
+  // 32-byte roots stay; the tree of a slot that is proved is rebuilt on demand (0.2 s per 8 GiB), which is what the reference
+  // does on EVERY run and once more per sample (gen_input/bn254.nim:42,57).
+  DevBuf local_roots;                         // roots-only: n_local x 32 bytes
   bool have_roots = false;
   std::vector<size_t> dsizes;                 // dataset-tree layer sizes
   std::vector<uint8_t> dlayers;               // all dataset-tree layers, bottom first (host copy)
@@ -225,16 +230,75 @@ static int dataset_build_trees(cp2_dataset* ds, size_t group, const SlotsDone& d
   return trees_build_fake(ds->ctx, c.seed, ds->first_slot, ds->n_local, c.cell_size, c.block_size, c.n_cells, group, done, &ds->trees);
 }
 
-extern "C" int cp2_dataset_build(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local,
-                                 cp2_dataset** out) try {
+// the device buffer holding the roots of the local slots (n_local x 32 bytes)
+static const void* dataset_roots_dev(const cp2_dataset* ds) {
+  return ds->trees ? cp2_slot_trees_roots_dev(ds->trees) : ds->local_roots.p;
+}
+
+// the trees of `n` local slots starting at local index `s0`, in pooled scratch (roots-only datasets: batches of the build, and
+// the one slot a proof input is made for)
+static int dataset_transient_trees(const cp2_dataset* ds, size_t s0, size_t n, cp2_slot_trees** out) {
+  const cp2_config& c = ds->cfg;
+  if (ds->from_file)
+    return trees_build_files(ds->ctx, ds->file_base, ds->first_slot + s0, n, c.cell_size, c.block_size, c.n_cells, 0, nullptr, out, 1, true);
+  return trees_build_fake(ds->ctx, c.seed, ds->first_slot + s0, n, c.cell_size, c.block_size, c.n_cells, 0, nullptr, out, 1, true);
+}
+
+// Does this dataset keep its trees?  The caller's word (cp2_set_keep_trees / CODEX_P2_KEEP_TREES), else whether the node buffer
+// fits: it must leave room for the builders' staging (two 2 GiB chunks) and some slack in what the device has free right now.
+static bool dataset_keeps_trees(cp2_ctx* ctx, const cp2_config& c, uint64_t n_local) {
+  int mode = ctx->keep_trees;
+  if (mode < 0) {
+    const char* e = std::getenv("CODEX_P2_KEEP_TREES");
+    if (e && (*e == '0' || *e == '1')) mode = *e - '0';
+  }
+  if (mode >= 0) return mode == 1;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return true; }
+  const unsigned __int128 need = (unsigned __int128)trees_node_bytes(1, c.cell_size, c.block_size, c.n_cells) * n_local;
+  return need + ((unsigned __int128)6 << 30) <= (unsigned __int128)free_b * 9 / 10;
+}
+
+// roots-only build: batches of at most ~2 GiB of nodes (8 slots of 8 GiB; at least one slot), every batch a normal builder call
+static int dataset_build_roots_only(cp2_dataset* ds) {
+  cp2_ctx* ctx = ds->ctx;
+  const cp2_config& c = ds->cfg;
+  const size_t per_slot = trees_node_bytes(1, c.cell_size, c.block_size, c.n_cells);
+  const size_t batch = std::max<size_t>(1, std::min<size_t>(ds->n_local, ((size_t)2 << 30) / std::max<size_t>(per_slot, 1)));
+  CP2_TRY(ds->local_roots.alloc(ctx, ds->n_local * 32));
+  StageTimer trace;
+  for (size_t s0 = 0; s0 < ds->n_local; s0 += batch) {
+    const size_t n = std::min(batch, (size_t)ds->n_local - s0);
+    cp2_slot_trees* t = nullptr;
+    CP2_TRY(dataset_transient_trees(ds, s0, n, &t));
+    hipError_t e = hipMemcpyAsync(ds->local_roots.u8() + s0 * 32, cp2_slot_trees_roots_dev(t), n * 32, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    cp2_slot_trees_free(t);
+    if (e != hipSuccess) { ctx->err = std::string("roots-only build: ") + hipGetErrorString(e); return CP2_ERR_HIP; }
+    if (trace.on && ((s0 / batch) % 32 == 31 || s0 + n == ds->n_local))   // a long build says where it is (CP2_TRACE)
+      std::fprintf(stderr, "[cp2 trace] roots-only build: %zu of %llu slots\n", s0 + n, (unsigned long long)ds->n_local);
+  }
+  trace.lap("roots-only build (trees dropped)");
+  return CP2_OK;
+}
+
+static int dataset_build(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local, bool always_keep_trees, cp2_dataset** out) {
   if (!ctx || !cfg || !out) return CP2_ERR_INVALID;
   *out = nullptr;
   CP2_TRY(dataset_check(cfg, first_slot, n_local));
   std::unique_ptr<cp2_dataset> ds(dataset_new(ctx, cfg, first_slot, n_local));
   if (!ds) return CP2_ERR_ALLOC;
-  CP2_TRY(dataset_build_trees(ds.get(), 0, nullptr));
+  CP2_TRY(trees_check_geometry(cfg->cell_size, cfg->block_size, cfg->n_cells, n_local));
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  if (always_keep_trees || dataset_keeps_trees(ctx, ds->cfg, n_local)) CP2_TRY(dataset_build_trees(ds.get(), 0, nullptr));
+  else CP2_TRY(dataset_build_roots_only(ds.get()));
   *out = ds.release();
   return CP2_OK;
+}
+
+extern "C" int cp2_dataset_build(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local,
+                                 cp2_dataset** out) try {
+  return dataset_build(ctx, cfg, first_slot, n_local, false, out);
 } catch (const std::bad_alloc&) {
   return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
 } catch (...) {
@@ -264,7 +328,7 @@ extern "C" int cp2_dataset_build_cached(cp2_ctx* ctx, const cp2_config* cfg, uin
     }
     cp2_slot_trees_free(t);
   }
-  CP2_TRY(cp2_dataset_build(ctx, cfg, first_slot, n_local, out));
+  CP2_TRY(dataset_build(ctx, cfg, first_slot, n_local, true, out));   // what is cached IS the trees
   int st = cp2_slot_trees_save((*out)->trees, cache_path);
   if (st != CP2_OK) { cp2_dataset_free(*out); *out = nullptr; }
   return st;
@@ -278,7 +342,12 @@ extern "C" void cp2_dataset_free(cp2_dataset* ds) { delete ds; }
 
 extern "C" int cp2_dataset_local_roots(cp2_dataset* ds, uint8_t* out) try {
   if (!ds || !out) return CP2_ERR_INVALID;
-  return cp2_slot_trees_roots(ds->trees, out);
+  if (ds->trees) return cp2_slot_trees_roots(ds->trees, out);
+  cp2_ctx* ctx = ds->ctx;
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  CP2_HIP(ctx, hipMemcpyAsync(out, ds->local_roots.p, ds->n_local * 32, hipMemcpyDeviceToHost, ctx->stream));
+  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return CP2_OK;
 } catch (const std::bad_alloc&) {
   return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
 } catch (...) {
@@ -312,7 +381,7 @@ extern "C" int cp2_dataset_set_roots(cp2_dataset* ds, const uint8_t* all_roots) 
   const size_t n = ds->cfg.n_slots;
   if (!all_roots) {   // single GPU: the local roots are all of them and are already on the device
     if (ds->first_slot != 0 || ds->n_local != n) return CP2_ERR_INVALID;   // roots of other ranks' slots are missing
-    return dataset_tree_from_dev(ds, cp2_slot_trees_roots_dev(ds->trees));
+    return dataset_tree_from_dev(ds, dataset_roots_dev(ds));
   }
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   DevBuf d;
@@ -337,13 +406,14 @@ extern "C" int cp2_dataset_set_roots_dev(cp2_dataset* ds, const void* d_all_root
   return CP2_ERR_INVALID;
 }
 
-extern "C" const void* cp2_dataset_local_roots_dev(const cp2_dataset* ds) { return ds ? cp2_slot_trees_roots_dev(ds->trees) : nullptr; }
+extern "C" const void* cp2_dataset_local_roots_dev(const cp2_dataset* ds) { return ds ? dataset_roots_dev(ds) : nullptr; }
+extern "C" int cp2_dataset_keeps_trees(const cp2_dataset* ds) { return ds && ds->trees ? 1 : 0; }
 
 extern "C" int cp2_dataset_copy_local_roots_dev(cp2_dataset* ds, void* d_out) try {
   if (!ds || !d_out) return CP2_ERR_INVALID;
   cp2_ctx* ctx = ds->ctx;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
-  CP2_HIP(ctx, hipMemcpyAsync(d_out, cp2_slot_trees_roots_dev(ds->trees), ds->n_local * 32, hipMemcpyDeviceToDevice, ctx->stream));
+  CP2_HIP(ctx, hipMemcpyAsync(d_out, dataset_roots_dev(ds), ds->n_local * 32, hipMemcpyDeviceToDevice, ctx->stream));
   return CP2_OK;
 } catch (...) {
   return CP2_ERR_INVALID;
@@ -546,11 +616,29 @@ extern "C" int cp2_proof_inputs_generate_batch(cp2_dataset* ds, const uint64_t* 
   if (n == 0) return CP2_OK;
   const cp2_config& cfg = ds->cfg;
   cp2_ctx* ctx = ds->ctx;
-  cp2_slot_trees* t = ds->trees;
   for (size_t i = 0; i < n; ++i)
     if (slot_idx[i] < ds->first_slot || slot_idx[i] >= ds->first_slot + ds->n_local) return CP2_ERR_INVALID;
   if (!is_pow2(cfg.n_cells)) return CP2_ERR_INVALID;                    // sample/bn254.nim:19-20
   if (cfg.n_samples && cfg.n_cells < 2) return CP2_ERR_INVALID;         // extractLowBits asserts k > 0, types/bn254.nim:48
+  if (!ds->trees && n > 1) {                                            // roots-only dataset: one slot, one rebuilt tree, at a time
+    for (size_t i = 0; i < n; ++i) {
+      int st = cp2_proof_inputs_generate_batch(ds, slot_idx + i, 1, entropy_in, out + i);
+      if (st != CP2_OK) {
+        for (size_t j = 0; j < i; ++j) { delete out[j]; out[j] = nullptr; }
+        return st;
+      }
+    }
+    return CP2_OK;
+  }
+  // the trees the paths come from: the dataset's own, or (roots-only) the tree of this one slot, rebuilt in pooled scratch
+  cp2_slot_trees* t = ds->trees;
+  struct Transient { cp2_slot_trees* t = nullptr; ~Transient() { cp2_slot_trees_free(t); } } transient;
+  if (!t) {
+    CP2_HIP(ctx, hipSetDevice(ctx->device));
+    CP2_TRY(dataset_transient_trees(ds, (size_t)(slot_idx[0] - ds->first_slot), 1, &transient.t));
+    t = transient.t;
+  }
+  const uint64_t local_base = ds->trees ? ds->first_slot : slot_idx[0];  // index inside `t` = slot index - local_base
   if (!ds->have_roots) CP2_TRY(cp2_dataset_set_roots(ds, nullptr));
   if (ds->dsizes.size() - 1 > (size_t)cfg.max_log2_nslots) return CP2_ERR_INVALID;   // padMerkleProof assert
   if (cp2_slot_trees_depth(t) > (size_t)cfg.max_depth) return CP2_ERR_INVALID;        // padMerkleProof assert
@@ -565,7 +653,7 @@ extern "C" int cp2_proof_inputs_generate_batch(cp2_dataset* ds, const uint64_t* 
     cp2k::TreeGeom g;
     trees_geom(t, &g);
     std::vector<uint64_t> local(n);
-    for (size_t i = 0; i < n; ++i) local[i] = slot_idx[i] - ds->first_slot;
+    for (size_t i = 0; i < n; ++i) local[i] = slot_idx[i] - local_base;
     SampleDev dev;
     SampleHost host;
     CP2_TRY(dev.init(ctx, n, ns, md, cs, dev_cells));

@@ -90,7 +90,16 @@ static int trees_layout(cp2_slot_trees* t) {
     t->toff.push_back(off);
     off += t->n_slots * t->tsizes[k];
   }
-  return t->nodes.alloc(t->ctx, off * 32);
+  return t->pooled_nodes ? t->nodes.scratch(t->ctx, off * 32) : t->nodes.alloc(t->ctx, off * 32);
+}
+
+size_t cp2i::trees_node_bytes(size_t n_slots, size_t cell_size, size_t block_size, size_t n_cells) {
+  const size_t cpb = block_size / cell_size, nblocks = n_cells / cpb;
+  size_t per_block = 0, per_slot = 0;
+  const std::vector<size_t> b = layer_sizes_of(cpb), t = layer_sizes_of(nblocks);
+  for (size_t k = 0; k + 1 < b.size(); ++k) per_block += b[k];     // the block roots are layer 0 of the slot tree
+  for (size_t m : t) per_slot += m;
+  return n_slots * (nblocks * per_block + per_slot) * 32;
 }
 
 void cp2i::trees_geom(const cp2_slot_trees* t, cp2k::TreeGeom* g) {
@@ -200,7 +209,7 @@ struct LayerScheduler {
 
 int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_slot, size_t n_slots, size_t cell_size,
                            size_t block_size, size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out,
-                           uint64_t units_per_slot) {
+                           uint64_t units_per_slot, bool pooled_nodes) {
   *out = nullptr;
   if (units_per_slot == 0) return CP2_ERR_INVALID;
   CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
@@ -211,6 +220,7 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
   t->dataset_seed = dataset_seed;
   t->first_slot = first_slot;
   t->units_per_slot = units_per_slot;
+  t->pooled_nodes = pooled_nodes;
   StageTimer trace;
   CP2_TRY(trees_layout(t.get()));
   const size_t total_cells = n_slots * n_cells;
@@ -487,7 +497,7 @@ extern "C" int cp2_slot_trees_build_host(cp2_ctx* ctx, const uint8_t* cells, siz
 // slot files "<base><k>.dat" (dataset.nim:34) streamed through the ingestion pipe; short files read as zeros
 int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t first_slot, size_t n_slots, size_t cell_size,
                             size_t block_size, size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out,
-                            uint64_t units_per_slot) {
+                            uint64_t units_per_slot, bool pooled_nodes) {
   *out = nullptr;
   if (units_per_slot == 0) return CP2_ERR_INVALID;
   CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
@@ -498,6 +508,7 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
   t->file_base = base;
   t->first_slot = first_slot;
   t->units_per_slot = units_per_slot;
+  t->pooled_nodes = pooled_nodes;
   CP2_TRY(trees_layout(t.get()));
   int st = CP2_OK;
   {

@@ -22,6 +22,7 @@ struct cp2_slot_trees {
   // cells each, unit i being unit first_slot + i of the dataset, unit u = cells [(u % units_per_slot) * n_cells, +n_cells) of
   // slot u / units_per_slot.  1: a unit is a whole slot (everything outside multi_gpu.cpp).
   uint64_t units_per_slot = 1;
+  bool pooled_nodes = false;            // node buffer from the context's scratch pool (transient batches: roots-only datasets)
   const uint8_t* d_cells = nullptr;     // not owned
   const uint8_t* h_cells = nullptr;     // not owned
   std::string file_base;
@@ -39,11 +40,15 @@ using SlotsDone = std::function<int(cp2_slot_trees* t, size_t s0, size_t s1, hip
 int trees_check_geometry(size_t cell_size, size_t block_size, size_t n_cells, size_t n_slots);
 // fake-data or slot-file trees; `group` = how many finished slots to batch per layer pass / callback (0: all at the end)
 // units_per_slot > 1: first_slot / n_slots / n_cells count UNITS and the cells of one unit (cp2_slot_trees above)
+// pooled_nodes: the node buffer comes from (and goes back to) the context's scratch pool instead of hipMalloc / hipFree
 int trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_slot, size_t n_slots, size_t cell_size, size_t block_size,
-                     size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out, uint64_t units_per_slot = 1);
+                     size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out, uint64_t units_per_slot = 1,
+                     bool pooled_nodes = false);
 int trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t first_slot, size_t n_slots, size_t cell_size,
                       size_t block_size, size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out,
-                      uint64_t units_per_slot = 1);
+                      uint64_t units_per_slot = 1, bool pooled_nodes = false);
+// bytes of the node buffer of a batch of n_slots slots of this geometry (all layers, 32 bytes per node)
+size_t trees_node_bytes(size_t n_slots, size_t cell_size, size_t block_size, size_t n_cells);
 void trees_geom(const cp2_slot_trees* t, cp2k::TreeGeom* g);
 // node-row indices of the merged path of `cell` in slot `slot` (host twin of k_sample_paths' row arithmetic)
 void path_rows(const cp2_slot_trees* t, size_t slot, uint64_t cell, size_t max_depth, uint64_t* rows);

@@ -79,6 +79,15 @@ int cp2_trim(cp2_ctx* ctx);
  * CP2_BODY_BUDGET_MB), spill_dir NULL = $TMPDIR or /tmp.  max_resident_bytes = 0 keeps the current budget; (size_t)-1 = never
  * spill.  A spill that fails is CP2_ERR_IO with the path in cp2_last_error. */
 int cp2_set_body_budget(cp2_ctx* ctx, size_t max_resident_bytes, const char* spill_dir);
+/* Device memory of cp2_dataset_build: the nodes of every local slot tree stay resident (3.1 % of the data: 256 MiB per 8 GiB
+ * slot) so that proof inputs for any entropy cost two permutations per sample plus gathers.  A dataset whose nodes do not fit
+ * (config 5's nominal 4096 x 8 GiB slots per GPU would need 1 TiB) is built ROOTS ONLY instead: the trees are built batch by
+ * batch in the context's scratch and dropped, the 32-byte slot roots stay, and cp2_proof_input_generate rebuilds the tree of
+ * the slot it proves (0.2 s per 8 GiB slot; the reference rebuilds it once per sample, gen_input/bn254.nim:57).  Same results.
+ * mode: 1 keep the trees, 0 roots only, -1 (default) the environment variable CODEX_P2_KEEP_TREES ("0" / "1"), else keep
+ * them when they fit what the device has free.  cp2_dataset_keeps_trees tells what a built dataset did.  Streamed and cached
+ * builds always keep their trees. */
+int cp2_set_keep_trees(cp2_ctx* ctx, int mode);
 
 /* ---- a1: Poseidon2 t=3 permutation --------------------------------------------------------- */
 /* replaces nim-poseidon2 `perm` as specified by reference/haskell/src/Poseidon2/Permutation.hs:40-45.
@@ -229,6 +238,7 @@ const void* cp2_dataset_local_roots_dev(const cp2_dataset* ds);
 int cp2_dataset_copy_local_roots_dev(cp2_dataset* ds, void* d_out);
 int cp2_dataset_set_roots_dev(cp2_dataset* ds, const void* d_all_roots);
 int cp2_dataset_root(cp2_dataset* ds, uint8_t out[32]);
+int cp2_dataset_keeps_trees(const cp2_dataset* ds);
 /* the slot range and the context a dataset was built with */
 int cp2_dataset_range(const cp2_dataset* ds, uint64_t* first_slot, uint64_t* n_local);
 cp2_ctx* cp2_dataset_ctx(const cp2_dataset* ds);

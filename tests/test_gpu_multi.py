@@ -321,6 +321,75 @@ def test_cli_twin_fuzz_against_the_oracle(pkg, oracle, tmp_path):
     assert runs >= 20
 
 
+# ---- roots-only datasets: the trees do not have to fit the device ------------------------------------------------------
+@pytest.mark.parametrize("name", ["params_default", "testmain_small", "odd_slots_one_block"])
+def test_roots_only_dataset_gives_the_same_proof_inputs(pkg, golden, oracle, tmp_path, name):
+    """cp2_set_keep_trees(0): the slot trees are built batch by batch and dropped, the roots stay, the tree of the proved slot is
+    rebuilt on demand -- same roots, same dataset tree, same input.json (the committed oracle text), fake and file sources,
+    single and batched generation, also through cp2_multi and the cli twin (CODEX_P2_KEEP_TREES=0)."""
+    C, _ = oracle
+    m0 = golden("proof_inputs.json")["inputs"][name]
+    c = m0["config"]
+    want = golden("input_%s.json" % name)
+    single = pkg.Context(0)
+    keep = single.dataset(pkg.make_config(**c))
+    assert keep.keeps_trees                                       # small: left to itself the library keeps the trees
+    single.set_keep_trees(0)
+    base = str(tmp_path / "slot")
+    for k in range(c["nSlots"]):
+        C.gen_fake_cells(C.slot_seed(c["seed"], k), 0, c["nCells"], c["cellSize"]).tofile("%s%d.dat" % (base, k))
+    for src in (dict(seed=c["seed"]), dict(file=base)):
+        cfg = pkg.make_config(**dict({k: v for k, v in c.items() if k != "seed"}, **src))
+        ds = single.dataset(cfg)
+        assert not ds.keeps_trees
+        assert np.array_equal(ds.local_roots(), keep.local_roots()) and np.array_equal(ds.root(), keep.root())
+        assert ds.proof_input(m0["slotIndex"], m0["entropy"]).json() == want
+        every = ds.proof_inputs(list(range(c["nSlots"])), m0["entropy"])          # a batch: one rebuilt tree after the other
+        assert every[m0["slotIndex"]].json() == want
+        assert every[0].json() == keep.proof_input(0, m0["entropy"]).json()
+        ds.free()
+    single.set_keep_trees(-1)
+    # two contexts, whole slots, both roots-only
+    m = pkg.Multi([0, 0])
+    m.set_policy(pkg.GATHER_AUTO, 1)
+    m.set_split(1)
+    for i in range(m.count):
+        m.ctx(i).set_keep_trees(0)
+    md = m.dataset(pkg.make_config(**c))
+    assert md.proof_input(m0["slotIndex"], m0["entropy"]).json() == want and hexroot(md.root()) == hexroot(keep.root())
+    md.free()
+    m.close()
+    keep.free()
+    single.close()
+
+
+def test_cli_twin_roots_only(pkg, golden, tmp_path):
+    args = ["--depth=32", "--maxslots=256", "--cellsize=2048", "--blocksize=65536", "--nsamples=5", "--entropy=1234567",
+            "--seed=12345", "--nslots=11", "--ncells=512", "--index=3", "--field=bn254", "--hash=poseidon2"]
+    out = str(tmp_path / "input.json")
+    r = subprocess.run([pkg.CLI_PATH] + args + ["--output=" + out], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, CP2_TRACE="1", CODEX_P2_KEEP_TREES="0"))
+    assert r.returncode == 0 and "roots-only build" in r.stderr, r.stderr
+    assert open(out).read() == golden("input_params_default.json")
+
+
+def test_bigslots_roots_only_vs_oracle_fixture(pkg, golden):
+    """8 slots of 8 GiB with only the roots kept (2 GiB of nodes in flight instead of 2 GiB per 8 slots resident ... at 4096 slots
+    per GPU, config 5's nominal share, the resident trees would need 1 TiB): roots, dataset root and input.json of slots 0 and 7
+    -- each from its tree rebuilt on demand -- against the oracle-only fixture."""
+    g = _big(golden)
+    ctx = pkg.Context(0)
+    ctx.set_keep_trees(0)
+    ds = ctx.dataset(pkg.make_config(**g["config"]))
+    assert not ds.keeps_trees
+    assert [hexroot(r) for r in ds.local_roots()] == g["slot_roots_hex"] and hexroot(ds.root()) == g["dataset_root_hex"]
+    for slot in (0, 7):
+        text = ds.proof_input(slot, g["entropy"]).json()
+        assert tsha(text) == g["inputs"][str(slot)]["json_sha256"], slot
+    ds.free()
+    ctx.close()
+
+
 # ---- by units: several devices sharing ONE slot (SURVEY.md 8e: "within one very large slot the same scheme one level down") ----
 def test_unit_roots_and_paths_are_pieces_of_the_slot_tree(pkg, ctx, oracle, tmp_path):
     """cp2_slot_trees_build_fake_units / _file_units: the root of a unit is the node of its slot's tree above the unit's cells,
