@@ -34,6 +34,7 @@ proc cp2_last_error(ctx: Cp2Ctx): cstring {.importc.}
 proc cp2_trim(ctx: Cp2Ctx): cint {.importc.}
 proc cp2_set_ingest_direct(ctx: Cp2Ctx, on: cint): cint {.importc.}
 proc cp2_set_body_budget(ctx: Cp2Ctx, maxResidentBytes: csize_t, spillDir: cstring): cint {.importc.}
+proc cp2_set_keep_trees(ctx: Cp2Ctx, mode: cint): cint {.importc.}
 proc cp2_permute_batch(ctx: Cp2Ctx, inp, outp: ptr byte, n: csize_t): cint {.importc.}
 proc cp2_compress_batch(ctx: Cp2Ctx, xy: ptr byte, key: uint32, outp: ptr byte, n: csize_t): cint {.importc.}
 proc cp2_sponge2_felts(ctx: Cp2Ctx, felts: ptr byte, n: csize_t, outp: ptr byte): cint {.importc.}
@@ -303,6 +304,11 @@ proc engineTrim*() =
 proc engineSetIngestDirect*(on: bool) =
   ## SlotFile source: O_DIRECT reads of slot files that are not in the page cache
   check(cp2_set_ingest_direct(ctx(), cint(ord(on))), "cp2_set_ingest_direct")
+
+proc engineSetKeepTrees*(mode: int) =
+  ## 1: every slot tree stays in device memory; 0: roots only (the proved slot's tree is rebuilt on demand); -1: by what fits
+  for i in 0 ..< int(cp2_multi_count(multi())):
+    check(cp2_set_keep_trees(cp2_multi_ctx(multi(), cint(i)), cint(mode)), "cp2_set_keep_trees")
 
 proc engineSetBodyBudget*(maxResidentBytes: int, spillDir: string = "") =
   check(cp2_set_body_budget(ctx(), csize_t(maxResidentBytes), (if spillDir.len > 0: cstring(spillDir) else: nil)), "cp2_set_body_budget")

@@ -44,6 +44,8 @@ int main(void) {
       cp2_multi_dataset_export_streamed(NULL, NULL, 1, NULL) != CP2_ERR_INVALID) return 16;
   if (cp2_dataset_set_roots_dev(NULL, NULL) != CP2_ERR_INVALID || cp2_dataset_copy_local_roots_dev(NULL, NULL) != CP2_ERR_INVALID ||
       cp2_dataset_local_roots_dev(NULL) != NULL || cp2_dataset_ctx(NULL) != NULL || cp2_dataset_range(NULL, NULL, NULL) != CP2_ERR_INVALID) return 17;
+  if (cp2_set_keep_trees(NULL, 0) != CP2_ERR_INVALID || cp2_dataset_keeps_trees(NULL) != 0 || cp2_multi_set_split(NULL, 2) != CP2_ERR_INVALID ||
+      cp2_multi_dataset_units_per_slot(NULL) != 0 || cp2_slot_trees_build_fake_units(NULL, 1, 2, 0, 1, 64, 128, 4, NULL) != CP2_ERR_INVALID) return 18;
   printf("c abi ok\n");
   return 0;
 }
