@@ -337,6 +337,15 @@ def main():
                 extra.update(cli_default_leg(pkg, g))
             except Exception as e:
                 extra["cli_default_error"] = repr(e)
+    # config 5 at its nominal slot size (one GPU's share, 32 TiB: 13 minutes, so not run here): the committed record, named as such
+    rec = newest_profile("r*_config5_nominal_share.txt")
+    if rec and rank == 0:
+        try:
+            last = [l for l in open(rec).read().splitlines() if l.startswith("{")][-1]
+            extra["config5_nominal_share_record"] = dict(json.loads(last), source="%s (tools/config5_share.py; NOT measured in this run)" % os.path.relpath(rec, ROOT),
+                                                         workload="configs[4] at its nominal slot size, one GPU's share: 4096 slots x 2^22 cells x 2048 B = 32 TiB, roots-only build")
+        except Exception:
+            pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(C, np, torch, dev)
     if extra:
