@@ -1174,6 +1174,7 @@ extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, u
   size_t consumed = 0;          // passes whose body tasks have been handed to the workers
   cp2k::TreeGeom geom;
   bool have_geom = false;
+  size_t slot_base = 0;         // roots-only build: dataset-local index of the first slot of the batch being built
   StageTimer trace;
   {
     Workers pool(threads);      // declared last: joins before anything above is destroyed
@@ -1234,8 +1235,8 @@ extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, u
         CP2_HIP(ctx, hipStreamWaitEvent(aux, trees_ready, 0));
         CP2_TRY(enqueue_sampling(t, geom, dev, ring.host[r], nullptr, g0, g1 - g0, ns, md, !from_file, aux));
         CP2_HIP(ctx, hipEventRecord(ring.landed[r], aux));
-        ring.s0[r] = g0;
-        ring.s1[r] = g1;
+        ring.s0[r] = slot_base + g0;                           // dataset-local slot indices (bodies, file names); g0 counts inside `t`
+        ring.s1[r] = slot_base + g1;
         ++n_groups;
         // the pass before this one has had a whole group's hashing time to land: hand it out now
         while (consumed + 1 < n_groups) { CP2_TRY(consume(consumed)); ++consumed; }
@@ -1243,12 +1244,44 @@ extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, u
       return CP2_OK;
     };
 
-    int st = dataset_build_trees(dsp, group_slots, on_done);
-    trace.lap("trees (sampling overlapped)");
-    while (st == CP2_OK && consumed < n_groups) { st = consume(consumed); ++consumed; }
-    pool.wait_idle();
-    (void)hipStreamSynchronize(aux);
-    trace.lap("last bodies");
+    int st = CP2_OK;
+    if (dataset_keeps_trees(ctx, cfgv, n_local)) {
+      st = dataset_build_trees(dsp, group_slots, on_done);
+      trace.lap("trees (sampling overlapped)");
+      while (st == CP2_OK && consumed < n_groups) { st = consume(consumed); ++consumed; }
+      pool.wait_idle();
+      (void)hipStreamSynchronize(aux);
+      trace.lap("last bodies");
+    } else {
+      // Roots only (the nodes of all local slots do not fit the device, or the caller said so): the same pipeline over batches of
+      // slots whose nodes live in pooled scratch -- about 2 GiB of them: 8 slots of 8 GiB, a whole number of groups -- and go
+      // back to the pool once the batch's bodies are made; roots and bodies stay.  The tail of a batch (its last group's
+      // sampling and formatting) is not overlapped with the next batch's hashing: a few tens of ms per batch.
+      const size_t per_slot = trees_node_bytes(1, cfgv.cell_size, cfgv.block_size, cfgv.n_cells);
+      size_t batch = std::max<size_t>(1, ((size_t)2 << 30) / std::max<size_t>(per_slot, 1));
+      batch = std::max(group_slots, batch / group_slots * group_slots);
+      st = dsp->local_roots.alloc(ctx, n_local * 32);
+      for (size_t base = 0; st == CP2_OK && base < n_local; base += batch) {
+        const size_t nb = std::min(batch, (size_t)n_local - base);
+        slot_base = base;
+        have_geom = false;                                     // node offsets are those of THIS batch's layout
+        cp2_slot_trees* t = nullptr;
+        st = from_file ? trees_build_files(ctx, file_base, first_slot + base, nb, cfgv.cell_size, cfgv.block_size, cfgv.n_cells, group_slots, on_done, &t, 1, true)
+                       : trees_build_fake(ctx, cfgv.seed, first_slot + base, nb, cfgv.cell_size, cfgv.block_size, cfgv.n_cells, group_slots, on_done, &t, 1, true);
+        while (st == CP2_OK && consumed < n_groups) { st = consume(consumed); ++consumed; }
+        pool.wait_idle();                                      // nothing reads this batch's landing buffers or nodes any more
+        (void)hipStreamSynchronize(aux);
+        if (st == CP2_OK && t) {
+          hipError_t e = hipMemcpyAsync(dsp->local_roots.u8() + base * 32, cp2_slot_trees_roots_dev(t), nb * 32, hipMemcpyDeviceToDevice, ctx->stream);
+          if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+          if (e != hipSuccess) { ctx->err = std::string("streamed roots-only build: ") + hipGetErrorString(e); st = CP2_ERR_HIP; }
+        }
+        cp2_slot_trees_free(t);
+        if (trace.on && ((base / batch) % 32 == 31 || base + nb == n_local))
+          std::fprintf(stderr, "[cp2 trace] streamed roots-only build: %zu of %llu slots\n", base + nb, (unsigned long long)n_local);
+      }
+      trace.lap("trees + bodies, batch by batch (trees dropped)");
+    }
     if (st != CP2_OK) return st;
   }
   if (task_status.load() != CP2_OK) {

@@ -85,8 +85,10 @@ int cp2_set_body_budget(cp2_ctx* ctx, size_t max_resident_bytes, const char* spi
  * batch in the context's scratch and dropped, the 32-byte slot roots stay, and cp2_proof_input_generate rebuilds the tree of
  * the slot it proves (0.2 s per 8 GiB slot; the reference rebuilds it once per sample, gen_input/bn254.nim:57).  Same results.
  * mode: 1 keep the trees, 0 roots only, -1 (default) the environment variable CODEX_P2_KEEP_TREES ("0" / "1"), else keep
- * them when they fit what the device has free.  cp2_dataset_keeps_trees tells what a built dataset did.  Streamed and cached
- * builds always keep their trees. */
+ * them when they fit what the device has free.  cp2_dataset_keeps_trees tells what a built dataset did.  The streamed build
+ * follows the same rule (roots only: the bodies of a batch of slots are made while its trees exist, then the trees go: every
+ * proof input of 4096 slots of 8 GiB in one pass over the data); cached builds always keep their trees (they are what is
+ * cached). */
 int cp2_set_keep_trees(cp2_ctx* ctx, int mode);
 
 /* ---- a1: Poseidon2 t=3 permutation --------------------------------------------------------- */

@@ -344,6 +344,13 @@ def test_roots_only_dataset_gives_the_same_proof_inputs(pkg, golden, oracle, tmp
         assert not ds.keeps_trees
         assert np.array_equal(ds.local_roots(), keep.local_roots()) and np.array_equal(ds.root(), keep.root())
         assert ds.proof_input(m0["slotIndex"], m0["entropy"]).json() == want
+        sd = single.dataset_streamed(cfg, m0["entropy"], threads=3, group_slots=2)   # streamed: bodies made while a batch's trees exist
+        assert not sd.keeps_trees and np.array_equal(sd.local_roots(), keep.local_roots())
+        sd.export_streamed(None, threads=2)
+        assert sd.streamed_json(m0["slotIndex"]) == want
+        assert sd.streamed_json(c["nSlots"] - 1) == keep.proof_input(c["nSlots"] - 1, m0["entropy"]).json()
+        assert sd.proof_input(0, 987654321).json() == keep.proof_input(0, 987654321).json()   # another entropy: the slot's tree rebuilt
+        sd.free()
         every = ds.proof_inputs(list(range(c["nSlots"])), m0["entropy"])          # a batch: one rebuilt tree after the other
         assert every[m0["slotIndex"]].json() == want
         assert every[0].json() == keep.proof_input(0, m0["entropy"]).json()
@@ -387,6 +394,13 @@ def test_bigslots_roots_only_vs_oracle_fixture(pkg, golden):
         text = ds.proof_input(slot, g["entropy"]).json()
         assert tsha(text) == g["inputs"][str(slot)]["json_sha256"], slot
     ds.free()
+    # streamed and roots-only: every input.json of the 8 slots in one pass, nodes of at most 8 slots alive
+    sd = ctx.dataset_streamed(pkg.make_config(**g["config"]), g["entropy"], threads=_threads(), group_slots=1)
+    assert not sd.keeps_trees and hexroot(sd.root()) == g["dataset_root_hex"]
+    sd.export_streamed(None, threads=2)
+    for slot in range(8):
+        assert tsha(sd.streamed_json(slot)) == g["inputs"][str(slot)]["json_sha256"], slot
+    sd.free()
     ctx.close()
 
 
