@@ -346,6 +346,14 @@ def main():
                                                          workload="configs[4] at its nominal slot size, one GPU's share: 4096 slots x 2^22 cells x 2048 B = 32 TiB, roots-only build")
         except Exception:
             pass
+    rec = newest_profile("r*_config4_nominal.txt")
+    if rec and rank == 0:
+        try:
+            last = [l for l in open(rec).read().splitlines() if l.startswith("{")][-1]
+            extra["config4_nominal_record"] = dict(json.loads(last), source="%s (tools/config4_nominal.py; NOT measured in this run)" % os.path.relpath(rec, ROOT),
+                                                   workload="configs[3] at configs[2]'s slot size: 4096 slots x 8 GiB, nSamples=100, maxDepth=32, every input.json, streamed roots-only")
+        except Exception:
+            pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(C, np, torch, dev)
     if extra:
