@@ -19,7 +19,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20261004)
 single = pkg.Context(0)
 handles = {n: pkg.Multi([0] * n) for n in (2, 3, 4)}          # long-lived handles: contexts and their scratch pools are reused
 t0 = time.time()
-it = bad = checked_roots = checked_json = by_units = 0
+it = bad = checked_roots = checked_json = by_units = roots_only = 0
 free0 = None
 tmp = tempfile.mkdtemp(prefix="cp2soakm")
 modes = Counter()
@@ -43,6 +43,11 @@ while time.time() - t0 < budget:
     m.set_policy(int(rng.choice([pkg.GATHER_AUTO, pkg.GATHER_HOST])), min_cells)
     split = int(rng.choice([2, 4, 8] if UNITS else [0, 0, 1, 2, 4]))   # choose / whole slots only / every slot cut into 2, 4 (8) units
     m.set_split(split)
+    keep = int(rng.choice([-1, -1, 0]))                        # now and then roots-only datasets (trees dropped, rebuilt per proved slot)
+    for i in range(m.count):
+        m.ctx(i).set_keep_trees(keep)
+    single.set_keep_trees(int(rng.choice([-1, 0])))
+    roots_only += keep == 0
     use_file = (it % 5 == 0) and (cs & 3) == 0 and not big
     cc = dict(c)
     if use_file:
@@ -120,6 +125,6 @@ while time.time() - t0 < budget:
               (it, bad, checked_roots, checked_json, by_units, dict(modes), resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024, free / 2**30, free0 / 2**30,
                time.time() - t0), flush=True)
 shutil.rmtree(tmp, ignore_errors=True)
-print("multi-context soak done: %d iterations (%d of them cut by units), %d roots and %d input.json texts checked against the oracle, gather modes %s, mismatches: %d, %.0f s" %
-      (it, by_units, checked_roots, checked_json, dict(modes), bad, time.time() - t0))
+print("multi-context soak done: %d iterations (%d of them cut by units, %d roots-only), %d roots and %d input.json texts checked against the oracle, gather modes %s, mismatches: %d, %.0f s" %
+      (it, by_units, roots_only, checked_roots, checked_json, dict(modes), bad, time.time() - t0))
 sys.exit(1 if bad else 0)
