@@ -88,7 +88,8 @@ int cp2_set_body_budget(cp2_ctx* ctx, size_t max_resident_bytes, const char* spi
  * them when they fit what the device has free.  cp2_dataset_keeps_trees tells what a built dataset did.  The streamed build
  * follows the same rule (roots only: the bodies of a batch of slots are made while its trees exist, then the trees go: every
  * proof input of 4096 slots of 8 GiB in one pass over the data); cached builds always keep their trees (they are what is
- * cached). */
+ * cached).  On a roots-only dataset every cp2_proof_input_generate costs one slot rebuild, and the batch / export calls one per
+ * slot: to get the proof inputs of ALL slots use the streamed build. */
 int cp2_set_keep_trees(cp2_ctx* ctx, int mode);
 
 /* ---- a1: Poseidon2 t=3 permutation --------------------------------------------------------- */
