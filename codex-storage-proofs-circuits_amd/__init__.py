@@ -270,7 +270,8 @@ class Context:
         self._ck(self.L.cp2_trim(self.h), "cp2_trim")
 
     def set_keep_trees(self, mode=-1):
-        """cp2_dataset_build keeps every slot tree resident (1), only the roots (0), or decides by what fits (-1)"""
+        """cp2_dataset_build keeps every node of the slot trees resident (1), the block roots and up (2: compact), only the
+        roots (0), or the most that fits (-1)"""
         self._ck(self.L.cp2_set_keep_trees(self.h, mode), "cp2_set_keep_trees")
 
     def set_body_budget(self, max_resident_bytes=0, spill_dir=None):
@@ -525,8 +526,13 @@ class Dataset:
             self.ctx._ck(self.ctx.L.cp2_dataset_set_roots(self.h, _p(r)), "cp2_dataset_set_roots")
 
     @property
+    def tree_mode(self):
+        """1 every node resident, 2 compact (block roots and up), 0 roots only"""
+        return self.ctx.L.cp2_dataset_keeps_trees(self.h)
+
+    @property
     def keeps_trees(self):
-        return bool(self.ctx.L.cp2_dataset_keeps_trees(self.h))
+        return self.tree_mode == 1
 
     def local_roots_dev(self):
         """device pointer to the n_local x 32 bytes of local slot roots"""

@@ -115,7 +115,7 @@ extern "C" int cp2_trim(cp2_ctx* ctx) try {
 }
 
 extern "C" int cp2_set_keep_trees(cp2_ctx* ctx, int mode) try {
-  if (!ctx || mode < -1 || mode > 1) return CP2_ERR_INVALID;
+  if (!ctx || mode < -1 || mode > 2) return CP2_ERR_INVALID;
   ctx->keep_trees = mode;
   return CP2_OK;
 } catch (...) {

@@ -106,7 +106,7 @@ struct cp2_ctx {
   size_t ingest_chunk = 0;
   int ingest_direct = -1;                    // SlotFile reads with O_DIRECT: 1 on, 0 off, -1 = environment CP2_INGEST_DIRECT (cp2_set_ingest_direct)
   size_t body_budget = 0;                    // streamed proof-input bodies kept in host memory; 0: CP2_BODY_BUDGET_MB or 4 GiB (cp2_set_body_budget)
-  int keep_trees = -1;                       // cp2_dataset_build keeps every slot tree in device memory: 1 yes, 0 roots only, -1 = CODEX_P2_KEEP_TREES or by what fits (cp2_set_keep_trees)
+  int keep_trees = -1;                       // what cp2_dataset_build keeps of the slot trees in device memory: 1 every node, 2 block roots and up, 0 roots only, -1 = CODEX_P2_KEEP_TREES or the most that fits (cp2_set_keep_trees)
   std::string spill_dir;                     // where bodies beyond the budget go; empty: $TMPDIR or /tmp
   std::string err;
 };

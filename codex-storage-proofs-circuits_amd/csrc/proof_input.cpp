@@ -172,6 +172,14 @@ struct cp2_dataset {
   // 32-byte roots stay; the tree of a slot that is proved is rebuilt on demand (0.2 s per 8 GiB), which is what the reference
   // does on EVERY run and once more per sample (gen_input/bn254.nim:42,57).
   DevBuf local_roots;                         // roots-only: n_local x 32 bytes
+  // Compact dataset (between the two): of every local slot tree the part from the BLOCK ROOTS up stays (2 x nBlocks - 1 nodes:
+  // 8 MiB per 8 GiB slot, 1/32 of the full tree), layer-major over the local slots: layer k of slot s starts at element
+  // coff[k] + s * csizes[k].  The bottom of a path -- inside one network block -- is recomputed from the block's own cells
+  // (<= nSamples blocks of 64 KiB per proof input: SURVEY.md section 7, "keep only block roots + upper layers and re-hash the
+  // touched blocks"), checked against the stored block root.
+  DevBuf compact;
+  std::vector<size_t> csizes, coff;
+  int tree_mode = 1;                          // 1 every node resident, 2 compact, 0 roots only
   bool have_roots = false;
   std::vector<size_t> dsizes;                 // dataset-tree layer sizes
   std::vector<uint8_t> dlayers;               // all dataset-tree layers, bottom first (host copy)
@@ -232,7 +240,9 @@ static int dataset_build_trees(cp2_dataset* ds, size_t group, const SlotsDone& d
 
 // the device buffer holding the roots of the local slots (n_local x 32 bytes)
 static const void* dataset_roots_dev(const cp2_dataset* ds) {
-  return ds->trees ? cp2_slot_trees_roots_dev(ds->trees) : ds->local_roots.p;
+  if (ds->trees) return cp2_slot_trees_roots_dev(ds->trees);
+  if (ds->tree_mode == 2) return ds->compact.u8() + ds->coff.back() * 32;   // the last layer: one root per local slot
+  return ds->local_roots.p;
 }
 
 // the trees of `n` local slots starting at local index `s0`, in pooled scratch (roots-only datasets: batches of the build, and
@@ -244,41 +254,79 @@ static int dataset_transient_trees(const cp2_dataset* ds, size_t s0, size_t n, c
   return trees_build_fake(ds->ctx, c.seed, ds->first_slot + s0, n, c.cell_size, c.block_size, c.n_cells, 0, nullptr, out, 1, true);
 }
 
-// Does this dataset keep its trees?  The caller's word (cp2_set_keep_trees / CODEX_P2_KEEP_TREES), else whether the node buffer
-// fits: it must leave room for the builders' staging (two 2 GiB chunks) and some slack in what the device has free right now.
-static bool dataset_keeps_trees(cp2_ctx* ctx, const cp2_config& c, uint64_t n_local) {
+// bytes of the compact part (block roots and up) of n_slots slot trees
+static size_t compact_bytes(const cp2_config& c, size_t n_slots) {
+  size_t per_slot = 0;
+  for (size_t m : layer_sizes_of(c.n_cells / (c.block_size / c.cell_size))) per_slot += m;
+  return n_slots * per_slot * 32;
+}
+
+// What of its trees does this dataset keep?  1 every node, 2 the compact part, 0 the roots.  The caller's word (cp2_set_keep_trees /
+// CODEX_P2_KEEP_TREES), else the most that fits: a buffer must leave room for the builders' staging (two 2 GiB chunks), the batch in
+// flight and some slack in what the device has free right now.
+static int dataset_tree_mode(cp2_ctx* ctx, const cp2_config& c, uint64_t n_local) {
   int mode = ctx->keep_trees;
   if (mode < 0) {
     const char* e = std::getenv("CODEX_P2_KEEP_TREES");
-    if (e && (*e == '0' || *e == '1')) mode = *e - '0';
+    if (e && *e >= '0' && *e <= '2' && e[1] == 0) mode = *e - '0';
   }
-  if (mode >= 0) return mode == 1;
+  if (mode >= 0) return mode;
   size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return true; }
-  const unsigned __int128 need = (unsigned __int128)trees_node_bytes(1, c.cell_size, c.block_size, c.n_cells) * n_local;
-  return need + ((unsigned __int128)6 << 30) <= (unsigned __int128)free_b * 9 / 10;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 1; }
+  const unsigned __int128 room = (unsigned __int128)free_b * 9 / 10, slack = (unsigned __int128)8 << 30;
+  if ((unsigned __int128)trees_node_bytes(1, c.cell_size, c.block_size, c.n_cells) * n_local + slack <= room) return 1;
+  if ((unsigned __int128)compact_bytes(c, 1) * n_local + slack <= room) return 2;
+  return 0;
 }
 
-// roots-only build: batches of at most ~2 GiB of nodes (8 slots of 8 GiB; at least one slot), every batch a normal builder call
-static int dataset_build_roots_only(cp2_dataset* ds) {
+// compact / roots-only datasets: room for what stays of the local slots
+static int dataset_alloc_kept(cp2_dataset* ds, int mode) {
+  ds->tree_mode = mode;
+  if (mode == 0) return ds->local_roots.alloc(ds->ctx, ds->n_local * 32);
+  const cp2_config& c = ds->cfg;
+  ds->csizes = layer_sizes_of(c.n_cells / (c.block_size / c.cell_size));
+  ds->coff.clear();
+  size_t off = 0;
+  for (size_t m : ds->csizes) { ds->coff.push_back(off); off += ds->n_local * m; }
+  return ds->compact.alloc(ds->ctx, off * 32);
+}
+
+// ... and what stays of a finished batch `t` (local slots [base, base + t->n_slots)): its roots, or its layers from the block roots up.
+// Enqueued on the context's stream; the caller synchronises before the batch's nodes go back to the pool.
+static int dataset_keep_from_batch(cp2_dataset* ds, const cp2_slot_trees* t, size_t base) {
+  cp2_ctx* ctx = ds->ctx;
+  if (ds->tree_mode == 0) {
+    CP2_HIP(ctx, hipMemcpyAsync(ds->local_roots.u8() + base * 32, cp2_slot_trees_roots_dev(t), t->n_slots * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    return CP2_OK;
+  }
+  for (size_t k = 0; k < t->tsizes.size(); ++k)   // layer k of the batch's slots is contiguous, and so is its place in the dataset's layout
+    CP2_HIP(ctx, hipMemcpyAsync(ds->compact.u8() + (ds->coff[k] + base * ds->csizes[k]) * 32, t->nodes.u8() + t->toff[k] * 32,
+                                t->n_slots * t->tsizes[k] * 32, hipMemcpyDeviceToDevice, ctx->stream));
+  return CP2_OK;
+}
+
+// compact / roots-only build: batches of at most ~2 GiB of nodes (8 slots of 8 GiB; at least one slot), every batch a normal builder
+// call into pooled scratch; what the mode keeps is copied out, the rest goes back to the pool
+static int dataset_build_transient(cp2_dataset* ds, int mode) {
   cp2_ctx* ctx = ds->ctx;
   const cp2_config& c = ds->cfg;
   const size_t per_slot = trees_node_bytes(1, c.cell_size, c.block_size, c.n_cells);
   const size_t batch = std::max<size_t>(1, std::min<size_t>(ds->n_local, ((size_t)2 << 30) / std::max<size_t>(per_slot, 1)));
-  CP2_TRY(ds->local_roots.alloc(ctx, ds->n_local * 32));
+  CP2_TRY(dataset_alloc_kept(ds, mode));
+  const char* what = mode == 2 ? "compact" : "roots-only";
   StageTimer trace;
   for (size_t s0 = 0; s0 < ds->n_local; s0 += batch) {
     const size_t n = std::min(batch, (size_t)ds->n_local - s0);
     cp2_slot_trees* t = nullptr;
     CP2_TRY(dataset_transient_trees(ds, s0, n, &t));
-    hipError_t e = hipMemcpyAsync(ds->local_roots.u8() + s0 * 32, cp2_slot_trees_roots_dev(t), n * 32, hipMemcpyDeviceToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    int st = dataset_keep_from_batch(ds, t, s0);
+    if (st == CP2_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = std::string(what) + " build: copy out of a batch failed"; st = CP2_ERR_HIP; }
     cp2_slot_trees_free(t);
-    if (e != hipSuccess) { ctx->err = std::string("roots-only build: ") + hipGetErrorString(e); return CP2_ERR_HIP; }
+    if (st != CP2_OK) return st;
     if (trace.on && ((s0 / batch) % 32 == 31 || s0 + n == ds->n_local))   // a long build says where it is (CP2_TRACE)
-      std::fprintf(stderr, "[cp2 trace] roots-only build: %zu of %llu slots\n", s0 + n, (unsigned long long)ds->n_local);
+      std::fprintf(stderr, "[cp2 trace] %s build: %zu of %llu slots\n", what, s0 + n, (unsigned long long)ds->n_local);
   }
-  trace.lap("roots-only build (trees dropped)");
+  trace.lap(mode == 2 ? "compact build (block layers dropped)" : "roots-only build (trees dropped)");
   return CP2_OK;
 }
 
@@ -290,8 +338,9 @@ static int dataset_build(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slo
   if (!ds) return CP2_ERR_ALLOC;
   CP2_TRY(trees_check_geometry(cfg->cell_size, cfg->block_size, cfg->n_cells, n_local));
   CP2_HIP(ctx, hipSetDevice(ctx->device));
-  if (always_keep_trees || dataset_keeps_trees(ctx, ds->cfg, n_local)) CP2_TRY(dataset_build_trees(ds.get(), 0, nullptr));
-  else CP2_TRY(dataset_build_roots_only(ds.get()));
+  const int mode = always_keep_trees ? 1 : dataset_tree_mode(ctx, ds->cfg, n_local);
+  if (mode == 1) CP2_TRY(dataset_build_trees(ds.get(), 0, nullptr));
+  else CP2_TRY(dataset_build_transient(ds.get(), mode));
   *out = ds.release();
   return CP2_OK;
 }
@@ -345,7 +394,7 @@ extern "C" int cp2_dataset_local_roots(cp2_dataset* ds, uint8_t* out) try {
   if (ds->trees) return cp2_slot_trees_roots(ds->trees, out);
   cp2_ctx* ctx = ds->ctx;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
-  CP2_HIP(ctx, hipMemcpyAsync(out, ds->local_roots.p, ds->n_local * 32, hipMemcpyDeviceToHost, ctx->stream));
+  CP2_HIP(ctx, hipMemcpyAsync(out, dataset_roots_dev(ds), ds->n_local * 32, hipMemcpyDeviceToHost, ctx->stream));
   CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return CP2_OK;
 } catch (const std::bad_alloc&) {
@@ -407,7 +456,7 @@ extern "C" int cp2_dataset_set_roots_dev(cp2_dataset* ds, const void* d_all_root
 }
 
 extern "C" const void* cp2_dataset_local_roots_dev(const cp2_dataset* ds) { return ds ? dataset_roots_dev(ds) : nullptr; }
-extern "C" int cp2_dataset_keeps_trees(const cp2_dataset* ds) { return ds && ds->trees ? 1 : 0; }
+extern "C" int cp2_dataset_keeps_trees(const cp2_dataset* ds) { return !ds ? 0 : (ds->trees ? 1 : ds->tree_mode); }
 
 extern "C" int cp2_dataset_copy_local_roots_dev(cp2_dataset* ds, void* d_out) try {
   if (!ds || !d_out) return CP2_ERR_INVALID;
@@ -605,6 +654,107 @@ static int host_cells_global(cp2_slot_trees* t, const uint64_t* g, size_t n, uin
   return CP2_ERR_INVALID;
 }
 
+static void fill_slot_proof(const cp2_dataset* ds, uint64_t slot_idx, std::vector<uint8_t>& out);
+
+// generateProofInput (gen_input/bn254.nim:53-74) on a COMPACT dataset: the top of every path -- block root to slot root -- is
+// gathered from the stored layers; the bottom -- cell to block root (merkleProof on the block's tree, blocks/bn254.nim:60-67) --
+// comes from the trees of the <= nSamples touched blocks, rebuilt here from the blocks' own cells (regenerated, or read from the
+// slot file) as a batch of one-block "slots" and checked against the stored block roots.  One slot per call; entropy canonical.
+static int compact_proof_input(cp2_dataset* ds, uint64_t slot, const uint8_t entropy[32], cp2_proof_input** out) {
+  cp2_ctx* ctx = ds->ctx;
+  const cp2_config& c = ds->cfg;
+  const size_t ns = c.n_samples, md = (size_t)c.max_depth, cs = c.cell_size, cpb = c.block_size / c.cell_size, nblocks = c.n_cells / cpb;
+  const size_t ls = (size_t)(slot - ds->first_slot);
+  const size_t depth_b = layer_sizes_of(cpb).size() - 1, depth_t = ds->csizes.size() - 1;
+  if (depth_b + depth_t > md) return CP2_ERR_INVALID;                                   // padMerkleProof assert, types.nim:29
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  const uint8_t* slot_root = &ds->dlayers[slot * 32];                                   // layer 0 of the dataset tree
+  std::vector<uint64_t> idx(ns);
+  if (ns) CP2_TRY(cp2_cell_indices(ctx, entropy, slot_root, c.n_cells, ns, idx.data()));   // sample/bn254.nim:16-27
+  std::vector<uint8_t> paths(ns * md * 32, 0), leaves(ns * 32), cells(ns * cs);
+  if (ns) {
+    // the cells of the touched blocks, block after block, in device scratch
+    const size_t n_bc = ns * cpb;
+    DevBuf d_cells, d_list, d_rows, d_got;
+    CP2_TRY(d_cells.scratch(ctx, n_bc * cs));
+    std::vector<uint8_t> h_blocks;                                                       // SlotFile: read on the host first
+    if (ds->from_file) {
+      h_blocks.resize(n_bc * cs);
+      const std::string fname = slot_file_name(ds->file_base, slot);
+      const int fd = open(fname.c_str(), O_RDONLY);
+      if (fd < 0) { ctx->err = "cannot open " + fname; return CP2_ERR_IO; }
+      for (size_t i = 0; i < ns; ++i)
+        for (size_t j = 0; j < cpb; ++j) read_file_cell(fd, cs, (idx[i] / cpb) * cpb + j, &h_blocks[(i * cpb + j) * cs]);
+      close(fd);
+      CP2_HIP(ctx, hipMemcpyAsync(d_cells.p, h_blocks.data(), h_blocks.size(), hipMemcpyHostToDevice, ctx->stream));
+    } else {
+      std::vector<uint64_t> list(n_bc);
+      for (size_t i = 0; i < ns; ++i)
+        for (size_t j = 0; j < cpb; ++j) list[i * cpb + j] = (idx[i] / cpb) * cpb + j;
+      CP2_TRY(d_list.scratch(ctx, n_bc * 8));
+      CP2_HIP(ctx, hipMemcpyAsync(d_list.p, list.data(), n_bc * 8, hipMemcpyHostToDevice, ctx->stream));
+      CP2_HIP(ctx, cp2k::launch_gen_fake_cells(cp2_slot_seed(c.seed, slot), 0, 0, static_cast<const uint64_t*>(d_list.p), n_bc, cs, d_cells.p, ctx->stream));
+      CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));                                   // `list` leaves scope below
+    }
+    // one-block "slots": hash the cells, build the block trees (the singleton layer on top of each is not used)
+    cp2_slot_trees* mini = nullptr;
+    CP2_TRY(cp2_slot_trees_build_dev(ctx, d_cells.p, ns, cs, c.block_size, cpb, &mini));
+    struct Mini { cp2_slot_trees* t; ~Mini() { cp2_slot_trees_free(t); } } mini_guard{mini};
+    // rows to gather: per sample the depth_b siblings inside its block, its leaf, the rebuilt block root (from `mini`), then the
+    // depth_t siblings above the block and the stored block root (from the compact layers)
+    const size_t per_m = depth_b + 2, per_c = depth_t + 1;
+    std::vector<uint64_t> rows_m(ns * per_m), rows_c(ns * per_c);
+    for (size_t i = 0; i < ns; ++i) {
+      const uint64_t in_block = idx[i] % cpb, b = idx[i] / cpb;
+      std::vector<uint64_t> r(depth_b + 1);
+      path_rows(mini, i, in_block, depth_b + 1, r.data());                               // block layers, then the singleton's (unused) entry
+      for (size_t d = 0; d < depth_b; ++d) rows_m[i * per_m + d] = r[d];
+      rows_m[i * per_m + depth_b] = i * cpb + in_block;                                  // the leaf: layer 0 of `mini`
+      rows_m[i * per_m + depth_b + 1] = mini->toff[0] + i;                               // the block root: layer 0 of its singleton tree
+      uint64_t k = b, m = nblocks;
+      for (size_t d = 0; d < depth_t; ++d) {                                             // merkleProof(bigTree, blockIdx), merkle.nim:21-42
+        const uint64_t sib = k ^ 1;
+        rows_c[i * per_c + d] = sib < m ? ds->coff[d] + ls * ds->csizes[d] + sib : NO_ROW;
+        k >>= 1;
+        m = (m + 1) >> 1;
+      }
+      rows_c[i * per_c + depth_t] = ds->coff[0] + ls * ds->csizes[0] + b;                // the stored root of the block
+    }
+    const size_t n_m = rows_m.size(), n_c = rows_c.size();
+    CP2_TRY(d_rows.scratch(ctx, (n_m + n_c) * 8));
+    CP2_TRY(d_got.scratch(ctx, (n_m + n_c) * 32));
+    uint64_t* dr = static_cast<uint64_t*>(d_rows.p);
+    CP2_HIP(ctx, hipMemcpyAsync(dr, rows_m.data(), n_m * 8, hipMemcpyHostToDevice, ctx->stream));
+    CP2_HIP(ctx, hipMemcpyAsync(dr + n_m, rows_c.data(), n_c * 8, hipMemcpyHostToDevice, ctx->stream));
+    CP2_HIP(ctx, cp2k::launch_gather_rows(mini->nodes.p, dr, n_m, 32, d_got.p, ctx->stream));
+    CP2_HIP(ctx, cp2k::launch_gather_rows(ds->compact.p, dr + n_m, n_c, 32, d_got.u8() + n_m * 32, ctx->stream));
+    std::vector<uint8_t> got((n_m + n_c) * 32), blocks;
+    CP2_HIP(ctx, hipMemcpyAsync(got.data(), d_got.p, got.size(), hipMemcpyDeviceToHost, ctx->stream));
+    if (!ds->from_file) {
+      blocks.resize(n_bc * cs);
+      CP2_HIP(ctx, hipMemcpyAsync(blocks.data(), d_cells.p, blocks.size(), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint8_t* src_blocks = ds->from_file ? h_blocks.data() : blocks.data();
+    for (size_t i = 0; i < ns; ++i) {
+      const uint8_t* gm = &got[i * per_m * 32];
+      const uint8_t* gc = &got[(n_m + i * per_c) * 32];
+      if (std::memcmp(gm + (depth_b + 1) * 32, gc + depth_t * 32, 32) != 0) {            // the data no longer hashes to the stored block root
+        ctx->err = "block " + std::to_string(idx[i] / cpb) + " of slot " + std::to_string(slot) + " does not hash to its stored root (slot data changed since the build?)";
+        return CP2_ERR_IO;
+      }
+      std::memcpy(&paths[i * md * 32], gm, depth_b * 32);
+      std::memcpy(&paths[(i * md + depth_b) * 32], gc, depth_t * 32);
+      std::memcpy(&leaves[i * 32], gm + depth_b * 32, 32);
+      std::memcpy(&cells[i * cs], src_blocks + (i * cpb + idx[i] % cpb) * cs, cs);
+    }
+  }
+  std::vector<uint8_t> proof;
+  fill_slot_proof(ds, slot, proof);
+  return cp2_proof_input_create(&c, slot, &ds->dlayers[ds->dlayers.size() - 32], entropy, slot_root, proof.data(), ns, idx.data(), cells.data(),
+                                paths.data(), leaves.data(), out);
+}
+
 // generateProofInput (gen_input/bn254.nim:35-79) for `n` slots of the dataset at once: one sampling launch,
 // one path gather, one cell fetch for all of them.
 extern "C" int cp2_proof_inputs_generate_batch(cp2_dataset* ds, const uint64_t* slot_idx, size_t n, const uint8_t entropy_in[32],
@@ -620,6 +770,18 @@ extern "C" int cp2_proof_inputs_generate_batch(cp2_dataset* ds, const uint64_t* 
     if (slot_idx[i] < ds->first_slot || slot_idx[i] >= ds->first_slot + ds->n_local) return CP2_ERR_INVALID;
   if (!is_pow2(cfg.n_cells)) return CP2_ERR_INVALID;                    // sample/bn254.nim:19-20
   if (cfg.n_samples && cfg.n_cells < 2) return CP2_ERR_INVALID;         // extractLowBits asserts k > 0, types/bn254.nim:48
+  if (!ds->trees && ds->tree_mode == 2) {                               // compact dataset: stored upper layers + the touched blocks, slot by slot
+    if (!ds->have_roots) CP2_TRY(cp2_dataset_set_roots(ds, nullptr));
+    if (ds->dsizes.size() - 1 > (size_t)cfg.max_log2_nslots) return CP2_ERR_INVALID;   // padMerkleProof assert
+    for (size_t i = 0; i < n; ++i) {
+      int st = compact_proof_input(ds, slot_idx[i], entropy, out + i);
+      if (st != CP2_OK) {
+        for (size_t j = 0; j < i; ++j) { cp2_proof_input_free(out[j]); out[j] = nullptr; }
+        return st;
+      }
+    }
+    return CP2_OK;
+  }
   if (!ds->trees && n > 1) {                                            // roots-only dataset: one slot, one rebuilt tree, at a time
     for (size_t i = 0; i < n; ++i) {
       int st = cp2_proof_inputs_generate_batch(ds, slot_idx + i, 1, entropy_in, out + i);
@@ -1245,7 +1407,8 @@ extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, u
     };
 
     int st = CP2_OK;
-    if (dataset_keeps_trees(ctx, cfgv, n_local)) {
+    const int tree_mode = dataset_tree_mode(ctx, cfgv, n_local);
+    if (tree_mode == 1) {
       st = dataset_build_trees(dsp, group_slots, on_done);
       trace.lap("trees (sampling overlapped)");
       while (st == CP2_OK && consumed < n_groups) { st = consume(consumed); ++consumed; }
@@ -1260,7 +1423,7 @@ extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, u
       const size_t per_slot = trees_node_bytes(1, cfgv.cell_size, cfgv.block_size, cfgv.n_cells);
       size_t batch = std::max<size_t>(1, ((size_t)2 << 30) / std::max<size_t>(per_slot, 1));
       batch = std::max(group_slots, batch / group_slots * group_slots);
-      st = dsp->local_roots.alloc(ctx, n_local * 32);
+      st = dataset_alloc_kept(dsp, tree_mode);
       for (size_t base = 0; st == CP2_OK && base < n_local; base += batch) {
         const size_t nb = std::min(batch, (size_t)n_local - base);
         slot_base = base;
@@ -1272,13 +1435,12 @@ extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, u
         pool.wait_idle();                                      // nothing reads this batch's landing buffers or nodes any more
         (void)hipStreamSynchronize(aux);
         if (st == CP2_OK && t) {
-          hipError_t e = hipMemcpyAsync(dsp->local_roots.u8() + base * 32, cp2_slot_trees_roots_dev(t), nb * 32, hipMemcpyDeviceToDevice, ctx->stream);
-          if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-          if (e != hipSuccess) { ctx->err = std::string("streamed roots-only build: ") + hipGetErrorString(e); st = CP2_ERR_HIP; }
+          st = dataset_keep_from_batch(dsp, t, base);
+          if (st == CP2_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "streamed build: copy out of a batch failed"; st = CP2_ERR_HIP; }
         }
         cp2_slot_trees_free(t);
         if (trace.on && ((base / batch) % 32 == 31 || base + nb == n_local))
-          std::fprintf(stderr, "[cp2 trace] streamed roots-only build: %zu of %llu slots\n", base + nb, (unsigned long long)n_local);
+          std::fprintf(stderr, "[cp2 trace] streamed %s build: %zu of %llu slots\n", tree_mode == 2 ? "compact" : "roots-only", base + nb, (unsigned long long)n_local);
       }
       trace.lap("trees + bodies, batch by batch (trees dropped)");
     }

@@ -79,17 +79,22 @@ int cp2_trim(cp2_ctx* ctx);
  * CP2_BODY_BUDGET_MB), spill_dir NULL = $TMPDIR or /tmp.  max_resident_bytes = 0 keeps the current budget; (size_t)-1 = never
  * spill.  A spill that fails is CP2_ERR_IO with the path in cp2_last_error. */
 int cp2_set_body_budget(cp2_ctx* ctx, size_t max_resident_bytes, const char* spill_dir);
-/* Device memory of cp2_dataset_build: the nodes of every local slot tree stay resident (3.1 % of the data: 256 MiB per 8 GiB
- * slot) so that proof inputs for any entropy cost two permutations per sample plus gathers.  A dataset whose nodes do not fit
- * (config 5's nominal 4096 x 8 GiB slots per GPU would need 1 TiB) is built ROOTS ONLY instead: the trees are built batch by
- * batch in the context's scratch and dropped, the 32-byte slot roots stay, and cp2_proof_input_generate rebuilds the tree of
- * the slot it proves (0.2 s per 8 GiB slot; the reference rebuilds it once per sample, gen_input/bn254.nim:57).  Same results.
- * mode: 1 keep the trees, 0 roots only, -1 (default) the environment variable CODEX_P2_KEEP_TREES ("0" / "1"), else keep
- * them when they fit what the device has free.  cp2_dataset_keeps_trees tells what a built dataset did.  The streamed build
- * follows the same rule (roots only: the bodies of a batch of slots are made while its trees exist, then the trees go: every
- * proof input of 4096 slots of 8 GiB in one pass over the data); cached builds always keep their trees (they are what is
- * cached).  On a roots-only dataset every cp2_proof_input_generate costs one slot rebuild, and the batch / export calls one per
- * slot: to get the proof inputs of ALL slots use the streamed build. */
+/* Device memory of cp2_dataset_build.  Three ways to hold the slot trees of a dataset, same results from each:
+ *   1  every node resident (3.1 % of the data: 256 MiB per 8 GiB slot): a proof input for any entropy costs two permutations
+ *      per sample plus gathers;
+ *   2  COMPACT: of every slot tree only the part from the block roots up stays (8 MiB per 8 GiB slot, 1/32 of the above); the
+ *      bottom of each path is recomputed from the <= nSamples touched network blocks (regenerated, or read from the slot file:
+ *      100 x 64 KiB), whose rebuilt roots are checked against the stored ones (a mismatch is CP2_ERR_IO: the slot data changed):
+ *      a few ms per proof input; 4096 slots of 8 GiB hold 32 GiB of device memory instead of 1 TiB;
+ *   0  ROOTS ONLY: the 32-byte slot roots stay; cp2_proof_input_generate rebuilds the whole tree of the slot it proves (0.2 s per
+ *      8 GiB slot; the reference rebuilds it once per SAMPLE, gen_input/bn254.nim:57).
+ * For 2 and 0 the trees are built batch by batch (about 2 GiB of nodes) in the context's scratch, what is kept is copied out, the
+ * rest dropped.  mode -1 (default): the environment variable CODEX_P2_KEEP_TREES ("0" / "1" / "2"), else the most that fits what
+ * the device has free (1, else 2, else 0).  cp2_dataset_keeps_trees tells what a built dataset did.  The streamed build follows
+ * the same rule (the bodies of a batch of slots are made while its trees exist: every proof input of 4096 slots of 8 GiB in one
+ * pass over the data); cached builds always keep every node (the nodes are what is cached).  On a roots-only dataset every
+ * cp2_proof_input_generate costs one slot rebuild, and the batch / export calls one per slot: to get the proof inputs of ALL
+ * slots use the streamed build. */
 int cp2_set_keep_trees(cp2_ctx* ctx, int mode);
 
 /* ---- a1: Poseidon2 t=3 permutation --------------------------------------------------------- */

@@ -322,11 +322,13 @@ def test_cli_twin_fuzz_against_the_oracle(pkg, oracle, tmp_path):
 
 
 # ---- roots-only datasets: the trees do not have to fit the device ------------------------------------------------------
+@pytest.mark.parametrize("mode", [0, 2])
 @pytest.mark.parametrize("name", ["params_default", "testmain_small", "odd_slots_one_block"])
-def test_roots_only_dataset_gives_the_same_proof_inputs(pkg, golden, oracle, tmp_path, name):
+def test_roots_only_dataset_gives_the_same_proof_inputs(pkg, golden, oracle, tmp_path, name, mode):
     """cp2_set_keep_trees(0): the slot trees are built batch by batch and dropped, the roots stay, the tree of the proved slot is
-    rebuilt on demand -- same roots, same dataset tree, same input.json (the committed oracle text), fake and file sources,
-    single and batched generation, also through cp2_multi and the cli twin (CODEX_P2_KEEP_TREES=0)."""
+    rebuilt on demand; cp2_set_keep_trees(2): the part of every slot tree from the block roots up stays, the bottom of each path
+    is recomputed from the touched blocks -- same roots, same dataset tree, same input.json (the committed oracle text), fake and
+    file sources, single, batched and streamed generation, also through cp2_multi and the cli twin (CODEX_P2_KEEP_TREES)."""
     C, _ = oracle
     m0 = golden("proof_inputs.json")["inputs"][name]
     c = m0["config"]
@@ -334,18 +336,18 @@ def test_roots_only_dataset_gives_the_same_proof_inputs(pkg, golden, oracle, tmp
     single = pkg.Context(0)
     keep = single.dataset(pkg.make_config(**c))
     assert keep.keeps_trees                                       # small: left to itself the library keeps the trees
-    single.set_keep_trees(0)
+    single.set_keep_trees(mode)
     base = str(tmp_path / "slot")
     for k in range(c["nSlots"]):
         C.gen_fake_cells(C.slot_seed(c["seed"], k), 0, c["nCells"], c["cellSize"]).tofile("%s%d.dat" % (base, k))
     for src in (dict(seed=c["seed"]), dict(file=base)):
         cfg = pkg.make_config(**dict({k: v for k, v in c.items() if k != "seed"}, **src))
         ds = single.dataset(cfg)
-        assert not ds.keeps_trees
+        assert ds.tree_mode == mode
         assert np.array_equal(ds.local_roots(), keep.local_roots()) and np.array_equal(ds.root(), keep.root())
         assert ds.proof_input(m0["slotIndex"], m0["entropy"]).json() == want
         sd = single.dataset_streamed(cfg, m0["entropy"], threads=3, group_slots=2)   # streamed: bodies made while a batch's trees exist
-        assert not sd.keeps_trees and np.array_equal(sd.local_roots(), keep.local_roots())
+        assert sd.tree_mode == mode and np.array_equal(sd.local_roots(), keep.local_roots())
         sd.export_streamed(None, threads=2)
         assert sd.streamed_json(m0["slotIndex"]) == want
         assert sd.streamed_json(c["nSlots"] - 1) == keep.proof_input(c["nSlots"] - 1, m0["entropy"]).json()
@@ -361,7 +363,7 @@ def test_roots_only_dataset_gives_the_same_proof_inputs(pkg, golden, oracle, tmp
     m.set_policy(pkg.GATHER_AUTO, 1)
     m.set_split(1)
     for i in range(m.count):
-        m.ctx(i).set_keep_trees(0)
+        m.ctx(i).set_keep_trees(mode)
     md = m.dataset(pkg.make_config(**c))
     assert md.proof_input(m0["slotIndex"], m0["entropy"]).json() == want and hexroot(md.root()) == hexroot(keep.root())
     md.free()
@@ -370,14 +372,40 @@ def test_roots_only_dataset_gives_the_same_proof_inputs(pkg, golden, oracle, tmp
     single.close()
 
 
-def test_cli_twin_roots_only(pkg, golden, tmp_path):
+@pytest.mark.parametrize("mode,marker", [("0", "roots-only build"), ("2", "compact build")])
+def test_cli_twin_roots_only(pkg, golden, tmp_path, mode, marker):
     args = ["--depth=32", "--maxslots=256", "--cellsize=2048", "--blocksize=65536", "--nsamples=5", "--entropy=1234567",
             "--seed=12345", "--nslots=11", "--ncells=512", "--index=3", "--field=bn254", "--hash=poseidon2"]
     out = str(tmp_path / "input.json")
     r = subprocess.run([pkg.CLI_PATH] + args + ["--output=" + out], capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, CP2_TRACE="1", CODEX_P2_KEEP_TREES="0"))
-    assert r.returncode == 0 and "roots-only build" in r.stderr, r.stderr
+                       env=dict(os.environ, CP2_TRACE="1", CODEX_P2_KEEP_TREES=mode))
+    assert r.returncode == 0 and marker in r.stderr, r.stderr
     assert open(out).read() == golden("input_params_default.json")
+
+
+def test_compact_dataset_notices_changed_slot_data(pkg, oracle, tmp_path):
+    """Compact datasets re-hash the touched blocks of the slot FILE at proof time: data that changed since the build no longer
+    hashes to the stored block root -- an I/O error naming block and slot, never a proof over mixed data."""
+    C, _ = oracle
+    c = dict(maxDepth=12, maxLog2NSlots=2, cellSize=128, blockSize=1024, nSlots=2, nCells=256, nSamples=40)
+    base = str(tmp_path / "slot")
+    for k in range(2):
+        C.gen_fake_cells(C.slot_seed(5, k), 0, 256, 128).tofile("%s%d.dat" % (base, k))
+    ctx = pkg.Context(0)
+    ctx.set_keep_trees(2)
+    ds = ctx.dataset(pkg.make_config(file=base, **c))
+    assert ds.tree_mode == 2
+    good = ds.proof_input(1, 77).json()
+    raw = bytearray(open(base + "1.dat", "rb").read())
+    for off in range(0, len(raw), 1024):                            # one byte in every block
+        raw[off] ^= 1
+    open(base + "1.dat", "wb").write(bytes(raw))
+    with pytest.raises(pkg.CodexP2Error) as e:
+        ds.proof_input(1, 77)
+    assert e.value.status == -5 and "does not hash to its stored root" in str(e.value) and "slot 1" in str(e.value)
+    assert ds.proof_input(0, 77).json() and good                    # the untouched slot still proves
+    ds.free()
+    ctx.close()
 
 
 def test_bigslots_roots_only_vs_oracle_fixture(pkg, golden):
@@ -386,14 +414,16 @@ def test_bigslots_roots_only_vs_oracle_fixture(pkg, golden):
     -- each from its tree rebuilt on demand -- against the oracle-only fixture."""
     g = _big(golden)
     ctx = pkg.Context(0)
+    for mode in (0, 2):
+        ctx.set_keep_trees(mode)
+        ds = ctx.dataset(pkg.make_config(**g["config"]))
+        assert ds.tree_mode == mode
+        assert [hexroot(r) for r in ds.local_roots()] == g["slot_roots_hex"] and hexroot(ds.root()) == g["dataset_root_hex"]
+        for slot in ((0, 7) if mode == 0 else range(8)):
+            text = ds.proof_input(slot, g["entropy"]).json()
+            assert tsha(text) == g["inputs"][str(slot)]["json_sha256"], (mode, slot)
+        ds.free()
     ctx.set_keep_trees(0)
-    ds = ctx.dataset(pkg.make_config(**g["config"]))
-    assert not ds.keeps_trees
-    assert [hexroot(r) for r in ds.local_roots()] == g["slot_roots_hex"] and hexroot(ds.root()) == g["dataset_root_hex"]
-    for slot in (0, 7):
-        text = ds.proof_input(slot, g["entropy"]).json()
-        assert tsha(text) == g["inputs"][str(slot)]["json_sha256"], slot
-    ds.free()
     # streamed and roots-only: every input.json of the 8 slots in one pass, nodes of at most 8 slots alive
     sd = ctx.dataset_streamed(pkg.make_config(**g["config"]), g["entropy"], threads=_threads(), group_slots=1)
     assert not sd.keeps_trees and hexroot(sd.root()) == g["dataset_root_hex"]

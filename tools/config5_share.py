@@ -7,7 +7,7 @@ rebuilt on demand.  No oracle can follow at this size (14 days of CPU), so the r
   * two more slot roots, chosen far apart, are recomputed by the C oracle on the host WHILE the GPU hashes;
   * the dataset root equals the oracle's Merkle root over the 4096 GPU-computed slot roots;
   * the emitted proof input passes the circuit-side checker (oracle.circuit_check: every `===` of the circom templates).
-Usage (needs CP2_TRACE=1 in the environment for progress lines):  config5_share.py [n_slots]"""
+Usage (needs CP2_TRACE=1 in the environment for progress lines):  config5_share.py [n_slots] [auto | 0 | 2]"""
 import json, os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -38,12 +38,16 @@ def oracle_side():
 th = threading.Thread(target=oracle_side)
 th.start()
 t0 = time.time()
-fits = n_slots * 0.2501 + 6 < free0 / 2**30 * 0.9
-if fits:
-    ctx.set_keep_trees(0)                  # a rehearsal at a size whose trees WOULD fit: roots only by request
-ds = ctx.dataset(cfg)                      # full share: roots only, decided by the library from the free memory
+mode_arg = sys.argv[2] if len(sys.argv) > 2 else "auto"      # auto: what the library picks from the free memory; 0 / 2: roots only / compact by request
+if mode_arg != "auto":
+    ctx.set_keep_trees(int(mode_arg))
+elif n_slots * 0.2501 + 8 < free0 / 2**30 * 0.9:
+    ctx.set_keep_trees(2)                  # a rehearsal at a size whose full trees WOULD fit: compact by request
+ds = ctx.dataset(cfg)
 dt = time.time() - t0
-assert not ds.keeps_trees, "expected a roots-only build"
+mode = ds.tree_mode
+print("the dataset keeps: %s" % {1: "every node", 2: "block roots and up (compact)", 0: "roots only"}[mode], flush=True)
+assert mode != 1
 free1, _ = torch.cuda.mem_get_info()
 perms = n_slots * (35 * n_cells - 1)
 print("built %d slots x 2^22 cells (%.1f TiB) in %.1f s: %.3e perm/s, %.2f GB/s hashed; device memory in use after the build %.2f GiB" %
@@ -58,9 +62,13 @@ root = ds.root()
 ok_tree = bool(np.array_equal(root, C.merkle_root(roots)))
 print("dataset root %s (%d-level tree over the %d roots) equals the oracle's tree over the same roots: %s  (%.3f s)" % (hexroot(root), len(ds.ctx.merkle_tree(roots[:n_slots])) - 1 if False else c["maxLog2NSlots"], n_slots, ok_tree, time.time() - t1), flush=True)
 slot = min(7, n_slots - 1)
-t2 = time.time()
-pi = ds.proof_input(slot, 1234567)
-dt_pi = time.time() - t2
+lat = []
+for s_ in (0, n_slots // 2, n_slots - 1, slot):      # the first call also sizes the context's scratch
+    t2 = time.time()
+    pi = ds.proof_input(s_, 1234567)
+    lat.append(round(time.time() - t2, 4))
+dt_pi = lat[-1]
+print("proof-input latency (slots 0, %d, %d, %d): %s s" % (n_slots // 2, n_slots - 1, slot, lat), flush=True)
 text = pi.json()
 d, sroot, e = pi.roots()
 to_int = lambda a: int.from_bytes(np.asarray(a, dtype=np.uint8).tobytes(), "little")   # noqa: E731
@@ -69,14 +77,14 @@ prf = {"dataSetRoot": to_int(d), "entropy": to_int(e), "nCells": n_cells, "nSlot
        "proofInputs": [{"cellData": pi.cell_data()[i].tobytes(), "merkleProof": {"merklePath": [to_int(x) for x in pi.merkle_paths()[i]]}}
                        for i in range(c["nSamples"])]}
 ok_circuit = bool(P.circuit_check(prf, c))
-print("proof input of slot %d from its tree rebuilt on demand: %.3f s, %d bytes of input.json; passes the circuit-side checker: %s" %
+print("proof input of slot %d: %.4f s, %d bytes of input.json; passes the circuit-side checker: %s" %
       (slot, dt_pi, len(text), ok_circuit), flush=True)
 th.join()
 ok_oracle = all(np.array_equal(roots[s], oracle_roots[s]) for s in checks)
 print("slot roots %s equal the C oracle's: %s" % (checks, ok_oracle), flush=True)
 print(json.dumps({"n_slots": n_slots, "TiB_hashed": n_slots * n_cells * cs / 2**40, "seconds": round(dt, 1), "perms_per_s": perms / dt,
                   "GB_per_s": n_slots * n_cells * cs / dt / 1e9, "device_GiB_in_use_after_build": round((free0 - free1) / 2**30, 2),
-                  "proof_input_s": round(dt_pi, 3), "dataset_root_hex": hexroot(root),
+                  "tree_mode": mode, "proof_input_s": round(dt_pi, 4), "proof_input_latencies_s": lat, "dataset_root_hex": hexroot(root),
                   "checks": {"slots_0_7_vs_fixture": ok_fixture, "dataset_tree_vs_oracle": ok_tree, "slots_vs_c_oracle": {str(s): bool(np.array_equal(roots[s], oracle_roots[s])) for s in checks},
                              "circuit_check": ok_circuit}}))
 sys.exit(0 if (ok_fixture and ok_tree and ok_circuit and ok_oracle) else 1)
