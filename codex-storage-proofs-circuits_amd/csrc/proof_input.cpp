@@ -307,12 +307,12 @@ static int dataset_keep_from_batch(cp2_dataset* ds, const cp2_slot_trees* t, siz
 
 // compact / roots-only build: batches of at most ~2 GiB of nodes (8 slots of 8 GiB; at least one slot), every batch a normal builder
 // call into pooled scratch; what the mode keeps is copied out, the rest goes back to the pool
-static int dataset_build_transient(cp2_dataset* ds, int mode) {
+static int dataset_build_transient(cp2_dataset* ds, int mode, bool allocated = false) {
   cp2_ctx* ctx = ds->ctx;
   const cp2_config& c = ds->cfg;
   const size_t per_slot = trees_node_bytes(1, c.cell_size, c.block_size, c.n_cells);
   const size_t batch = std::max<size_t>(1, std::min<size_t>(ds->n_local, ((size_t)2 << 30) / std::max<size_t>(per_slot, 1)));
-  CP2_TRY(dataset_alloc_kept(ds, mode));
+  if (!allocated) CP2_TRY(dataset_alloc_kept(ds, mode));
   const char* what = mode == 2 ? "compact" : "roots-only";
   StageTimer trace;
   for (size_t s0 = 0; s0 < ds->n_local; s0 += batch) {
@@ -361,6 +361,32 @@ extern "C" int cp2_dataset_build_cached(cp2_ctx* ctx, const cp2_config* cfg, uin
   if (!ctx || !cfg || !out || !cache_path) return CP2_ERR_INVALID;
   *out = nullptr;
   CP2_TRY(dataset_check(cfg, first_slot, n_local));
+  CP2_TRY(trees_check_geometry(cfg->cell_size, cfg->block_size, cfg->n_cells, n_local));
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  const int mode = dataset_tree_mode(ctx, *cfg, n_local);
+  if (mode != 1) {
+    // A dataset that keeps its trees compact (or only their roots) caches exactly that: 8 MiB per 8 GiB slot -- a later run loads
+    // it and proves with the touched blocks alone, no slot is hashed again.
+    std::unique_ptr<cp2_dataset> ds(dataset_new(ctx, cfg, first_slot, n_local));
+    if (!ds) return CP2_ERR_ALLOC;
+    CP2_TRY(dataset_alloc_kept(ds.get(), mode));
+    KeptMeta meta;
+    meta.n_slots = n_local; meta.cell_size = cfg->cell_size; meta.block_size = cfg->block_size; meta.n_cells = cfg->n_cells;
+    meta.src = (uint64_t)(ds->from_file ? CellSrc::File : CellSrc::Fake); meta.dataset_seed = cfg->seed; meta.first_slot = first_slot;
+    meta.mode = (uint64_t)mode; meta.file_base = ds->file_base;
+    void* buf = mode == 2 ? ds->compact.p : ds->local_roots.p;
+    const size_t bytes = mode == 2 ? compact_bytes(*cfg, n_local) : (size_t)n_local * 32;
+    StageTimer trace;
+    if (kept_load(ctx, cache_path, meta, buf, bytes) == CP2_OK) {
+      trace.lap(mode == 2 ? "compact layers loaded from the cache" : "slot roots loaded from the cache");
+    } else {
+      CP2_TRY(dataset_build_transient(ds.get(), mode, true));
+      CP2_TRY(kept_save(ctx, cache_path, meta, buf, bytes));
+      trace.lap("built and written to the cache");
+    }
+    *out = ds.release();
+    return CP2_OK;
+  }
   cp2_slot_trees* t = nullptr;
   if (cp2_slot_trees_load(ctx, cache_path, &t) == CP2_OK) {
     const bool from_file = cfg->file_base != nullptr;

@@ -880,6 +880,92 @@ extern "C" int cp2_slot_trees_load(cp2_ctx* ctx, const char* path, cp2_slot_tree
   return CP2_ERR_INVALID;
 }
 
+// ---- persisted compact layers / roots (what a dataset that does not keep every node keeps) ------------------------------------
+// Same discipline as the tree cache above: written to "<path>.tmp.<pid>" and renamed, a checksum over the payload, size + mtime of
+// every slot file for the SlotFile source.  The payload moves through one pinned 64 MiB buffer, chunk by chunk.
+namespace {
+struct KeptFileHeader {
+  char magic[8];            // "CP2KEPT1"
+  uint64_t n_slots, cell_size, block_size, n_cells, src, dataset_seed, first_slot, mode;
+  uint64_t file_base_len, n_stamps, payload_bytes, checksum;
+};
+}  // namespace
+
+int cp2i::kept_save(cp2_ctx* ctx, const char* path, const KeptMeta& m, const void* d_buf, size_t bytes) {
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  KeptFileHeader h{};
+  std::memcpy(h.magic, "CP2KEPT1", 8);
+  h.n_slots = m.n_slots; h.cell_size = m.cell_size; h.block_size = m.block_size; h.n_cells = m.n_cells;
+  h.src = m.src; h.dataset_seed = m.dataset_seed; h.first_slot = m.first_slot; h.mode = m.mode;
+  h.file_base_len = m.file_base.size();
+  std::vector<uint64_t> stamps;
+  if (m.src == (uint64_t)CellSrc::File) stamps = file_stamps(m.file_base, m.first_slot, m.n_slots);
+  h.n_stamps = stamps.size() / 2;
+  h.payload_bytes = bytes;
+  const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid());
+  const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0) { ctx->err = "cannot create " + tmp; return CP2_ERR_IO; }
+  struct FdGuard { int fd; std::string tmp; bool keep = false; ~FdGuard() { if (fd >= 0) close(fd); if (!keep) std::remove(tmp.c_str()); } } guard{fd, tmp};
+  off_t off = (off_t)sizeof h;
+  if (h.file_base_len && !pwrite_all(fd, reinterpret_cast<const uint8_t*>(m.file_base.data()), h.file_base_len, off)) return CP2_ERR_IO;
+  off += (off_t)h.file_base_len;
+  if (!stamps.empty() && !pwrite_all(fd, reinterpret_cast<const uint8_t*>(stamps.data()), stamps.size() * 8, off)) return CP2_ERR_IO;
+  off += (off_t)(stamps.size() * 8);
+  PinBuf pin;
+  CP2_TRY(pin.alloc(ctx, std::min(CACHE_CHUNK, std::max<size_t>(bytes, 32))));
+  Checksum64 sum;
+  for (size_t at = 0; at < bytes; at += CACHE_CHUNK) {
+    const size_t n = std::min(CACHE_CHUNK, bytes - at);
+    CP2_HIP(ctx, hipMemcpyAsync(pin.p, static_cast<const uint8_t*>(d_buf) + at, n, hipMemcpyDeviceToHost, ctx->stream));
+    CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    sum.update(pin.u8(), n);
+    if (!pwrite_all(fd, pin.u8(), n, off + (off_t)at)) return CP2_ERR_IO;
+  }
+  h.checksum = sum.finish();
+  if (!pwrite_all(fd, reinterpret_cast<const uint8_t*>(&h), sizeof h, 0)) return CP2_ERR_IO;
+  if (close(fd) != 0) { guard.fd = -1; return CP2_ERR_IO; }
+  guard.fd = -1;
+  if (std::rename(tmp.c_str(), path) != 0) return CP2_ERR_IO;
+  guard.keep = true;
+  return CP2_OK;
+}
+
+int cp2i::kept_load(cp2_ctx* ctx, const char* path, const KeptMeta& w, void* d_buf, size_t bytes) {
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) return CP2_ERR_IO;
+  struct Closer { int fd; ~Closer() { close(fd); } } closer{fd};
+  KeptFileHeader h{};
+  if (!pread_all(fd, reinterpret_cast<uint8_t*>(&h), sizeof h, 0) || std::memcmp(h.magic, "CP2KEPT1", 8) != 0 || h.file_base_len > 4096) return CP2_ERR_IO;
+  if (h.n_slots != w.n_slots || h.cell_size != w.cell_size || h.block_size != w.block_size || h.n_cells != w.n_cells || h.src != w.src ||
+      h.first_slot != w.first_slot || h.mode != w.mode || h.payload_bytes != bytes || h.file_base_len != w.file_base.size() ||
+      (w.src == (uint64_t)CellSrc::Fake && h.dataset_seed != w.dataset_seed) || (h.n_stamps != 0 && h.n_stamps != h.n_slots) ||
+      (h.src == (uint64_t)CellSrc::File) != (h.n_stamps != 0))
+    return CP2_ERR_IO;
+  off_t off = (off_t)sizeof h;
+  std::string base(h.file_base_len, '\0');
+  if (h.file_base_len && !pread_all(fd, reinterpret_cast<uint8_t*>(&base[0]), h.file_base_len, off)) return CP2_ERR_IO;
+  if (base != w.file_base) return CP2_ERR_IO;
+  off += (off_t)h.file_base_len;
+  std::vector<uint64_t> stamps(2 * h.n_stamps);
+  if (!stamps.empty() && !pread_all(fd, reinterpret_cast<uint8_t*>(stamps.data()), stamps.size() * 8, off)) return CP2_ERR_IO;
+  off += (off_t)(stamps.size() * 8);
+  if (h.src == (uint64_t)CellSrc::File && stamps != file_stamps(base, h.first_slot, h.n_slots)) return CP2_ERR_IO;   // the slot files changed
+  struct stat sb;
+  if (fstat(fd, &sb) != 0 || (uint64_t)sb.st_size != (uint64_t)off + bytes) return CP2_ERR_IO;                          // truncated / appended
+  if (hipSetDevice(ctx->device) != hipSuccess) return CP2_ERR_HIP;
+  PinBuf pin;
+  CP2_TRY(pin.alloc(ctx, std::min(CACHE_CHUNK, std::max<size_t>(bytes, 32))));
+  Checksum64 sum;
+  for (size_t at = 0; at < bytes; at += CACHE_CHUNK) {
+    const size_t n = std::min(CACHE_CHUNK, bytes - at);
+    if (!pread_all(fd, pin.u8(), n, off + (off_t)at)) return CP2_ERR_IO;
+    sum.update(pin.u8(), n);
+    CP2_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t*>(d_buf) + at, pin.p, n, hipMemcpyHostToDevice, ctx->stream));
+    CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return sum.finish() == h.checksum ? CP2_OK : CP2_ERR_IO;
+}
+
 // trees loaded from a cache that were built from caller memory have no cell source until one is attached
 extern "C" int cp2_slot_trees_attach_cells(cp2_slot_trees* t, const uint8_t* host_cells, const void* dev_cells) try {
   if (!t || (host_cells && dev_cells)) return CP2_ERR_INVALID;

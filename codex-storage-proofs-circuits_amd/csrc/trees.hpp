@@ -57,6 +57,16 @@ void read_file_cell(int fd, size_t cell_size, uint64_t cell, uint8_t* out);
 std::string slot_file_name(const std::string& base, uint64_t slot);
 bool is_pow2(uint64_t x);
 
+// Persisted form of what a compact / roots-only dataset keeps (proof_input.cpp): the kept layers of `n_slots` local slots plus what
+// they were built from.  kept_load fills the device buffer and returns CP2_OK only when the file is intact and describes exactly
+// `want` (and, for the SlotFile source, slot files of unchanged size and mtime); anything else is CP2_ERR_IO and means "rebuild".
+struct KeptMeta {
+  uint64_t n_slots = 0, cell_size = 0, block_size = 0, n_cells = 0, src = 0, dataset_seed = 0, first_slot = 0, mode = 0;
+  std::string file_base;
+};
+int kept_save(cp2_ctx* ctx, const char* path, const KeptMeta& meta, const void* d_buf, size_t bytes);
+int kept_load(cp2_ctx* ctx, const char* path, const KeptMeta& want, void* d_buf, size_t bytes);
+
 // stage timings on stderr when CP2_TRACE is set (the reference's only tracing is shell `time`, workflow/prove.sh:30-37)
 struct StageTimer {
   bool on;

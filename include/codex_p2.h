@@ -92,7 +92,8 @@ int cp2_set_body_budget(cp2_ctx* ctx, size_t max_resident_bytes, const char* spi
  * rest dropped.  mode -1 (default): the environment variable CODEX_P2_KEEP_TREES ("0" / "1" / "2"), else the most that fits what
  * the device has free (1, else 2, else 0).  cp2_dataset_keeps_trees tells what a built dataset did.  The streamed build follows
  * the same rule (the bodies of a batch of slots are made while its trees exist: every proof input of 4096 slots of 8 GiB in one
- * pass over the data); cached builds always keep every node (the nodes are what is cached).  On a roots-only dataset every
+ * pass over the data).  cp2_dataset_build_cached caches what the dataset keeps: every node, or -- 1/32 of that -- the compact
+ * layers, or the roots; a later run loads them and, compact, proves from the touched blocks alone.  On a roots-only dataset every
  * cp2_proof_input_generate costs one slot rebuild, and the batch / export calls one per slot: to get the proof inputs of ALL
  * slots use the streamed build. */
 int cp2_set_keep_trees(cp2_ctx* ctx, int mode);
@@ -228,7 +229,9 @@ typedef struct cp2_dataset cp2_dataset;
 /* Builds the trees of slots [first_slot, first_slot + n_local) on this GPU.  For a single GPU pass
  * first_slot = 0, n_local = cfg->n_slots.  */
 int cp2_dataset_build(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local, cp2_dataset** out);
-/* cp2_dataset_build with the slot trees cached in `cache_path` (read when present and matching, else built and written) */
+/* cp2_dataset_build with what it keeps of the slot trees (cp2_set_keep_trees: every node, the compact layers, or the roots) cached
+ * in `cache_path`: read when present, intact and matching the configuration -- and, for the SlotFile source, slot files of
+ * unchanged size and mtime --, else built and written (to a temporary name, then renamed) */
 int cp2_dataset_build_cached(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local,
                              const char* cache_path, cp2_dataset** out);
 void cp2_dataset_free(cp2_dataset* ds);

@@ -383,6 +383,58 @@ def test_cli_twin_roots_only(pkg, golden, tmp_path, mode, marker):
     assert open(out).read() == golden("input_params_default.json")
 
 
+@pytest.mark.parametrize("mode", [2, 0])
+def test_compact_and_roots_only_datasets_are_cached_as_what_they_keep(pkg, oracle, golden, tmp_path, mode):
+    """cp2_dataset_build_cached on a compact (roots-only) dataset writes the compact layers (the roots) -- 1/32 (1/2^21) of the
+    tree cache -- and a later build loads them instead of hashing any slot: same proof inputs; a damaged cache or changed slot
+    files mean rebuild, never stale layers.  Through the cli twin as well (CODEX_P2_CACHE + CODEX_P2_KEEP_TREES)."""
+    C, P = oracle
+    m0 = golden("proof_inputs.json")["inputs"]["testmain_small"]
+    c = m0["config"]
+    want = golden("input_testmain_small.json")
+    ctx = pkg.Context(0)
+    ctx.set_keep_trees(mode)
+    cache = str(tmp_path / "kept.cp2")
+    a = ctx.dataset(pkg.make_config(**c), cache=cache)
+    assert a.tree_mode == mode and a.proof_input(m0["slotIndex"], m0["entropy"]).json() == want
+    size = os.path.getsize(cache)
+    full_nodes = c["nSlots"] * (2 * c["nCells"] - 1) * 32
+    assert size < (full_nodes / 20 if mode == 2 else 1024)         # compact: 1/32 of the nodes (+ header); roots: 32 bytes per slot
+    b = ctx.dataset(pkg.make_config(**c), cache=cache)             # loaded
+    assert b.tree_mode == mode and b.proof_input(m0["slotIndex"], m0["entropy"]).json() == want
+    assert np.array_equal(a.local_roots(), b.local_roots())
+    a.free()
+    b.free()
+    raw = bytearray(open(cache, "rb").read())                      # one flipped payload byte: checksum mismatch -> rebuilt and rewritten
+    raw[-7] ^= 0x20
+    open(cache, "wb").write(bytes(raw))
+    d = ctx.dataset(pkg.make_config(**c), cache=cache)
+    assert d.proof_input(m0["slotIndex"], m0["entropy"]).json() == want and open(cache, "rb").read() != bytes(raw)
+    d.free()
+    assert not [f for f in os.listdir(tmp_path) if ".tmp." in f]
+    # SlotFile source: a cache is keyed on size + mtime of every slot file
+    base = str(tmp_path / "slot")
+    for k in range(c["nSlots"]):
+        C.gen_fake_cells(C.slot_seed(c["seed"], k), 0, c["nCells"], c["cellSize"]).tofile("%s%d.dat" % (base, k))
+    fcfg = pkg.make_config(file=base, **{k: v for k, v in c.items() if k != "seed"})
+    fcache = str(tmp_path / "kept_files.cp2")
+    assert ctx.dataset(fcfg, cache=fcache).proof_input(m0["slotIndex"], m0["entropy"]).json() == want
+    assert ctx.dataset(fcfg, cache=fcache).proof_input(m0["slotIndex"], m0["entropy"]).json() == want          # loaded
+    C.gen_fake_cells(C.slot_seed(999, 3), 0, c["nCells"], c["cellSize"]).tofile(base + "3.dat")                # new contents for slot 3
+    changed = ctx.dataset(fcfg, cache=fcache).proof_input(m0["slotIndex"], m0["entropy"]).json()
+    ctx.set_keep_trees(1)
+    assert changed == ctx.dataset(fcfg).proof_input(m0["slotIndex"], m0["entropy"]).json() != want
+    ctx.close()
+    # the drop-in: first run builds and writes, second run loads (no slot is hashed again)
+    args = [pkg.CLI_PATH, "-d:16", "-N=32", "-c128", "-b:4096", "-n=10", "-e:1234567", "-S12345", "-s=5", "-K:256", "-i3", "-F:bn254", "-H=poseidon2"]
+    env = dict(os.environ, CP2_TRACE="1", CODEX_P2_KEEP_TREES=str(mode), CODEX_P2_CACHE=str(tmp_path / "cli.cp2"))
+    for marker in ("built and written to the cache", "loaded from the cache"):
+        out = str(tmp_path / "cli.json")
+        r = subprocess.run(args + ["-o=" + out], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0 and marker in r.stderr, r.stderr
+        assert open(out).read() == want
+
+
 def test_compact_dataset_notices_changed_slot_data(pkg, oracle, tmp_path):
     """Compact datasets re-hash the touched blocks of the slot FILE at proof time: data that changed since the build no longer
     hashes to the stored block root -- an I/O error naming block and slot, never a proof over mixed data."""
@@ -422,6 +474,20 @@ def test_bigslots_roots_only_vs_oracle_fixture(pkg, golden):
         for slot in ((0, 7) if mode == 0 else range(8)):
             text = ds.proof_input(slot, g["entropy"]).json()
             assert tsha(text) == g["inputs"][str(slot)]["json_sha256"], (mode, slot)
+        ds.free()
+    # the compact layers of the 8 slots cached (64 MiB against 2 GiB of nodes): the second build hashes nothing
+    import tempfile
+    import time
+    with tempfile.TemporaryDirectory() as td:
+        ctx.set_keep_trees(2)
+        cache = os.path.join(td, "big.cp2")
+        ctx.dataset(pkg.make_config(**g["config"]), cache=cache).free()
+        assert os.path.getsize(cache) < 80 << 20
+        t0 = time.perf_counter()
+        ds = ctx.dataset(pkg.make_config(**g["config"]), cache=cache)
+        t_load = time.perf_counter() - t0
+        assert t_load < 0.6 and hexroot(ds.root()) == g["dataset_root_hex"]          # a rebuild takes 1.6 s
+        assert tsha(ds.proof_input(5, g["entropy"]).json()) == g["inputs"]["5"]["json_sha256"]
         ds.free()
     ctx.set_keep_trees(0)
     # streamed and roots-only: every input.json of the 8 slots in one pass, nodes of at most 8 slots alive
