@@ -764,22 +764,50 @@ def big_slots_leg(torch, dist, ctx, pkg, dev, rank, world):
     elif err:
         raise err
     dt = time.perf_counter() - t0
-    backend.dataset.free()
-    ctx.trim()
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     import hashlib
-    perms = n_slots * (35 * n_cells - 1) + (n_slots - 1) * world + 200 * world
-    root_hex = root.tobytes()[::-1].hex()
     gold = None
     try:
         gold = json.load(open(os.path.join(ROOT, "tests", "golden", "bigslots.json")))
     except Exception:
         pass
+    # what a proof input costs once the trees exist, by what is kept of them (one rank is enough): every node resident, or compact
+    # (block roots and up, 1/32 of the nodes: the bottom of each path from the touched blocks)
+    latency = None
+    if world == 1:
+        def median_ms(ds_, slots):
+            ts = []
+            for s_ in slots:
+                a = time.perf_counter()
+                ds_.proof_input(s_, 7654321)
+                ts.append((time.perf_counter() - a) * 1e3)
+            return round(sorted(ts)[len(ts) // 2], 3)
+        full_ms = median_ms(backend.dataset, range(n_slots))
+        backend.dataset.free()
+        ctx.set_keep_trees(2)
+        try:
+            a = time.perf_counter()
+            cds = ctx.dataset(cfg)
+            build_s = time.perf_counter() - a
+            ok = all(hashlib.sha256(cds.proof_input(s_, 1234567).json().encode()).hexdigest() == gold["inputs"][str(s_)]["json_sha256"]
+                     for s_ in (0, 5)) if gold else None
+            latency = {"every_node_resident_ms": full_ms, "compact_ms": median_ms(cds, range(n_slots)), "compact_build_s": round(build_s, 3),
+                       "device_bytes_per_slot": {"every_node_resident": 2 * n_cells * 32, "compact": 2 * (n_cells // 32) * 32},
+                       "compact_input_json_equals_oracle_fixture": ok,
+                       "note": "median wall time of cp2_proof_input_generate over the 8 slots (100 samples each), new entropy, trees already built"}
+            cds.free()
+        finally:
+            ctx.set_keep_trees(-1)
+    else:
+        backend.dataset.free()
+    ctx.trim()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    perms = n_slots * (35 * n_cells - 1) + (n_slots - 1) * world + 200 * world
+    root_hex = root.tobytes()[::-1].hex()
     return {"dataset_big_slots": {"workload": "configs[4] shape, SURVEY.md 8(d)'s other scale-down: 8 slots x 2^22 cells x 2048 B (nominal 8 GiB slots) sharded "
                                               "over %d GPU(s) (%d slots on rank 0), one exchange of slot roots, dataset tree, one proof input per rank" % (world, count),
                                   "scaling": "strong", "seconds": round(dt, 4), "roots_and_dataset_tree_s": round(t1 - t0, 4),
                                   "perms_per_s": perms / dt, "GB_per_s_hashed": round(n_slots * n_cells * 2048 / dt / 1e9, 2),
-                                  "dataset_root_hex": root_hex,
+                                  "dataset_root_hex": root_hex, "proof_input_latency": latency,
                                   "equals_oracle_fixture": (root_hex == gold["dataset_root_hex"] and
                                                             hashlib.sha256(text.encode()).hexdigest() == gold["inputs"][str(first)]["json_sha256"]) if gold else None}}
 
