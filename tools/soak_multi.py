@@ -43,11 +43,11 @@ while time.time() - t0 < budget:
     m.set_policy(int(rng.choice([pkg.GATHER_AUTO, pkg.GATHER_HOST])), min_cells)
     split = int(rng.choice([2, 4, 8] if UNITS else [0, 0, 1, 2, 4]))   # choose / whole slots only / every slot cut into 2, 4 (8) units
     m.set_split(split)
-    keep = int(rng.choice([-1, -1, 0]))                        # now and then roots-only datasets (trees dropped, rebuilt per proved slot)
+    keep = int(rng.choice([-1, -1, 0, 2]))                     # now and then roots-only / compact datasets
     for i in range(m.count):
         m.ctx(i).set_keep_trees(keep)
-    single.set_keep_trees(int(rng.choice([-1, 0])))
-    roots_only += keep == 0
+    single.set_keep_trees(int(rng.choice([-1, 0, 2])))
+    roots_only += keep in (0, 2)
     use_file = (it % 5 == 0) and (cs & 3) == 0 and not big
     cc = dict(c)
     if use_file:
