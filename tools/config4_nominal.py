@@ -41,8 +41,8 @@ def oracle_side():
 th = threading.Thread(target=oracle_side)
 th.start()
 free0, _ = torch.cuda.mem_get_info()
-if n_slots * 0.2501 + 6 < free0 / 2**30 * 0.9:
-    ctx.set_keep_trees(0)                      # a rehearsal whose trees WOULD fit: roots only by request
+if n_slots * 0.2501 + 8 < free0 / 2**30 * 0.9:
+    ctx.set_keep_trees(2)                      # a rehearsal whose trees WOULD fit: compact by request (the full run gets it by itself)
 t0 = time.time()
 ds = ctx.dataset_streamed(cfg, entropy, threads=threads, group_slots=1)
 t1 = time.time()
@@ -51,7 +51,7 @@ nbytes = ds.export_streamed(None, threads=threads)
 t2 = time.time()
 free1, _ = torch.cuda.mem_get_info()
 perms = n_slots * (35 * (1 << 22) - 1) + 200 * n_slots
-print("streamed roots-only: %d slots x 8 GiB (%.1f TiB), bodies of all slots in %.1f s + heads %.2f s: %.2f witnesses/s with JSON (%.2f GB of text), %.3e perm/s; "
+print("streamed, trees dropped batch by batch: %d slots x 8 GiB (%.1f TiB), bodies of all slots in %.1f s + heads %.2f s: %.2f witnesses/s with JSON (%.2f GB of text), %.3e perm/s; "
       "device memory in use after the build %.2f GiB" % (n_slots, n_slots / 128, t1 - t0, t2 - t1, n_slots / (t2 - t0), nbytes / 1e9, perms / (t2 - t0), (free0 - free1) / 2**30), flush=True)
 roots = ds.local_roots()
 gold = json.load(open(os.path.join(ROOT, "tests", "golden", "bigslots.json")))
@@ -72,7 +72,14 @@ for s in check_slots:
     if ok_circuit is None:
         ok_circuit = bool(P.circuit_check(prf, c))
 print("circuit-side checker on slot %d: %s" % (check_slots[0], ok_circuit), flush=True)
+# the dataset stays usable: a proof input for ANOTHER entropy, from what it kept of the trees
+lat = []
+for s_ in (1, n_slots // 3, n_slots - 1):
+    t = time.time()
+    ds.proof_input(s_, 7654321)
+    lat.append(round(time.time() - t, 4))
+print("the dataset keeps: %s; proof inputs for a new entropy afterwards: %s s" % ({1: "every node", 2: "block roots and up (compact)", 0: "roots only"}[ds.tree_mode], lat), flush=True)
 print(json.dumps({"n_slots": n_slots, "TiB_hashed": n_slots / 128, "build_with_bodies_s": round(t1 - t0, 1), "heads_s": round(t2 - t1, 2), "json_GB": nbytes / 1e9,
                   "witnesses_per_s_with_json": n_slots / (t2 - t0), "perms_per_s": perms / (t2 - t0), "device_GiB_in_use_after_build": round((free0 - free1) / 2**30, 2),
-                  "checks": {"slots_0_7_vs_fixture": ok_fixture, "dataset_tree_vs_oracle": ok_tree, "input_json_vs_oracle": ok_json, "circuit_check": ok_circuit}}))
+                  "tree_mode": ds.tree_mode, "new_entropy_proof_input_s": lat, "checks": {"slots_0_7_vs_fixture": ok_fixture, "dataset_tree_vs_oracle": ok_tree, "input_json_vs_oracle": ok_json, "circuit_check": ok_circuit}}))
 sys.exit(0 if (ok_fixture and ok_tree and all(ok_json.values()) and ok_circuit) else 1)
