@@ -273,7 +273,11 @@ static int dataset_tree_mode(cp2_ctx* ctx, const cp2_config& c, uint64_t n_local
   if (mode >= 0) return mode;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 1; }
-  const unsigned __int128 room = (unsigned __int128)free_b * 9 / 10, slack = (unsigned __int128)8 << 30;
+  // slack: the builders' staging (two chunks of at most 2 GiB, never more than the data itself), the node batch in flight (about
+  // 2 GiB for the transient modes) and 1 GiB of headroom
+  const unsigned __int128 data = (unsigned __int128)n_local * c.n_cells * c.cell_size;
+  const unsigned __int128 chunk = std::min<unsigned __int128>(data, (unsigned __int128)2 << 30);
+  const unsigned __int128 room = (unsigned __int128)free_b * 9 / 10, slack = 3 * chunk + ((unsigned __int128)1 << 30);
   if ((unsigned __int128)trees_node_bytes(1, c.cell_size, c.block_size, c.n_cells) * n_local + slack <= room) return 1;
   if ((unsigned __int128)compact_bytes(c, 1) * n_local + slack <= room) return 2;
   return 0;
