@@ -119,24 +119,33 @@ struct cp2_multi {
 
 // device indices from the environment: CODEX_P2_GPUS = "<count>" (the first <count> visible devices) or a comma-separated
 // list of indices ("0,2,3"; "0,0" = two contexts on device 0; "2," = device 2 only)
-static bool devices_from_env(int visible, std::vector<int>& out) {
+// returns 1 when the variable named devices, 0 when it is unset, -1 when it is set to something that is not a count or an index list
+static int devices_from_env(int visible, std::vector<int>& out) {
   const char* e = std::getenv("CODEX_P2_GPUS");
-  if (!e || !*e) return false;
+  if (!e || !*e) return 0;
   const std::string s(e);
+  auto number = [](const std::string& t, long* v) {
+    if (t.empty() || t.size() > 6 || t.find_first_not_of("0123456789") != std::string::npos) return false;
+    *v = std::strtol(t.c_str(), nullptr, 10);
+    return true;
+  };
+  long n = 0;
   if (s.find(',') == std::string::npos) {
-    const long n = std::strtol(e, nullptr, 10);
-    if (n < 1) return false;
+    if (!number(s, &n) || n < 1) return -1;
     for (int d = 0; d < std::min<long>(n, visible); ++d) out.push_back(d);
-    return !out.empty();
+    return 1;
   }
   size_t at = 0;
   while (at < s.size()) {
     size_t c = s.find(',', at);
     if (c == std::string::npos) c = s.size();
-    if (c > at) out.push_back((int)std::strtol(s.substr(at, c - at).c_str(), nullptr, 10));
+    if (c > at) {
+      if (!number(s.substr(at, c - at), &n)) return -1;
+      out.push_back((int)n);
+    }
     at = c + 1;
   }
-  return !out.empty();
+  return out.empty() ? -1 : 1;
 }
 
 extern "C" int cp2_multi_init(const int* devices, int n_dev, cp2_multi** out) try {
@@ -147,9 +156,11 @@ extern "C" int cp2_multi_init(const int* devices, int n_dev, cp2_multi** out) tr
   if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) { (void)hipGetLastError(); return CP2_ERR_NO_DEVICE; }
   trace.lap("HIP runtime init (device count)");
   std::unique_ptr<cp2_multi> m(new cp2_multi());
+  const int from_env = n_dev > 0 ? 0 : devices_from_env(visible, m->devices);
+  if (from_env < 0) return CP2_ERR_INVALID;      // CODEX_P2_GPUS is set but is neither "<count>" nor an index list: not guessed at
   if (n_dev > 0) {
     m->devices.assign(devices, devices + n_dev);
-  } else if (!devices_from_env(visible, m->devices)) {
+  } else if (from_env == 0) {
     for (int d = 0; d < visible; ++d) {          // every visible gfx950 device
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, d) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) m->devices.push_back(d);

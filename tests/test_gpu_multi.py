@@ -261,6 +261,10 @@ def test_cli_twin_spreads_over_contexts_without_a_new_flag(pkg, golden, tmp_path
     r = subprocess.run([pkg.CLI_PATH] + args + ["--output=" + str(tmp_path / "x.json")], capture_output=True, text=True, timeout=60,
                        env=dict(os.environ, CODEX_P2_GPUS="7,"))
     assert r.returncode != 0 and "no usable gfx950 HIP device" in r.stderr      # a device that is not there: loud, no fallback
+    for bad in ("two", "0,x", "-1", "0;1"):
+        r = subprocess.run([pkg.CLI_PATH] + args + ["--output=" + str(tmp_path / "x.json")], capture_output=True, text=True, timeout=60,
+                           env=dict(os.environ, CODEX_P2_GPUS=bad))
+        assert r.returncode != 0 and "invalid argument" in r.stderr, (bad, r.stderr)     # a malformed list is refused, not guessed at
 
 
 def test_cli_twin_reads_slot_files_whole_and_by_units(pkg, oracle, golden, tmp_path):
