@@ -146,6 +146,7 @@ def load_library():
         "cp2_multi_set_split": (i32, [vp, ctypes.c_int64]),
         "cp2_multi_dataset_units_per_slot": (u64, [vp]),
         "cp2_shard_range": (None, [u64, i32, i32, ctypes.POINTER(u64), ctypes.POINTER(u64)]),
+        "cp2_multi_plan": (i32, [ctypes.POINTER(Config), i32, u64, ctypes.c_int64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(u64)]),
         "cp2_multi_dataset_build": (i32, [vp, ctypes.POINTER(Config), pvp]),
         "cp2_multi_dataset_build_cached": (i32, [vp, ctypes.POINTER(Config), cp, pvp]),
         "cp2_multi_dataset_build_streamed": (i32, [vp, ctypes.POINTER(Config), vp, i32, sz, pvp]),
@@ -601,6 +602,16 @@ def shard_range(n_items, rank, world):
     a, b = ctypes.c_uint64(), ctypes.c_uint64()
     L.cp2_shard_range(n_items, rank, world, ctypes.byref(a), ctypes.byref(b))
     return a.value, b.value
+
+
+def multi_plan(cfg, n_devices, min_cells_per_device=0, units_per_slot=0):
+    """cp2_multi_plan: (number of shards, units per slot) cp2_multi_dataset_build would use -- host-only arithmetic."""
+    L = load_library()
+    w, u = ctypes.c_int(), ctypes.c_uint64()
+    st = L.cp2_multi_plan(ctypes.byref(cfg), n_devices, min_cells_per_device, units_per_slot, ctypes.byref(w), ctypes.byref(u))
+    if st != CP2_OK:
+        raise CodexP2Error(st, "cp2_multi_plan", L.cp2_strerror(st).decode())
+    return w.value, u.value
 
 
 class _BorrowedContext(Context):

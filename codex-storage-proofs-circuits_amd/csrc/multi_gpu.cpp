@@ -440,6 +440,18 @@ uint64_t choose_units_per_slot(const cp2_config& c, uint64_t world, int64_t forc
   return best;
 }
 
+// How a dataset is cut over `n_dev` devices: how many of them get a shard -- every device when there is a residency of hashing
+// for each, fewer for small datasets -- and into how many units every slot is cut (1: whole slots).  Pure arithmetic.
+void plan_shards(const cp2_config& c, size_t n_dev, uint64_t min_cells_per_device, int64_t split, uint64_t* world_out, uint64_t* units_out) {
+  const uint64_t min_cells = min_cells_per_device ? min_cells_per_device : RESIDENCY_CELLS;
+  const unsigned __int128 total_cells = (unsigned __int128)c.n_slots * c.n_cells;
+  uint64_t world = (uint64_t)std::min<unsigned __int128>((total_cells + min_cells - 1) / min_cells, n_dev);
+  world = std::max<uint64_t>(1, world);
+  const uint64_t S = split == 1 ? 1 : choose_units_per_slot(c, world, split);
+  *world_out = std::min<uint64_t>(world, c.n_slots * S);
+  *units_out = S;
+}
+
 enum class BuildKind { Plain, Streamed, Cached };
 
 int multi_build(cp2_multi* m, const cp2_config* cfg, BuildKind kind, const uint8_t* entropy, int threads, size_t group_slots,
@@ -448,15 +460,9 @@ int multi_build(cp2_multi* m, const cp2_config* cfg, BuildKind kind, const uint8
   *out = nullptr;
   m->err.clear();
   if (cfg->n_slots == 0 || cfg->max_depth < 0 || cfg->max_log2_nslots < 0) return CP2_ERR_INVALID;
-  // how many devices get a shard: every device when there is a residency of hashing for each, fewer for small datasets
-  const uint64_t min_cells = m->min_cells ? m->min_cells : RESIDENCY_CELLS;
-  const unsigned __int128 total_cells = (unsigned __int128)cfg->n_slots * cfg->n_cells;
-  uint64_t world = (uint64_t)std::min<unsigned __int128>((total_cells + min_cells - 1) / min_cells, m->devices.size());
-  world = std::max<uint64_t>(1, world);
   // whole slots or units: streamed and cached builds keep whole slots (their per-slot state lives in a cp2_dataset)
-  uint64_t S = 1;
-  if (kind == BuildKind::Plain && m->split != 1) S = choose_units_per_slot(*cfg, world, m->split);
-  world = std::min<uint64_t>(world, cfg->n_slots * S);
+  uint64_t world = 1, S = 1;
+  plan_shards(*cfg, m->devices.size(), m->min_cells, kind == BuildKind::Plain ? m->split : 1, &world, &S);
   std::unique_ptr<cp2_multi_dataset> mds(new cp2_multi_dataset());
   mds->m = m;
   mds->cfg = *cfg;
@@ -587,6 +593,20 @@ int units_proof_input(cp2_multi_dataset* mds, uint64_t slot, const uint8_t entro
 }
 
 }  // namespace
+
+// the plan cp2_multi_dataset_build would follow, without a device (host-only arithmetic)
+extern "C" int cp2_multi_plan(const cp2_config* cfg, int n_devices, uint64_t min_cells_per_device, int64_t units_per_slot, int* n_shards,
+                              uint64_t* units_per_slot_out) try {
+  if (!cfg || n_devices < 1 || cfg->n_slots == 0 || cfg->n_cells == 0 || units_per_slot < 0 ||
+      (units_per_slot > 1 && !is_pow2((uint64_t)units_per_slot))) return CP2_ERR_INVALID;
+  uint64_t world = 1, S = 1;
+  plan_shards(*cfg, (size_t)n_devices, min_cells_per_device, units_per_slot, &world, &S);
+  if (n_shards) *n_shards = (int)world;
+  if (units_per_slot_out) *units_per_slot_out = S;
+  return CP2_OK;
+} catch (...) {
+  return CP2_ERR_INVALID;
+}
 
 extern "C" int cp2_multi_dataset_build(cp2_multi* m, const cp2_config* cfg, cp2_multi_dataset** out) try {
   return multi_build(m, cfg, BuildKind::Plain, nullptr, 1, 0, nullptr, out);

@@ -361,6 +361,11 @@ int cp2_multi_set_policy(cp2_multi* m, int gather, uint64_t min_cells_per_device
 int cp2_multi_set_split(cp2_multi* m, int64_t units_per_slot);
 /* the split rule: contiguous ranges, the first (n_items mod world) ranks hold one item more */
 void cp2_shard_range(uint64_t n_items, int rank, int world, uint64_t* first, uint64_t* count);
+/* The plan cp2_multi_dataset_build follows for `cfg` on `n_devices` devices (host-only arithmetic, no GPU needed): how many of
+ * them get a shard and into how many units every slot is cut (1: whole slots).  min_cells_per_device / units_per_slot as for
+ * cp2_multi_set_policy / cp2_multi_set_split (0 = the defaults). */
+int cp2_multi_plan(const cp2_config* cfg, int n_devices, uint64_t min_cells_per_device, int64_t units_per_slot, int* n_shards,
+                   uint64_t* units_per_slot_out);
 /* cp2_dataset_build / _build_cached / _build_streamed for ALL cfg->n_slots slots over the devices of `m`, including the
  * exchange and the dataset tree on every device.  Cached: shard i of n uses "<cache_path>.shard<i>of<n>" (one shard: the path
  * itself).  Streamed: `threads` formatting threads in total, divided over the shards. */

@@ -46,6 +46,13 @@ int main(void) {
       cp2_dataset_local_roots_dev(NULL) != NULL || cp2_dataset_ctx(NULL) != NULL || cp2_dataset_range(NULL, NULL, NULL) != CP2_ERR_INVALID) return 17;
   if (cp2_set_keep_trees(NULL, 0) != CP2_ERR_INVALID || cp2_dataset_keeps_trees(NULL) != 0 || cp2_multi_set_split(NULL, 2) != CP2_ERR_INVALID ||
       cp2_multi_dataset_units_per_slot(NULL) != 0 || cp2_slot_trees_build_fake_units(NULL, 1, 2, 0, 1, 64, 128, 4, NULL) != CP2_ERR_INVALID) return 18;
+  {
+    int shards = 0;
+    uint64_t units = 0;
+    cfg.cell_size = 2048; cfg.block_size = 65536; cfg.n_slots = 11; cfg.n_cells = 1u << 22;
+    if (cp2_multi_plan(&cfg, 8, 0, 0, &shards, &units) != CP2_OK || shards != 8 || units != 8) return 19;   /* 88 units, 11 per device */
+    if (cp2_multi_plan(NULL, 8, 0, 0, &shards, &units) != CP2_ERR_INVALID) return 20;
+  }
   printf("c abi ok\n");
   return 0;
 }

@@ -94,6 +94,30 @@ def test_shard_ranges_cover_everything(entry):
             assert got == list(range(n))
 
 
+def test_multi_gpu_plan_is_what_the_design_says(pkg):
+    """cp2_multi_plan (host-only): small datasets stay on one device; many slots are dealt out whole; FEW, LARGE slots are cut
+    into units until the busiest device is within 6 % of its share."""
+    big = dict(maxDepth=32, cellSize=2048, blockSize=65536, nSamples=100, seed=1)
+    plan = lambda n_dev, **kw: pkg.multi_plan(pkg.make_config(**dict(big, **kw)), n_dev)   # noqa: E731
+    assert plan(8, maxLog2NSlots=8, nSlots=11, nCells=512) == (1, 1)                      # workflow/params.sh: 5632 cells, one context
+    assert plan(8, maxLog2NSlots=15, nSlots=32768, nCells=1 << 12) == (8, 1)              # config 5's scale-down: 4096 whole slots each
+    assert plan(8, maxLog2NSlots=15, nSlots=32767, nCells=1 << 12) == (8, 1)              # 4096 + 7 x 4095 ... : within 6 %
+    assert plan(8, maxLog2NSlots=4, nSlots=11, nCells=1 << 22) == (8, 8)                  # 11 slots of 8 GiB: 88 units, 11 each
+    assert plan(8, maxLog2NSlots=1, nSlots=1, nCells=1 << 26) == (8, 8)                   # ONE 128 GiB slot: an eighth each
+    assert plan(3, maxLog2NSlots=3, nSlots=8, nCells=1 << 22) == (3, 4)                   # 32 units: 11 / 11 / 10
+    assert plan(2, maxLog2NSlots=3, nSlots=8, nCells=1 << 22) == (2, 1)                   # 4 + 4 whole slots
+    assert plan(8, maxLog2NSlots=3, nSlots=3, nCells=1 << 17) == (2, 2)                   # 393 216 cells: two residencies, 6 units: 3 each
+    cfg = pkg.make_config(**dict(big, maxLog2NSlots=4, nSlots=11, nCells=1 << 22))
+    assert pkg.multi_plan(cfg, 8, units_per_slot=1) == (8, 1)                             # whole slots only, by request: 2 2 2 1 1 1 1 1
+    assert pkg.multi_plan(cfg, 8, min_cells_per_device=1 << 40) == (1, 1)
+    odd = pkg.make_config(**dict(big, maxLog2NSlots=4, nSlots=11, nCells=96, blockSize=2048 * 3))
+    assert pkg.multi_plan(odd, 8, min_cells_per_device=1)[1] == 1                         # not a power-of-two geometry: never cut
+    with pytest.raises(pkg.CodexP2Error):
+        pkg.multi_plan(cfg, 0)
+    with pytest.raises(pkg.CodexP2Error):
+        pkg.multi_plan(cfg, 8, units_per_slot=3)
+
+
 def test_multi_handle_fails_loudly_without_a_gpu(pkg):
     """cp2_multi_init: no device, no handle (no CPU fallback behind the multi-GPU entry points either)."""
     if _have_gpu():
