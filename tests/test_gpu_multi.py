@@ -599,6 +599,38 @@ def test_units_from_slot_files_and_one_slot_over_several_contexts(pkg, oracle, t
     m.close()
 
 
+def test_one_128gib_slot_over_eight_contexts(pkg, oracle):
+    """"within one very large slot (2^26+ cells) the same scheme applies one level down".  ONE slot of 2^26 cells
+    (128 GiB, generated and hashed on the device) over eight contexts -- an eighth of the slot each, unit roots exchanged, the
+    three upper layers and the (singleton) dataset tree built once -- against the same slot built whole by one context, and the
+    proof input through the circuit-side checker."""
+    _, P = oracle
+    c = dict(maxDepth=32, maxLog2NSlots=1, cellSize=2048, blockSize=65536, nSlots=1, nCells=1 << 26, nSamples=20, seed=2026)
+    cfg = pkg.make_config(**c)
+    m = pkg.Multi([0] * 8)
+    ds = m.dataset(cfg)
+    assert ds.units_per_slot == 8 and [(f, k) for _, f, k in ds.shards()] == [(i, 1) for i in range(8)]
+    text = ds.proof_input(0, 31415926).json()
+    root, droot = ds.slot_roots()[0].copy(), ds.root().copy()
+    ds.free()
+    m.close()
+    ctx = pkg.Context(0)
+    ctx.set_keep_trees(2)                                          # compact: 128 MiB kept of the 4 GiB of nodes
+    whole = ctx.dataset(cfg)
+    assert np.array_equal(whole.local_roots()[0], root) and np.array_equal(whole.root(), droot)
+    pi = whole.proof_input(0, 31415926)
+    assert pi.json() == text
+    to_int = lambda a: int.from_bytes(np.asarray(a, dtype=np.uint8).tobytes(), "little")   # noqa: E731
+    d, sroot, e = pi.roots()
+    prf = {"dataSetRoot": to_int(d), "entropy": to_int(e), "nCells": c["nCells"], "nSlots": 1, "slotIndex": 0, "slotRoot": to_int(sroot),
+           "slotProof": {"merklePath": [to_int(x) for x in pi.slot_proof()]},
+           "proofInputs": [{"cellData": pi.cell_data()[i].tobytes(), "merkleProof": {"merklePath": [to_int(x) for x in pi.merkle_paths()[i]]}}
+                           for i in range(c["nSamples"])]}
+    assert P.circuit_check(prf, c)
+    whole.free()
+    ctx.close()
+
+
 # ---- SURVEY.md 8(d), config 5's other stated scale-down: several slots at the nominal 8 GiB slot size ------------------
 def _big(golden):
     try:
