@@ -711,7 +711,7 @@ extern "C" int cp2_slot_trees_save(cp2_slot_trees* t, const char* path) try {
   h.n_nodes = t->nodes.bytes / 32;
   const size_t total = t->nodes.bytes;
   const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid());
-  const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_NOFOLLOW | O_CLOEXEC, 0644);
   if (fd < 0) { ctx->err = "cannot create " + tmp; return CP2_ERR_IO; }
   struct FdGuard { int fd; std::string tmp; bool keep = false; ~FdGuard() { if (fd >= 0) close(fd); if (!keep) std::remove(tmp.c_str()); } } guard{fd, tmp};
   const off_t data_off = (off_t)(sizeof h + h.file_base_len + stamps.size() * 8);
@@ -903,7 +903,7 @@ int cp2i::kept_save(cp2_ctx* ctx, const char* path, const KeptMeta& m, const voi
   h.n_stamps = stamps.size() / 2;
   h.payload_bytes = bytes;
   const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid());
-  const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_NOFOLLOW | O_CLOEXEC, 0644);
   if (fd < 0) { ctx->err = "cannot create " + tmp; return CP2_ERR_IO; }
   struct FdGuard { int fd; std::string tmp; bool keep = false; ~FdGuard() { if (fd >= 0) close(fd); if (!keep) std::remove(tmp.c_str()); } } guard{fd, tmp};
   off_t off = (off_t)sizeof h;
