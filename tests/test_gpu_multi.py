@@ -135,6 +135,23 @@ def test_multi_argument_checks(pkg, ctx):
     m.close()
 
 
+def test_eight_shards_at_config5_scale_down_vs_oracle_fixture(pkg, golden):
+    """The 8-GPU split itself -- 32 768 slots x 2^12 cells, eight shards of 4096 slots, eight host threads and contexts -- on the
+    one device a test box has: dataset root as every shard computed it, input.json on the edges of the 8-way split."""
+    g = golden("config5.json").get("scaled")
+    if not g:
+        pytest.skip("config5.json has no `scaled` fixture")
+    m = pkg.Multi([0] * 8)
+    ds = m.dataset(pkg.make_config(**g["config"]))
+    assert [k for _, _, k in ds.shards()] == [4096] * 8 and ds.units_per_slot == 1
+    assert sha(ds.slot_roots()) == g["slot_roots_sha256"]
+    assert all(hexroot(ds.shard_root(i)) == g["dataset_root_hex"] for i in range(8))
+    for slot in (0, 4095, 4096, 16383, 28672, 32767):
+        assert tsha(ds.proof_input(slot, g["entropy"]).json()) == g["inputs"][str(slot)]["json_sha256"], slot
+    ds.free()
+    m.close()
+
+
 def test_forced_rccl_on_a_repeated_device_is_refused_with_a_reason(pkg, golden):
     c = golden("config5.json")["cheap"]["config"]
     m = pkg.Multi([0, 0])
