@@ -686,69 +686,96 @@ static int host_cells_global(cp2_slot_trees* t, const uint64_t* g, size_t n, uin
 
 static void fill_slot_proof(const cp2_dataset* ds, uint64_t slot_idx, std::vector<uint8_t>& out);
 
-// generateProofInput (gen_input/bn254.nim:53-74) on a COMPACT dataset: the top of every path -- block root to slot root -- is
-// gathered from the stored layers; the bottom -- cell to block root (merkleProof on the block's tree, blocks/bn254.nim:60-67) --
-// comes from the trees of the <= nSamples touched blocks, rebuilt here from the blocks' own cells (regenerated, or read from the
-// slot file) as a batch of one-block "slots" and checked against the stored block roots.  One slot per call; entropy canonical.
-static int compact_proof_input(cp2_dataset* ds, uint64_t slot, const uint8_t entropy[32], cp2_proof_input** out) {
+// generateProofInput (gen_input/bn254.nim:53-74) on a COMPACT dataset, for `n` slots in one pass: the top of every path -- block
+// root to slot root -- is gathered from the stored layers; the bottom -- cell to block root (merkleProof on the block's tree,
+// blocks/bn254.nim:60-67) -- comes from the trees of the touched blocks (at most nSamples per slot), rebuilt here from the blocks'
+// own cells (regenerated, or read from the slot files) as ONE batch of one-block "slots" and checked against the stored block
+// roots.  One sampling launch, one generator launch, one hash + layer pass and two gathers for all n slots (a node that proves
+// every slot it holds each period: 4096 slots cost one pass over 26 GB of touched blocks, not 4096 latency-bound little ones).
+// The caller chunks n so that the blocks fit the scratch; entropy canonical.
+static int compact_proof_inputs(cp2_dataset* ds, const uint64_t* slots, size_t n, const uint8_t entropy[32], cp2_proof_input** out) {
   cp2_ctx* ctx = ds->ctx;
   const cp2_config& c = ds->cfg;
   const size_t ns = c.n_samples, md = (size_t)c.max_depth, cs = c.cell_size, cpb = c.block_size / c.cell_size, nblocks = c.n_cells / cpb;
-  const size_t ls = (size_t)(slot - ds->first_slot);
   const size_t depth_b = layer_sizes_of(cpb).size() - 1, depth_t = ds->csizes.size() - 1;
   if (depth_b + depth_t > md) return CP2_ERR_INVALID;                                   // padMerkleProof assert, types.nim:29
   CP2_HIP(ctx, hipSetDevice(ctx->device));
-  const uint8_t* slot_root = &ds->dlayers[slot * 32];                                   // layer 0 of the dataset tree
-  std::vector<uint64_t> idx(ns);
-  if (ns) CP2_TRY(cp2_cell_indices(ctx, entropy, slot_root, c.n_cells, ns, idx.data()));   // sample/bn254.nim:16-27
-  std::vector<uint8_t> paths(ns * md * 32, 0), leaves(ns * 32), cells(ns * cs);
-  if (ns) {
+  const size_t total = n * ns;                                                          // (slot, counter) pairs = touched blocks
+  std::vector<uint64_t> idx(total);
+  if (total) {                                                                          // cellIndices, sample/bn254.nim:16-27, for all pairs at once
+    std::vector<uint8_t> felts(total * 96, 0), dig(total * 32);
+    for (size_t i = 0; i < n; ++i)
+      for (size_t k = 0; k < ns; ++k) {
+        uint8_t* f = &felts[(i * ns + k) * 96];
+        std::memcpy(f, entropy, 32);
+        std::memcpy(f + 32, &ds->dlayers[slots[i] * 32], 32);                           // the slot root: layer 0 of the dataset tree
+        const uint64_t counter = k + 1;
+        std::memcpy(f + 64, &counter, 8);
+      }
+    CP2_TRY(cp2_sponge2_felts_batch(ctx, felts.data(), 3, total, dig.data()));
+    for (size_t p = 0; p < total; ++p) {
+      uint64_t lo;
+      std::memcpy(&lo, &dig[32 * p], 8);                                                // extractLowBits, types/bn254.nim:47-59
+      idx[p] = lo & (c.n_cells - 1);
+    }
+  }
+  std::vector<uint8_t> paths(total * md * 32, 0), leaves(total * 32), cells(total * cs);
+  if (total) {
     // the cells of the touched blocks, block after block, in device scratch
-    const size_t n_bc = ns * cpb;
+    const size_t n_bc = total * cpb;
     DevBuf d_cells, d_list, d_rows, d_got;
     CP2_TRY(d_cells.scratch(ctx, n_bc * cs));
     std::vector<uint8_t> h_blocks;                                                       // SlotFile: read on the host first
     if (ds->from_file) {
       h_blocks.resize(n_bc * cs);
-      const std::string fname = slot_file_name(ds->file_base, slot);
-      const int fd = open(fname.c_str(), O_RDONLY);
-      if (fd < 0) { ctx->err = "cannot open " + fname; return CP2_ERR_IO; }
-      for (size_t i = 0; i < ns; ++i)
-        for (size_t j = 0; j < cpb; ++j) read_file_cell(fd, cs, (idx[i] / cpb) * cpb + j, &h_blocks[(i * cpb + j) * cs]);
-      close(fd);
+      for (size_t i = 0; i < n; ++i) {
+        const std::string fname = slot_file_name(ds->file_base, slots[i]);
+        const int fd = open(fname.c_str(), O_RDONLY);
+        if (fd < 0) { ctx->err = "cannot open " + fname; return CP2_ERR_IO; }
+        for (size_t k = 0; k < ns; ++k)
+          for (size_t j = 0; j < cpb; ++j) read_file_cell(fd, cs, (idx[i * ns + k] / cpb) * cpb + j, &h_blocks[((i * ns + k) * cpb + j) * cs]);
+        close(fd);
+      }
       CP2_HIP(ctx, hipMemcpyAsync(d_cells.p, h_blocks.data(), h_blocks.size(), hipMemcpyHostToDevice, ctx->stream));
     } else {
+      // the generator's list form over "global cells" of the local slots: g = local slot * nCells + cell, seed of local slot 0
       std::vector<uint64_t> list(n_bc);
-      for (size_t i = 0; i < ns; ++i)
-        for (size_t j = 0; j < cpb; ++j) list[i * cpb + j] = (idx[i] / cpb) * cpb + j;
+      for (size_t i = 0; i < n; ++i)
+        for (size_t k = 0; k < ns; ++k)
+          for (size_t j = 0; j < cpb; ++j)
+            list[(i * ns + k) * cpb + j] = (slots[i] - ds->first_slot) * c.n_cells + (idx[i * ns + k] / cpb) * cpb + j;
       CP2_TRY(d_list.scratch(ctx, n_bc * 8));
       CP2_HIP(ctx, hipMemcpyAsync(d_list.p, list.data(), n_bc * 8, hipMemcpyHostToDevice, ctx->stream));
-      CP2_HIP(ctx, cp2k::launch_gen_fake_cells(cp2_slot_seed(c.seed, slot), 0, 0, static_cast<const uint64_t*>(d_list.p), n_bc, cs, d_cells.p, ctx->stream));
+      CP2_HIP(ctx, cp2k::launch_gen_fake_cells(cp2_slot_seed(c.seed, ds->first_slot), c.n_cells, 0, static_cast<const uint64_t*>(d_list.p), n_bc, cs,
+                                               d_cells.p, ctx->stream));
       CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));                                   // `list` leaves scope below
     }
     // one-block "slots": hash the cells, build the block trees (the singleton layer on top of each is not used)
     cp2_slot_trees* mini = nullptr;
-    CP2_TRY(cp2_slot_trees_build_dev(ctx, d_cells.p, ns, cs, c.block_size, cpb, &mini));
+    CP2_TRY(cp2_slot_trees_build_dev(ctx, d_cells.p, total, cs, c.block_size, cpb, &mini));
     struct Mini { cp2_slot_trees* t; ~Mini() { cp2_slot_trees_free(t); } } mini_guard{mini};
-    // rows to gather: per sample the depth_b siblings inside its block, its leaf, the rebuilt block root (from `mini`), then the
+    // rows to gather: per pair the depth_b siblings inside its block, its leaf, the rebuilt block root (from `mini`), then the
     // depth_t siblings above the block and the stored block root (from the compact layers)
     const size_t per_m = depth_b + 2, per_c = depth_t + 1;
-    std::vector<uint64_t> rows_m(ns * per_m), rows_c(ns * per_c);
-    for (size_t i = 0; i < ns; ++i) {
-      const uint64_t in_block = idx[i] % cpb, b = idx[i] / cpb;
-      std::vector<uint64_t> r(depth_b + 1);
-      path_rows(mini, i, in_block, depth_b + 1, r.data());                               // block layers, then the singleton's (unused) entry
-      for (size_t d = 0; d < depth_b; ++d) rows_m[i * per_m + d] = r[d];
-      rows_m[i * per_m + depth_b] = i * cpb + in_block;                                  // the leaf: layer 0 of `mini`
-      rows_m[i * per_m + depth_b + 1] = mini->toff[0] + i;                               // the block root: layer 0 of its singleton tree
-      uint64_t k = b, m = nblocks;
-      for (size_t d = 0; d < depth_t; ++d) {                                             // merkleProof(bigTree, blockIdx), merkle.nim:21-42
-        const uint64_t sib = k ^ 1;
-        rows_c[i * per_c + d] = sib < m ? ds->coff[d] + ls * ds->csizes[d] + sib : NO_ROW;
-        k >>= 1;
-        m = (m + 1) >> 1;
+    std::vector<uint64_t> rows_m(total * per_m), rows_c(total * per_c), r(depth_b + 1);
+    for (size_t i = 0; i < n; ++i) {
+      const size_t ls = (size_t)(slots[i] - ds->first_slot);
+      for (size_t k = 0; k < ns; ++k) {
+        const size_t p = i * ns + k;
+        const uint64_t in_block = idx[p] % cpb, b = idx[p] / cpb;
+        path_rows(mini, p, in_block, depth_b + 1, r.data());                             // block layers, then the singleton's (unused) entry
+        for (size_t d = 0; d < depth_b; ++d) rows_m[p * per_m + d] = r[d];
+        rows_m[p * per_m + depth_b] = p * cpb + in_block;                                // the leaf: layer 0 of `mini`
+        rows_m[p * per_m + depth_b + 1] = mini->toff[0] + p;                             // the block root: layer 0 of its singleton tree
+        uint64_t q = b, m = nblocks;
+        for (size_t d = 0; d < depth_t; ++d) {                                           // merkleProof(bigTree, blockIdx), merkle.nim:21-42
+          const uint64_t sib = q ^ 1;
+          rows_c[p * per_c + d] = sib < m ? ds->coff[d] + ls * ds->csizes[d] + sib : NO_ROW;
+          q >>= 1;
+          m = (m + 1) >> 1;
+        }
+        rows_c[p * per_c + depth_t] = ds->coff[0] + ls * ds->csizes[0] + b;              // the stored root of the block
       }
-      rows_c[i * per_c + depth_t] = ds->coff[0] + ls * ds->csizes[0] + b;                // the stored root of the block
     }
     const size_t n_m = rows_m.size(), n_c = rows_c.size();
     CP2_TRY(d_rows.scratch(ctx, (n_m + n_c) * 8));
@@ -758,31 +785,53 @@ static int compact_proof_input(cp2_dataset* ds, uint64_t slot, const uint8_t ent
     CP2_HIP(ctx, hipMemcpyAsync(dr + n_m, rows_c.data(), n_c * 8, hipMemcpyHostToDevice, ctx->stream));
     CP2_HIP(ctx, cp2k::launch_gather_rows(mini->nodes.p, dr, n_m, 32, d_got.p, ctx->stream));
     CP2_HIP(ctx, cp2k::launch_gather_rows(ds->compact.p, dr + n_m, n_c, 32, d_got.u8() + n_m * 32, ctx->stream));
-    std::vector<uint8_t> got((n_m + n_c) * 32), blocks;
+    std::vector<uint8_t> got((n_m + n_c) * 32);
     CP2_HIP(ctx, hipMemcpyAsync(got.data(), d_got.p, got.size(), hipMemcpyDeviceToHost, ctx->stream));
+    // the sampled cells themselves: one row of cellSize bytes per pair out of the block scratch (device sources), or the host copy
+    DevBuf d_sel, d_sel_rows;
     if (!ds->from_file) {
-      blocks.resize(n_bc * cs);
-      CP2_HIP(ctx, hipMemcpyAsync(blocks.data(), d_cells.p, blocks.size(), hipMemcpyDeviceToHost, ctx->stream));
+      if ((cs & 3) == 0) {
+        std::vector<uint64_t> sel(total);
+        for (size_t p = 0; p < total; ++p) sel[p] = p * cpb + idx[p] % cpb;
+        CP2_TRY(d_sel_rows.scratch(ctx, total * 8));
+        CP2_TRY(d_sel.scratch(ctx, total * cs));
+        CP2_HIP(ctx, hipMemcpyAsync(d_sel_rows.p, sel.data(), total * 8, hipMemcpyHostToDevice, ctx->stream));
+        CP2_HIP(ctx, cp2k::launch_gather_rows(d_cells.p, static_cast<const uint64_t*>(d_sel_rows.p), total, cs, d_sel.p, ctx->stream));
+        CP2_HIP(ctx, hipMemcpyAsync(cells.data(), d_sel.p, total * cs, hipMemcpyDeviceToHost, ctx->stream));
+        CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));                                 // `sel` leaves scope
+      } else {                                                                           // cell sizes the row gather cannot take: plain copies
+        for (size_t p = 0; p < total; ++p)
+          CP2_HIP(ctx, hipMemcpyAsync(&cells[p * cs], d_cells.u8() + (p * cpb + idx[p] % cpb) * cs, cs, hipMemcpyDeviceToHost, ctx->stream));
+      }
     }
     CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const uint8_t* src_blocks = ds->from_file ? h_blocks.data() : blocks.data();
-    for (size_t i = 0; i < ns; ++i) {
-      const uint8_t* gm = &got[i * per_m * 32];
-      const uint8_t* gc = &got[(n_m + i * per_c) * 32];
-      if (std::memcmp(gm + (depth_b + 1) * 32, gc + depth_t * 32, 32) != 0) {            // the data no longer hashes to the stored block root
-        ctx->err = "block " + std::to_string(idx[i] / cpb) + " of slot " + std::to_string(slot) + " does not hash to its stored root (slot data changed since the build?)";
-        return CP2_ERR_IO;
+    for (size_t i = 0; i < n; ++i)
+      for (size_t k = 0; k < ns; ++k) {
+        const size_t p = i * ns + k;
+        const uint8_t* gm = &got[p * per_m * 32];
+        const uint8_t* gc = &got[(n_m + p * per_c) * 32];
+        if (std::memcmp(gm + (depth_b + 1) * 32, gc + depth_t * 32, 32) != 0) {          // the data no longer hashes to the stored block root
+          ctx->err = "block " + std::to_string(idx[p] / cpb) + " of slot " + std::to_string(slots[i]) +
+                     " does not hash to its stored root (slot data changed since the build?)";
+          return CP2_ERR_IO;
+        }
+        std::memcpy(&paths[p * md * 32], gm, depth_b * 32);
+        std::memcpy(&paths[(p * md + depth_b) * 32], gc, depth_t * 32);
+        std::memcpy(&leaves[p * 32], gm + depth_b * 32, 32);
+        if (ds->from_file) std::memcpy(&cells[p * cs], &h_blocks[(p * cpb + idx[p] % cpb) * cs], cs);
       }
-      std::memcpy(&paths[i * md * 32], gm, depth_b * 32);
-      std::memcpy(&paths[(i * md + depth_b) * 32], gc, depth_t * 32);
-      std::memcpy(&leaves[i * 32], gm + depth_b * 32, 32);
-      std::memcpy(&cells[i * cs], src_blocks + (i * cpb + idx[i] % cpb) * cs, cs);
-    }
   }
   std::vector<uint8_t> proof;
-  fill_slot_proof(ds, slot, proof);
-  return cp2_proof_input_create(&c, slot, &ds->dlayers[ds->dlayers.size() - 32], entropy, slot_root, proof.data(), ns, idx.data(), cells.data(),
-                                paths.data(), leaves.data(), out);
+  for (size_t i = 0; i < n; ++i) {
+    fill_slot_proof(ds, slots[i], proof);
+    int st = cp2_proof_input_create(&c, slots[i], &ds->dlayers[ds->dlayers.size() - 32], entropy, &ds->dlayers[slots[i] * 32], proof.data(), ns,
+                                    &idx[i * ns], &cells[i * ns * cs], &paths[i * ns * md * 32], &leaves[i * ns * 32], out + i);
+    if (st != CP2_OK) {
+      for (size_t j = 0; j < i; ++j) { cp2_proof_input_free(out[j]); out[j] = nullptr; }
+      return st;
+    }
+  }
+  return CP2_OK;
 }
 
 // generateProofInput (gen_input/bn254.nim:35-79) for `n` slots of the dataset at once: one sampling launch,
@@ -803,10 +852,14 @@ extern "C" int cp2_proof_inputs_generate_batch(cp2_dataset* ds, const uint64_t* 
   if (!ds->trees && ds->tree_mode == 2) {                               // compact dataset: stored upper layers + the touched blocks, slot by slot
     if (!ds->have_roots) CP2_TRY(cp2_dataset_set_roots(ds, nullptr));
     if (ds->dsizes.size() - 1 > (size_t)cfg.max_log2_nslots) return CP2_ERR_INVALID;   // padMerkleProof assert
-    for (size_t i = 0; i < n; ++i) {
-      int st = compact_proof_input(ds, slot_idx[i], entropy, out + i);
+    // as many slots per pass as keep the touched blocks within about 2 GiB of scratch (327 slots at 100 samples of 64 KiB blocks)
+    const size_t per_slot = std::max<size_t>(1, (size_t)cfg.n_samples * cfg.block_size);
+    const size_t chunk = std::max<size_t>(1, ((size_t)2 << 30) / per_slot);
+    for (size_t i0 = 0; i0 < n; i0 += chunk) {
+      const size_t m = std::min(chunk, n - i0);
+      int st = compact_proof_inputs(ds, slot_idx + i0, m, entropy, out + i0);
       if (st != CP2_OK) {
-        for (size_t j = 0; j < i; ++j) { cp2_proof_input_free(out[j]); out[j] = nullptr; }
+        for (size_t j = 0; j < i0; ++j) { cp2_proof_input_free(out[j]); out[j] = nullptr; }
         return st;
       }
     }

@@ -456,6 +456,32 @@ def test_compact_and_roots_only_datasets_are_cached_as_what_they_keep(pkg, oracl
         assert open(out).read() == want
 
 
+def test_compact_dataset_proves_every_slot_in_batched_passes(pkg, golden, tmp_path):
+    """A node proves EVERY slot it holds each period.  Config 4's shape (4096 slots x 2^12 cells, 100 samples) kept compact: all
+    4096 proof inputs for a new entropy come from batched passes over the touched blocks (327 slots per pass), written as
+    input.json files; slots 1234 and 4095 against the oracle-only fixture, every file against the dataset that keeps every node."""
+    g = golden("fullsize.json")["config4"]
+    cfg = pkg.make_config(**g["config"])
+    ctx = pkg.Context(0)
+    ctx.set_keep_trees(2)
+    ds = ctx.dataset(cfg)
+    assert ds.tree_mode == 2 and hexroot(ds.root()) == g["dataset_root_hex"]
+    out = tmp_path / "compact"
+    out.mkdir()
+    total = ds.export_proof_inputs(list(range(4096)), g["entropy"], str(out), threads=_threads(), batch=1024)
+    assert len(os.listdir(out)) == 4096 and total == sum(os.path.getsize(out / f) for f in os.listdir(out))
+    for slot, want in g["inputs"].items():
+        text = open(out / ("input_%s.json" % slot)).read()
+        assert tsha(text) == want["json_sha256"] and len(text) == want["json_bytes"], slot
+    ds.free()
+    ctx.set_keep_trees(1)
+    full = ctx.dataset(cfg)
+    for slot in (0, 326, 327, 2048, 4094):                          # the edges of the 327-slot passes among them
+        assert open(out / ("input_%d.json" % slot)).read() == full.proof_input(slot, g["entropy"]).json(), slot
+    full.free()
+    ctx.close()
+
+
 def test_compact_dataset_notices_changed_slot_data(pkg, oracle, tmp_path):
     """Compact datasets re-hash the touched blocks of the slot FILE at proof time: data that changed since the build no longer
     hashes to the stored block root -- an I/O error naming block and slot, never a proof over mixed data."""
