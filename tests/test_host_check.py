@@ -15,3 +15,77 @@ def test_device_arithmetic_on_host_with_sanitizers(tmp_path):
     r = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert ", 0 mismatches, no bound violations" in r.stdout
+
+
+def _build_text_check(tmp_path):
+    import importlib
+    pkg = importlib.import_module("codex-storage-proofs-circuits_amd")
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    exe = str(tmp_path / "host_text_check")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", exe,
+                           os.path.join(ROOT, "tests", "host_check", "host_text_check.cpp"),
+                           "-L" + libdir, "-lcodex_p2", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib",
+                           "-lpthread"])
+    return exe
+
+
+def _run(exe, *args):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe, *args], capture_output=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    return r.stdout
+
+
+def test_host_text_and_body_store_with_sanitizers(tmp_path):
+    """The product's host-side hot loops -- the byte-exact JSON formatter (csrc/json_text.hpp; json/bn254.nim:57-74,
+    json/shared.nim:17-25, types/bn254.nim:29-43) and the streamed build's body store with its private spill files
+    (csrc/body_store.hpp) -- compiled from the product's own headers under AddressSanitizer + UBSan.  No GPU."""
+    import random
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle import poseidon2_ref as ref
+    exe = _build_text_check(tmp_path)
+
+    # 1. 256-bit integers to decimal: every edge of the base-10^19 chunking and of the reciprocal division, then random
+    rnd = random.Random(20261004)
+    vals = [0, 1, 9, 10, 99, 100, 2**32 - 1, 2**32, 2**64 - 1, 2**64, 2**128 - 1, 2**128, 2**192 - 1, 2**192, 2**256 - 1, ref.R_MOD - 1, ref.R_MOD]
+    for k in (19, 38, 57, 76):
+        vals += [10**k - 1, 10**k, 10**k + 1, 9 * 10**k, 10**k + 10**(k - 1)]
+    vals += [11 * 10**76, 2**256 - 1 - 10**19, (2**64 - 1) * 10**19, (10**19 - 1) * (2**64) + (2**64 - 1)]
+    vals += [rnd.getrandbits(rnd.choice((1, 8, 63, 64, 65, 127, 128, 191, 192, 250, 254, 256))) for _ in range(20000)]
+    vals = [v for v in vals if v < 2**256]
+    blob = tmp_path / "dec.bin"
+    blob.write_bytes(b"".join(v.to_bytes(32, "little") for v in vals))
+    got = _run(exe, "dec", str(blob)).decode().splitlines()
+    assert len(got) == len(vals)
+    for v, line in zip(vals, got):
+        assert line == '"%d"' % v, (v, line)
+
+    # 2. whole texts against the oracle's writer, on shapes that move every bound: no samples, one sample, depth 0 / 1 / 32,
+    #    no slotProof entries, cells of 1, 31, 32, 62, 2048 bytes, all-ones data (the longest numbers)
+    def text_case(md, ml, cs, ns, fill=None):
+        felt = (lambda: ref.R_MOD - 1) if fill == "max" else (lambda: rnd.randrange(ref.R_MOD) if rnd.random() < 0.9 else rnd.randrange(1000))
+        cell = (lambda: b"\xff" * cs) if fill == "max" else (lambda: bytes(rnd.getrandbits(8) for _ in range(cs)))
+        p = {"dataSetRoot": felt(), "entropy": felt(), "nCells": rnd.choice((2, 512, 2**22, 2**40)), "nSlots": rnd.choice((1, 11, 32768, 2**33)),
+             "slotIndex": rnd.choice((0, 3, 2**33 - 1)), "slotRoot": felt(), "slotProof": {"merklePath": [felt() for _ in range(ml)]},
+             "proofInputs": [{"cellData": cell(), "merkleProof": {"merklePath": [felt() for _ in range(md)]}} for _ in range(ns)]}
+        b = b"".join(x.to_bytes(8, "little") for x in (ml, md, cs, p["nCells"], p["nSlots"], p["slotIndex"], ns))
+        b += b"".join(p[k].to_bytes(32, "little") for k in ("dataSetRoot", "entropy", "slotRoot"))
+        b += b"".join(x.to_bytes(32, "little") for x in p["slotProof"]["merklePath"])
+        b += b"".join(q["cellData"] for q in p["proofInputs"])
+        b += b"".join(x.to_bytes(32, "little") for q in p["proofInputs"] for x in q["merkleProof"]["merklePath"])
+        f = tmp_path / "json.bin"
+        f.write_bytes(b)
+        assert _run(exe, "json", str(f)).decode() == ref.export_json(p), (md, ml, cs, ns, fill)
+
+    for (md, ml, cs, ns) in [(32, 8, 2048, 3), (0, 0, 1, 0), (1, 0, 31, 1), (5, 1, 32, 2), (16, 15, 62, 7), (32, 8, 93, 5), (12, 3, 64, 100)]:
+        text_case(md, ml, cs, ns)
+    text_case(32, 8, 2048, 4, fill="max")
+    text_case(3, 2, 31, 2, fill="max")
+
+    # 3. the body store: budget, concurrent spills, 0700 directory / 0600 files, a planted symlink, O_EXCL, clean-up
+    spill = tmp_path / "spill"
+    spill.mkdir()
+    assert b"body store ok" in _run(exe, "store", str(spill))
+    assert list(spill.iterdir()) == []
