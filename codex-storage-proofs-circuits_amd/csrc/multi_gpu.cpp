@@ -170,8 +170,18 @@ extern "C" int cp2_multi_init(const int* devices, int n_dev, cp2_multi** out) tr
   for (int d : m->devices)
     if (d < 0 || d >= visible) return CP2_ERR_NO_DEVICE;
   m->ctxs.assign(m->devices.size(), nullptr);
-  if (const char* e = std::getenv("CODEX_P2_MIN_CELLS")) m->min_cells = std::strtoull(e, nullptr, 10);   // see cp2_multi_set_policy
-  if (const char* e = std::getenv("CODEX_P2_SPLIT")) m->split = std::strtoll(e, nullptr, 10);              // see cp2_multi_set_split
+  // CODEX_P2_MIN_CELLS (cp2_multi_set_policy) and CODEX_P2_SPLIT (cp2_multi_set_split): plain decimal numbers, or refused like CODEX_P2_GPUS
+  auto env_number = [](const char* name, uint64_t* v) {
+    const char* e = std::getenv(name);
+    if (!e || !*e) return true;
+    const std::string t(e);
+    if (t.size() > 18 || t.find_first_not_of("0123456789") != std::string::npos) return false;
+    *v = std::strtoull(e, nullptr, 10);
+    return true;
+  };
+  uint64_t split = 0;
+  if (!env_number("CODEX_P2_MIN_CELLS", &m->min_cells) || !env_number("CODEX_P2_SPLIT", &split) || (split > 1 && !is_pow2(split))) return CP2_ERR_INVALID;
+  m->split = (int64_t)split;
   if (const char* e = std::getenv("CODEX_P2_GATHER")) {                                                      // "rccl" / "host" / anything else: auto
     if (std::strcmp(e, "rccl") == 0) m->gather = CP2_GATHER_RCCL;
     else if (std::strcmp(e, "host") == 0) m->gather = CP2_GATHER_HOST;
@@ -255,8 +265,14 @@ namespace {
 template <typename F> int for_each_shard(size_t n, F f) {
   std::vector<int> st(n, CP2_OK);
   std::vector<std::thread> th;
-  for (size_t i = 1; i < n; ++i) th.emplace_back([&, i] { try { st[i] = f(i); } catch (...) { st[i] = CP2_ERR_ALLOC; } });
+  th.reserve(n);
+  size_t started = 1;
+  try {
+    for (; started < n; ++started) th.emplace_back([&, i = started] { try { st[i] = f(i); } catch (...) { st[i] = CP2_ERR_ALLOC; } });
+  } catch (...) {   // the host refused another thread: the shards without one run here, after shard 0
+  }
   try { st[0] = f(0); } catch (...) { st[0] = CP2_ERR_ALLOC; }
+  for (size_t i = started; i < n; ++i) { try { st[i] = f(i); } catch (...) { st[i] = CP2_ERR_ALLOC; } }
   for (auto& t : th) t.join();
   for (int s : st)
     if (s != CP2_OK) return s;
@@ -460,9 +476,9 @@ int multi_build(cp2_multi* m, const cp2_config* cfg, BuildKind kind, const uint8
   *out = nullptr;
   m->err.clear();
   if (cfg->n_slots == 0 || cfg->max_depth < 0 || cfg->max_log2_nslots < 0) return CP2_ERR_INVALID;
-  // whole slots or units: streamed and cached builds keep whole slots (their per-slot state lives in a cp2_dataset)
+  // whole slots or units: streamed builds keep whole slots (their per-slot bodies live in a cp2_dataset)
   uint64_t world = 1, S = 1;
-  plan_shards(*cfg, m->devices.size(), m->min_cells, kind == BuildKind::Plain ? m->split : 1, &world, &S);
+  plan_shards(*cfg, m->devices.size(), m->min_cells, kind == BuildKind::Streamed ? 1 : m->split, &world, &S);
   std::unique_ptr<cp2_multi_dataset> mds(new cp2_multi_dataset());
   mds->m = m;
   mds->cfg = *cfg;
@@ -483,8 +499,21 @@ int multi_build(cp2_multi* m, const cp2_config* cfg, BuildKind kind, const uint8
     if (!ctx) { errs[i] = "device " + std::to_string(m->devices[s.dev]) + ": " + cp2_strerror(cst); return cst; }
     int r = CP2_OK;
     if (S > 1) {
+      // cached: this shard's unit trees from "<cache>.units<S>.shard<i>of<world>" when that file is intact and describes exactly
+      // these units of this data (cp2_slot_trees_load checks the checksum and, for slot files, their sizes and mtimes)
+      const std::string path = kind == BuildKind::Cached ? std::string(cache_path) + ".units" + std::to_string(S) + ".shard" + std::to_string(i) + "of" + std::to_string(world) : std::string();
+      if (kind == BuildKind::Cached && cp2_slot_trees_load(ctx, path.c_str(), &s.units) == CP2_OK) {
+        const cp2_slot_trees* t = s.units;
+        const bool match = t->n_slots == s.count && t->first_slot == s.first && t->units_per_slot == S && t->cell_size == cfg->cell_size &&
+                           t->block_size == cfg->block_size && t->n_cells == cfg->n_cells / S &&
+                           (cfg->file_base ? (t->src == CellSrc::File && t->file_base == mds->file_base) : (t->src == CellSrc::Fake && t->dataset_seed == cfg->seed));
+        if (match) return CP2_OK;
+        cp2_slot_trees_free(s.units);
+        s.units = nullptr;
+      }
       r = cfg->file_base ? cp2_slot_trees_build_file_units(ctx, mds->file_base.c_str(), S, s.first, s.count, cfg->cell_size, cfg->block_size, cfg->n_cells / S, &s.units)
                          : cp2_slot_trees_build_fake_units(ctx, cfg->seed, S, s.first, s.count, cfg->cell_size, cfg->block_size, cfg->n_cells / S, &s.units);
+      if (r == CP2_OK && kind == BuildKind::Cached) r = cp2_slot_trees_save(s.units, path.c_str());
     } else if (kind == BuildKind::Streamed) {
       r = cp2_dataset_build_streamed(ctx, &mds->cfg, s.first, s.count, entropy, per, group_slots, &s.ds);
     } else if (kind == BuildKind::Cached) {

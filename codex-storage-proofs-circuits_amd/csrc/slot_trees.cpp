@@ -281,13 +281,19 @@ extern "C" int cp2_slot_trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, ui
 // Units: `n_units` consecutive pieces of `cells_per_unit` cells, unit u = cells [(u % units_per_slot) * cells_per_unit, ...) of
 // slot u / units_per_slot.  The root of a unit is the node of that slot's tree (gen_input/bn254.nim:21-30) above its cells
 // (cells_per_unit / cellsPerBlock >= 2 blocks, a power of two, so that the unit's layers ARE layers of the slot tree).
+namespace {
+bool unit_geometry_ok(uint64_t units_per_slot, size_t cell_size, size_t block_size, size_t cells_per_unit) {
+  if (!is_pow2(units_per_slot) || cell_size == 0 || block_size < cell_size) return false;
+  const size_t nb = cells_per_unit / (block_size / cell_size);
+  return nb >= 2 && is_pow2(nb);
+}
+}  // namespace
 extern "C" int cp2_slot_trees_build_fake_units(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t units_per_slot, uint64_t first_unit,
                                                size_t n_units, size_t cell_size, size_t block_size, size_t cells_per_unit,
                                                cp2_slot_trees** out) try {
   if (!ctx || !out || units_per_slot == 0) return CP2_ERR_INVALID;
   CP2_TRY(trees_check_geometry(cell_size, block_size, cells_per_unit, n_units));
-  const size_t nb = cells_per_unit / (block_size / cell_size);
-  if (units_per_slot > 1 && (nb < 2 || !is_pow2(nb))) return CP2_ERR_INVALID;
+  if (units_per_slot > 1 && !unit_geometry_ok(units_per_slot, cell_size, block_size, cells_per_unit)) return CP2_ERR_INVALID;
   return trees_build_fake(ctx, dataset_seed, first_unit, n_units, cell_size, block_size, cells_per_unit, 0, nullptr, out, units_per_slot);
 } catch (const std::bad_alloc&) {
   return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
@@ -300,8 +306,7 @@ extern "C" int cp2_slot_trees_build_file_units(cp2_ctx* ctx, const char* file_ba
                                                cp2_slot_trees** out) try {
   if (!ctx || !out || !file_base || units_per_slot == 0) return CP2_ERR_INVALID;
   CP2_TRY(trees_check_geometry(cell_size, block_size, cells_per_unit, n_units));
-  const size_t nb = cells_per_unit / (block_size / cell_size);
-  if (units_per_slot > 1 && (nb < 2 || !is_pow2(nb))) return CP2_ERR_INVALID;
+  if (units_per_slot > 1 && !unit_geometry_ok(units_per_slot, cell_size, block_size, cells_per_unit)) return CP2_ERR_INVALID;
   return trees_build_files(ctx, file_base, first_unit, n_units, cell_size, block_size, cells_per_unit, 0, nullptr, out, units_per_slot);
 } catch (const std::bad_alloc&) {
   return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
@@ -601,8 +606,9 @@ extern "C" int cp2_set_ingest(cp2_ctx* ctx, int fill_threads, int ring_depth, si
 // SlotFile source, size + mtime of every slot file so that a cache is never reused over changed data.
 namespace {
 struct TreeFileHeader {
-  char magic[8];            // "CP2TREE2"
-  uint64_t n_slots, cell_size, block_size, n_cells;
+  char magic[8];            // "CP2TREE3"
+  uint64_t n_slots, cell_size, block_size, n_cells;   // a batch of units: units and the cells of one unit (trees.hpp)
+  uint64_t units_per_slot;  // 1: whole slots
   uint64_t src;             // CellSrc
   uint64_t dataset_seed, first_slot;
   uint64_t file_base_len;   // bytes following the header
@@ -677,12 +683,13 @@ bool pread_all(int fd, uint8_t* p, size_t n, off_t off) {
   return true;
 }
 
-// (size, mtime in ns) of each slot file; a missing file stamps as (~0, ~0)
-std::vector<uint64_t> file_stamps(const std::string& base, uint64_t first_slot, size_t n_slots) {
+// (size, mtime in ns) of the slot file behind each slot (each unit: several units then stamp the same file); a missing file
+// stamps as (~0, ~0)
+std::vector<uint64_t> file_stamps(const std::string& base, uint64_t first_slot, size_t n_slots, uint64_t units_per_slot = 1) {
   std::vector<uint64_t> v(2 * n_slots);
   for (size_t s = 0; s < n_slots; ++s) {
     struct stat sb;
-    if (stat(slot_file_name(base, first_slot + s).c_str(), &sb) == 0) {
+    if (stat(slot_file_name(base, (first_slot + s) / units_per_slot).c_str(), &sb) == 0) {
       v[2 * s] = (uint64_t)sb.st_size;
       v[2 * s + 1] = (uint64_t)sb.st_mtim.tv_sec * 1000000000ULL + (uint64_t)sb.st_mtim.tv_nsec;
     } else {
@@ -697,16 +704,16 @@ std::vector<uint64_t> file_stamps(const std::string& base, uint64_t first_slot, 
 // write of chunk i-1 overlap, and no host copy of the whole node buffer exists (8 GiB for 32 768 slots of 2^12 cells).
 extern "C" int cp2_slot_trees_save(cp2_slot_trees* t, const char* path) try {
   if (!t || !path) return CP2_ERR_INVALID;
-  if (t->units_per_slot != 1) return CP2_ERR_INVALID;   // the file format describes whole slots
   cp2_ctx* ctx = t->ctx;
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   TreeFileHeader h{};
-  std::memcpy(h.magic, "CP2TREE2", 8);
+  std::memcpy(h.magic, "CP2TREE3", 8);
+  h.units_per_slot = t->units_per_slot;
   h.n_slots = t->n_slots; h.cell_size = t->cell_size; h.block_size = t->block_size; h.n_cells = t->n_cells;
   h.src = (uint64_t)t->src; h.dataset_seed = t->dataset_seed; h.first_slot = t->first_slot;
   h.file_base_len = t->file_base.size();
   std::vector<uint64_t> stamps;
-  if (t->src == CellSrc::File) stamps = file_stamps(t->file_base, t->first_slot, t->n_slots);
+  if (t->src == CellSrc::File) stamps = file_stamps(t->file_base, t->first_slot, t->n_slots, t->units_per_slot);
   h.n_stamps = stamps.size() / 2;
   h.n_nodes = t->nodes.bytes / 32;
   const size_t total = t->nodes.bytes;
@@ -789,17 +796,25 @@ extern "C" int cp2_slot_trees_load(cp2_ctx* ctx, const char* path, cp2_slot_tree
   struct Closer { int fd; ~Closer() { close(fd); } } closer{fd};
   TreeFileHeader h{};
   // every header field is bounded before anything is sized from it
-  if (!pread_all(fd, reinterpret_cast<uint8_t*>(&h), sizeof h, 0) || std::memcmp(h.magic, "CP2TREE2", 8) != 0 || h.file_base_len > 4096 ||
+  if (!pread_all(fd, reinterpret_cast<uint8_t*>(&h), sizeof h, 0) || std::memcmp(h.magic, "CP2TREE3", 8) != 0 || h.file_base_len > 4096 ||
       trees_check_geometry(h.cell_size, h.block_size, h.n_cells, h.n_slots) != CP2_OK || h.src > (uint64_t)CellSrc::File ||
+      h.units_per_slot == 0 || (h.units_per_slot > 1 && !unit_geometry_ok(h.units_per_slot, h.cell_size, h.block_size, h.n_cells)) ||
       (h.n_stamps != 0 && h.n_stamps != h.n_slots) || (h.src == (uint64_t)CellSrc::File) != (h.n_stamps != 0)) {
     ctx->err = std::string("not a slot-tree cache of this version: ") + path;
     return CP2_ERR_IO;
+  }
+  {   // the stamps the header announces are in the file before anything is sized from their count
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || h.n_stamps > ((uint64_t)1 << 40) || (uint64_t)sb.st_size < sizeof h + h.file_base_len + 16 * h.n_stamps) {
+      ctx->err = std::string("slot-tree cache is truncated: ") + path;
+      return CP2_ERR_IO;
+    }
   }
   std::string base(h.file_base_len, '\0');
   if (h.file_base_len && !pread_all(fd, reinterpret_cast<uint8_t*>(&base[0]), h.file_base_len, sizeof h)) return CP2_ERR_IO;
   std::vector<uint64_t> stamps(2 * h.n_stamps);
   if (!stamps.empty() && !pread_all(fd, reinterpret_cast<uint8_t*>(stamps.data()), stamps.size() * 8, (off_t)(sizeof h + h.file_base_len))) return CP2_ERR_IO;
-  if (h.src == (uint64_t)CellSrc::File && stamps != file_stamps(base, h.first_slot, h.n_slots)) {
+  if (h.src == (uint64_t)CellSrc::File && stamps != file_stamps(base, h.first_slot, h.n_slots, h.units_per_slot)) {
     ctx->err = std::string("slot files changed since the cache was written: ") + path;
     return CP2_ERR_IO;   // size or mtime of a slot file differs: the trees no longer describe the data
   }
@@ -810,6 +825,7 @@ extern "C" int cp2_slot_trees_load(cp2_ctx* ctx, const char* path, cp2_slot_tree
   t->src = (CellSrc)h.src;
   t->dataset_seed = h.dataset_seed;
   t->first_slot = h.first_slot;
+  t->units_per_slot = h.units_per_slot;
   t->file_base = base;
   CP2_TRY(trees_layout(t.get()));
   if (t->nodes.bytes / 32 != h.n_nodes) return CP2_ERR_IO;

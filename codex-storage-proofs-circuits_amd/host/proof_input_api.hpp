@@ -118,7 +118,7 @@ class Engine {
  private:
   void init(const int* devices, int n) {
     int st = cp2_multi_init(devices, n, &multi_);
-    if (st != CP2_OK) throw std::runtime_error(std::string("cp2_multi_init: ") + cp2_strerror(st) + (st == CP2_ERR_INVALID ? " (CODEX_P2_GPUS must be a device count or a comma-separated index list)" : ""));
+    if (st != CP2_OK) throw std::runtime_error(std::string("cp2_multi_init: ") + cp2_strerror(st) + (st == CP2_ERR_INVALID ? " (CODEX_P2_GPUS must be a device count or a comma-separated index list, CODEX_P2_MIN_CELLS a number, CODEX_P2_SPLIT 0, 1 or a power of two)" : ""));
   }
   cp2_multi* multi_ = nullptr;
 };

@@ -174,7 +174,7 @@ int cp2_slot_trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t firs
  * (unit u = cells [(u mod units_per_slot) x cells_per_unit, + cells_per_unit) of slot u / units_per_slot).  The root of a unit is
  * the node of its slot's tree above those cells, so several devices can share ONE slot (section e, "by units"; SURVEY.md 8e:
  * "within one very large slot the same scheme applies one level down").  cp2_slot_trees_roots / _paths address units as
- * slots of cells_per_unit cells.  Unit batches are not cached (cp2_slot_trees_save refuses them). */
+ * slots of cells_per_unit cells.  cp2_slot_trees_save / _load carry unit batches too (the file records units_per_slot). */
 int cp2_slot_trees_build_fake_units(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t units_per_slot, uint64_t first_unit, size_t n_units,
                                     size_t cell_size, size_t block_size, size_t cells_per_unit, cp2_slot_trees** out);
 /* units of slot files "<file_base><slot>.dat" (dataset.nim:34): unit u is read at byte offset (u mod units_per_slot) x
@@ -336,14 +336,15 @@ int cp2_write_circom_main(const cp2_config* cfg, const char* path);
  *     more than 6 % above its share (11 slots on 8 GPUs: 2 against 1.375; ONE 128 GiB slot on 8 GPUs), every slot is cut into
  *     S = 2^s units of nCells / S cells (cp2_slot_trees_build_*_units), the nSlots x S units are dealt out contiguously, the
  *     unit roots exchanged, and the log2 S upper layers of every slot tree plus the dataset tree built once; a proof input then
- *     takes the bottom of each path from whichever device holds the sampled cell.  cp2_multi_dataset_build only (streamed and
- *     cached builds keep whole slots); cp2_multi_set_split / CODEX_P2_SPLIT override (1 = whole slots only). */
+ *     takes the bottom of each path from whichever device holds the sampled cell.  cp2_multi_dataset_build and _build_cached
+ *     (streamed builds keep whole slots); cp2_multi_set_split / CODEX_P2_SPLIT override (1 = whole slots only). */
 typedef struct cp2_multi cp2_multi;
 typedef struct cp2_multi_dataset cp2_multi_dataset;
 enum { CP2_GATHER_AUTO = 0, CP2_GATHER_RCCL = 1, CP2_GATHER_HOST = 2 };
 /* devices: n_dev HIP device indices (an index may repeat: several contexts on one device).  n_dev = 0: the environment
  * variable CODEX_P2_GPUS ("<count>" = the first <count> visible devices, or a comma-separated index list), else every
- * visible gfx950 device. */
+ * visible gfx950 device.  CODEX_P2_GPUS, CODEX_P2_MIN_CELLS and CODEX_P2_SPLIT are read here; a value that is not what
+ * the variable takes (a count / an index list; a decimal number; 0, 1 or a power of two) is CP2_ERR_INVALID, not guessed at. */
 int cp2_multi_init(const int* devices, int n_dev, cp2_multi** out);
 /* frees the handle, its contexts and communicators: free every cp2_multi_dataset (and proof input) made through it first */
 void cp2_multi_free(cp2_multi* m);
@@ -368,7 +369,7 @@ int cp2_multi_plan(const cp2_config* cfg, int n_devices, uint64_t min_cells_per_
                    uint64_t* units_per_slot_out);
 /* cp2_dataset_build / _build_cached / _build_streamed for ALL cfg->n_slots slots over the devices of `m`, including the
  * exchange and the dataset tree on every device.  Cached: shard i of n uses "<cache_path>.shard<i>of<n>" (one shard: the path
- * itself).  Streamed: `threads` formatting threads in total, divided over the shards. */
+ * itself; cut by S units per slot: "<cache_path>.units<S>.shard<i>of<n>", the unit trees of that shard).  Streamed: `threads` formatting threads in total, divided over the shards. */
 int cp2_multi_dataset_build(cp2_multi* m, const cp2_config* cfg, cp2_multi_dataset** out);
 int cp2_multi_dataset_build_cached(cp2_multi* m, const cp2_config* cfg, const char* cache_path, cp2_multi_dataset** out);
 int cp2_multi_dataset_build_streamed(cp2_multi* m, const cp2_config* cfg, const uint8_t entropy[32], int threads, size_t group_slots,

@@ -282,6 +282,10 @@ def test_cli_twin_spreads_over_contexts_without_a_new_flag(pkg, golden, tmp_path
         r = subprocess.run([pkg.CLI_PATH] + args + ["--output=" + str(tmp_path / "x.json")], capture_output=True, text=True, timeout=60,
                            env=dict(os.environ, CODEX_P2_GPUS=bad))
         assert r.returncode != 0 and "invalid argument" in r.stderr, (bad, r.stderr)     # a malformed list is refused, not guessed at
+    for var, bad in (("CODEX_P2_SPLIT", "3"), ("CODEX_P2_SPLIT", "-2"), ("CODEX_P2_SPLIT", "two"), ("CODEX_P2_MIN_CELLS", "1e6"), ("CODEX_P2_MIN_CELLS", "-1")):
+        r = subprocess.run([pkg.CLI_PATH] + args + ["--output=" + str(tmp_path / "x.json")], capture_output=True, text=True, timeout=60,
+                           env=dict(os.environ, **{var: bad}))
+        assert r.returncode != 0 and "invalid argument" in r.stderr and var in r.stderr, (var, bad, r.stderr)
 
 
 def test_cli_twin_reads_slot_files_whole_and_by_units(pkg, oracle, golden, tmp_path):
@@ -639,6 +643,69 @@ def test_units_from_slot_files_and_one_slot_over_several_contexts(pkg, oracle, t
         want = P.export_json(expected_proof_input_fast(C, P, dict(c, seed=99), 0, 31337, threads=4))
         assert ds.proof_input(0, 31337).json() == want
         ds.free()
+    m.close()
+
+
+def test_cached_builds_are_cut_by_units_too(pkg, oracle, tmp_path, capfd):
+    """cp2_multi_dataset_build_cached on a dataset of few, large slots: every shard's UNIT trees go to
+    "<cache>.units<S>.shard<i>of<n>" (the cache format records units_per_slot); a second build loads them and hashes nothing;
+    damage, another seed and changed slot files are noticed; a batch of units saved by hand loads back as the same units."""
+    C, P = oracle
+    c = dict(maxDepth=12, maxLog2NSlots=2, cellSize=128, blockSize=1024, nSlots=3, nCells=512, nSamples=9)
+    base = str(tmp_path / "slot")
+    for k in range(3):
+        C.gen_fake_cells(C.slot_seed(99, k), 0, 512, 128).tofile(base + "%d.dat" % k)
+    want = P.export_json(expected_proof_input_fast(C, P, dict(c, seed=99), 2, 4242, threads=4))
+    m = pkg.Multi([0, 0])
+    m.set_policy(pkg.GATHER_AUTO, 1)
+    for tag, src in (("fake", dict(seed=99)), ("file", dict(file=base))):
+        cache = str(tmp_path / ("units_%s.cp2" % tag))
+        cfg = pkg.make_config(**c, **src)
+        a = m.dataset(cfg, cache=cache)
+        assert a.units_per_slot == 2 and [(f, k) for _, f, k in a.shards()] == [(0, 3), (3, 3)]      # 6 units, 3 per context
+        files = sorted(f for f in os.listdir(tmp_path) if f.startswith("units_%s" % tag))
+        assert files == ["units_%s.cp2.units2.shard0of2" % tag, "units_%s.cp2.units2.shard1of2" % tag]
+        assert a.proof_input(2, 4242).json() == want
+        a.free()
+        stamp = [os.path.getmtime(str(tmp_path / f)) for f in files]
+        os.environ["CP2_TRACE"] = "1"
+        capfd.readouterr()
+        try:
+            b = m.dataset(cfg, cache=cache)                            # loaded: no generator / ingestion / hashing stage in the trace
+        finally:
+            del os.environ["CP2_TRACE"]
+        err = capfd.readouterr().err
+        assert "unit trees on 2" in err and "fake slots" not in err, err
+        assert b.units_per_slot == 2 and b.proof_input(2, 4242).json() == want
+        b.free()
+        assert [os.path.getmtime(str(tmp_path / f)) for f in files] == stamp                      # not rewritten
+        raw = bytearray(open(str(tmp_path / files[1]), "rb").read())
+        raw[-40] ^= 1                                                  # one node of shard 1 flipped: checksum -> rebuilt and rewritten
+        open(str(tmp_path / files[1]), "wb").write(bytes(raw))
+        d = m.dataset(cfg, cache=cache)
+        assert d.proof_input(2, 4242).json() == want and open(str(tmp_path / files[1]), "rb").read() != bytes(raw)
+        d.free()
+    # another seed under the same cache name: the unit trees do not describe it -> rebuilt
+    other = m.dataset(pkg.make_config(**c, seed=100), cache=str(tmp_path / "units_fake.cp2"))
+    assert other.proof_input(2, 4242).json() == P.export_json(expected_proof_input_fast(C, P, dict(c, seed=100), 2, 4242, threads=4))
+    other.free()
+    # a slot file rewritten with other data: size + mtime of the file behind every unit are part of the cache
+    cells = C.gen_fake_cells(C.slot_seed(99, 2), 0, 512, 128)
+    cells[300] ^= 1
+    cells.tofile(base + "2.dat")
+    os.utime(base + "2.dat", (1, 1))
+    changed = m.dataset(pkg.make_config(**c, file=base), cache=str(tmp_path / "units_file.cp2"))
+    text = changed.proof_input(2, 4242).json()
+    assert text != want
+    changed.free()
+    whole = pkg.Context(0)
+    assert whole.dataset(pkg.make_config(**c, file=base)).proof_input(2, 4242).json() == text      # = the slots built whole
+    # the seam: a batch of units saved and loaded by hand is the same batch
+    t = whole.slot_trees_fake_units(99, 4, 5, 3, 128, 1024, 128)       # units 5, 6, 7 of 4 per slot
+    t.save(str(tmp_path / "seam.cp2"))
+    u = whole.slot_trees_load(str(tmp_path / "seam.cp2"))
+    assert np.array_equal(t.roots(), u.roots()) and u.count == 3
+    whole.close()
     m.close()
 
 
