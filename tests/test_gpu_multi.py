@@ -223,6 +223,7 @@ def test_multi_cached_build_writes_one_file_per_shard(pkg, tmp_path):
     cfg = pkg.make_config(**c)
     m = pkg.Multi([0, 0])
     m.set_policy(pkg.GATHER_AUTO, 1)
+    m.set_split(1)                                               # whole slots (5 slots over 2 contexts would be cut by units: see below)
     cache = str(tmp_path / "trees.cp2")
     a = m.dataset(cfg, cache=cache)
     text = a.proof_input(4, 5).json()
