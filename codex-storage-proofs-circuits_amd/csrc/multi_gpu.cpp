@@ -18,6 +18,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -724,12 +725,14 @@ extern "C" int cp2_multi_dataset_export_proof_inputs(cp2_multi_dataset* mds, con
       std::unique_ptr<cp2_proof_input, void (*)(cp2_proof_input*)> guard(p, cp2_proof_input_free);
       char* text = nullptr;
       size_t len = 0;
+      CP2_TRY(cp2_proof_input_json(p, &text, &len));                 // formatted once: counted, and written when a directory is given
+      std::unique_ptr<char, void (*)(void*)> text_guard(text, cp2_free_buffer);
       if (dir) {
         const std::string name = std::string(dir) + "/input_" + std::to_string(slot_idx[i]) + ".json";
-        CP2_TRY(cp2_proof_input_write_json(p, name.c_str()));
+        FILE* f = std::fopen(name.c_str(), "wb");
+        const bool ok = f && std::fwrite(text, 1, len, f) == len;
+        if ((f && std::fclose(f) != 0) || !ok) { mds->m->err = "cannot write " + name; return CP2_ERR_IO; }
       }
-      CP2_TRY(cp2_proof_input_json(p, &text, &len));
-      cp2_free_buffer(text);
       tot += len;
     }
     if (total_bytes) *total_bytes = tot;

@@ -91,7 +91,7 @@ static void canonical_felt(const uint8_t in[32], uint8_t out[32]) {
 }
 
 static int dataset_check(const cp2_config* cfg, uint64_t first_slot, uint64_t n_local) {
-  if (n_local == 0 || first_slot + n_local > cfg->n_slots) return CP2_ERR_INVALID;
+  if (n_local == 0 || first_slot > cfg->n_slots || n_local > cfg->n_slots - first_slot) return CP2_ERR_INVALID;   // (no wrap-around)
   if (cfg->max_depth < 0 || cfg->max_log2_nslots < 0) return CP2_ERR_INVALID;
   return CP2_OK;
 }
