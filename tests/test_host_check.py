@@ -17,12 +17,12 @@ def test_device_arithmetic_on_host_with_sanitizers(tmp_path):
     assert ", 0 mismatches, no bound violations" in r.stdout
 
 
-def _build_text_check(tmp_path):
+def _build_text_check(tmp_path, sanitize=("-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"), name="host_text_check"):
     import importlib
     pkg = importlib.import_module("codex-storage-proofs-circuits_amd")
     libdir = os.path.dirname(pkg.LIB_PATH)
-    exe = str(tmp_path / "host_text_check")
-    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+    exe = str(tmp_path / name)
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", *sanitize,
                            "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", exe,
                            os.path.join(ROOT, "tests", "host_check", "host_text_check.cpp"),
                            "-L" + libdir, "-lcodex_p2", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib",
@@ -89,3 +89,12 @@ def test_host_text_and_body_store_with_sanitizers(tmp_path):
     spill.mkdir()
     assert b"body store ok" in _run(exe, "store", str(spill))
     assert list(spill.iterdir()) == []
+
+
+def test_body_store_workers_with_thread_sanitizer(tmp_path):
+    """put() runs on the formatting workers: the same harness under ThreadSanitizer (four workers spilling at once)."""
+    exe = _build_text_check(tmp_path, sanitize=("-fsanitize=thread",), name="host_text_check_tsan")
+    spill = tmp_path / "spill"
+    spill.mkdir()
+    r = subprocess.run([exe, "store", str(spill)], capture_output=True, timeout=600)
+    assert r.returncode == 0 and b"body store ok" in r.stdout and b"ThreadSanitizer" not in r.stderr, (r.returncode, r.stderr[-3000:])
