@@ -12,6 +12,8 @@
 ## hashCell, cellIndices, ...), so cli.nim and every other importer compile unchanged; build with
 ##   nim c -d:release --passL:"-L<repo>/codex-storage-proofs-circuits_amd -lcodex_p2" src/cli.nim
 
+import std/os                  # getEnv: CODEX_P2_CACHE, as in the cli twin
+
 const libName = "libcodex_p2.so"
 
 type
@@ -77,6 +79,7 @@ proc cp2_multi_gather_mode(m: Cp2Multi): cstring {.importc.}
 proc cp2_multi_set_policy(m: Cp2Multi, gather: cint, minCellsPerDevice: uint64): cint {.importc.}
 proc cp2_multi_set_split(m: Cp2Multi, unitsPerSlot: int64): cint {.importc.}
 proc cp2_multi_dataset_build(m: Cp2Multi, cfg: ptr Cp2Config, ds: ptr Cp2MultiDataset): cint {.importc.}
+proc cp2_multi_dataset_build_cached(m: Cp2Multi, cfg: ptr Cp2Config, cachePath: cstring, ds: ptr Cp2MultiDataset): cint {.importc.}
 proc cp2_multi_dataset_build_streamed(m: Cp2Multi, cfg: ptr Cp2Config, entropy: ptr byte, threads: cint, groupSlots: csize_t,
                                       ds: ptr Cp2MultiDataset): cint {.importc.}
 proc cp2_multi_dataset_free(ds: Cp2MultiDataset) {.importc.}
@@ -194,8 +197,14 @@ proc engineGenerateProofInput*(cfg: var Cp2Config, slotIdx: int, entropy: F): En
   ## every slot tree built once, the slots cut over all GPUs of the node (one device-to-device gather of the slot roots,
   ## the dataset tree on every device), then sampling + paths + cells for `slotIdx` on the device that holds it
   ## (the whole of gen_input/bn254.nim:35-74)
+  ## CODEX_P2_CACHE=<file> (not in the reference, which recomputes every tree on every run): what the datasets keep of their
+  ## trees is read from / written to that file (one file per shard), so a later run with new entropy hashes nothing again.
   var ds: Cp2MultiDataset
-  check(cp2_multi_dataset_build(multi(), addr cfg, addr ds), "cp2_multi_dataset_build")
+  let cache = getEnv("CODEX_P2_CACHE")
+  if cache.len > 0:
+    check(cp2_multi_dataset_build_cached(multi(), addr cfg, cstring(cache), addr ds), "cp2_multi_dataset_build_cached")
+  else:
+    check(cp2_multi_dataset_build(multi(), addr cfg, addr ds), "cp2_multi_dataset_build")
   defer: cp2_multi_dataset_free(ds)
   var p: Cp2ProofInput
   var e = entropy
@@ -297,18 +306,26 @@ proc engineSetPolicy*(gather: int, minCellsPerDevice: uint64) =
   ## 0 auto / 1 RCCL / 2 host gather; cells of hashing a device must have to get a shard (0: one hash-kernel residency)
   check(cp2_multi_set_policy(multi(), cint(gather), minCellsPerDevice), "cp2_multi_set_policy")
 
+iterator contexts(): Cp2Ctx =
+  ## the context of every device the engine holds (the per-context knobs below are set on all of them)
+  for i in 0 ..< int(cp2_multi_count(multi())):
+    let c = cp2_multi_ctx(multi(), cint(i))
+    if pointer(c) == nil: raiseAssert("cp2_multi_ctx: device " & $i & " is unusable")
+    yield c
+
 proc engineTrim*() =
   ## give the engine's cached device / pinned scratch back to the system (a long-lived process between runs)
-  check(cp2_trim(ctx()), "cp2_trim")
+  for c in contexts(): check(cp2_trim(c), "cp2_trim")
 
 proc engineSetIngestDirect*(on: bool) =
   ## SlotFile source: O_DIRECT reads of slot files that are not in the page cache
-  check(cp2_set_ingest_direct(ctx(), cint(ord(on))), "cp2_set_ingest_direct")
+  for c in contexts(): check(cp2_set_ingest_direct(c, cint(ord(on))), "cp2_set_ingest_direct")
 
 proc engineSetKeepTrees*(mode: int) =
-  ## 1: every slot tree stays in device memory; 0: roots only (the proved slot's tree is rebuilt on demand); -1: by what fits
-  for i in 0 ..< int(cp2_multi_count(multi())):
-    check(cp2_set_keep_trees(cp2_multi_ctx(multi(), cint(i)), cint(mode)), "cp2_set_keep_trees")
+  ## what a dataset keeps of its slot trees in device memory: 1 every node; 2 compact (block roots and up, the bottom of a path
+  ## recomputed from the touched blocks); 0 roots only (the proved slot's tree is rebuilt on demand); -1 the most that fits
+  for c in contexts(): check(cp2_set_keep_trees(c, cint(mode)), "cp2_set_keep_trees")
 
 proc engineSetBodyBudget*(maxResidentBytes: int, spillDir: string = "") =
-  check(cp2_set_body_budget(ctx(), csize_t(maxResidentBytes), (if spillDir.len > 0: cstring(spillDir) else: nil)), "cp2_set_body_budget")
+  for c in contexts():
+    check(cp2_set_body_budget(c, csize_t(maxResidentBytes), (if spillDir.len > 0: cstring(spillDir) else: nil)), "cp2_set_body_budget")
