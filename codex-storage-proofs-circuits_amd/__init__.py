@@ -10,6 +10,7 @@ import ctypes
 import os
 import subprocess
 import sys
+import weakref
 
 import numpy as np
 
@@ -20,6 +21,17 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "codex_p2.h")
 
 CP2_OK = 0
 FELT = 32
+
+
+def _free_children(owner):
+    """Datasets and tree batches live inside their context (device buffers, streams, the scratch pool): whatever of them is
+    still alive when the context / multi handle is closed is freed FIRST, so a late `free()` (or a destructor) finds nothing
+    left to touch -- the C ABI's rule ("free every dataset made through a handle before the handle") kept by the binding."""
+    for child in list(getattr(owner, "_children", ())):
+        try:
+            child.free()
+        except Exception:
+            pass
 
 
 def _finalizing(_is_finalizing=sys.is_finalizing):
@@ -230,9 +242,11 @@ class Context:
         if st != CP2_OK:
             raise CodexP2Error(st, "cp2_init", self.L.cp2_strerror(st).decode())
         self.h = h
+        self._children = weakref.WeakSet()
 
     def close(self):
         if self.h:
+            _free_children(self)
             self.L.cp2_free(self.h)
             self.h = None
 
@@ -442,6 +456,7 @@ def make_config(maxDepth=32, maxLog2NSlots=8, cellSize=2048, blockSize=65536, nS
 class SlotTrees:
     def __init__(self, ctx, h):
         self.ctx, self.h = ctx, h
+        ctx._children.add(self)
 
     def free(self):
         if self.h:
@@ -499,6 +514,7 @@ class Dataset:
         else:
             ctx._ck(ctx.L.cp2_dataset_build(ctx.h, ctypes.byref(cfg), first_slot, n_local, ctypes.byref(h)), "cp2_dataset_build")
         self.h, self.first_slot, self.n_local = h, first_slot, n_local
+        ctx._children.add(self)
 
     def free(self):
         if self.h:
@@ -619,8 +635,10 @@ class _BorrowedContext(Context):
 
     def __init__(self, L, h):
         self.L, self.h = L, h
+        self._children = weakref.WeakSet()
 
     def close(self):
+        _free_children(self)
         self.h = None
 
 
@@ -638,9 +656,15 @@ class Multi:
         if st != CP2_OK:
             raise CodexP2Error(st, "cp2_multi_init", self.L.cp2_strerror(st).decode())
         self.h = h
+        self._children = weakref.WeakSet()
+        self._borrowed = {}
 
     def close(self):
         if self.h:
+            _free_children(self)
+            for c in self._borrowed.values():
+                c.close()
+            self._borrowed = {}
             self.L.cp2_multi_free(self.h)
             self.h = None
 
@@ -664,10 +688,12 @@ class Multi:
         return [self.L.cp2_multi_device(self.h, i) for i in range(self.count)]
 
     def ctx(self, i=0):
-        h = self.L.cp2_multi_ctx(self.h, i)
-        if not h:
-            raise CodexP2Error(-2, "cp2_multi_ctx")
-        return _BorrowedContext(self.L, ctypes.c_void_p(h))
+        if i not in self._borrowed:
+            h = self.L.cp2_multi_ctx(self.h, i)
+            if not h:
+                raise CodexP2Error(-2, "cp2_multi_ctx")
+            self._borrowed[i] = _BorrowedContext(self.L, ctypes.c_void_p(h))   # one object per context: it tracks what was made through it
+        return self._borrowed[i]
 
     def gather_mode(self):
         return self.L.cp2_multi_gather_mode(self.h).decode()
@@ -701,6 +727,7 @@ class MultiDataset:
         else:
             multi._ck(L.cp2_multi_dataset_build(multi.h, ctypes.byref(cfg), ctypes.byref(h)), "cp2_multi_dataset_build")
         self.h = h
+        multi._children.add(self)
 
     def free(self):
         if self.h:

@@ -826,3 +826,28 @@ def test_bigslots_streamed_one_slot_per_group_and_prefix_datasets(pkg, ctx, gold
             assert tsha(text) == want["json_sha256"] and len(text) == want["json_bytes"], (n_slots, slot)
         sd.free()
     ctx.trim()
+
+
+@pytest.mark.gpu
+def test_binding_frees_what_lives_in_a_handle_before_the_handle(pkg):
+    """The C ABI's rule -- every dataset made through a context / multi handle is freed before the handle -- is kept by the
+    binding itself: closing a handle frees what is still alive inside it, and a late free() or destructor touches nothing."""
+    c = dict(maxDepth=12, maxLog2NSlots=3, cellSize=128, blockSize=1024, nSlots=6, nCells=64, nSamples=4, seed=5)
+    cfg = pkg.make_config(**c)
+    ctx = pkg.Context(0)
+    ds, trees = ctx.dataset(cfg), ctx.slot_trees_fake(5, 0, 2, 128, 1024, 64)
+    text = ds.proof_input(3, 9).json()
+    pi = ds.proof_input(3, 9)                                   # a proof input owns its buffers: it outlives everything
+    ctx.close()
+    assert ds.h is None and trees.h is None
+    ds.free(); trees.free()                                     # nothing left to do, nothing touched
+    assert pi.json() == text
+    m = pkg.Multi([0, 0])
+    m.set_policy(pkg.GATHER_AUTO, 1)
+    mds = m.dataset(cfg)
+    inner = m.ctx(1).dataset(cfg)                               # made through a context the handle owns
+    assert m.ctx(1) is m.ctx(1)
+    assert mds.proof_input(3, 9).json() == text and inner.proof_input(3, 9).json() == text
+    m.close()
+    assert mds.h is None and inner.h is None
+    del mds, inner, ds, trees
