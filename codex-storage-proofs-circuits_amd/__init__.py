@@ -609,7 +609,7 @@ class Dataset:
         return [ProofInput(self.ctx, ctypes.c_void_p(h), self.cfg) for h in hs]
 
 
-GATHER_AUTO, GATHER_RCCL, GATHER_HOST = 0, 1, 2
+GATHER_AUTO, GATHER_RCCL, GATHER_HOST, GATHER_COPY = 0, 1, 2, 3
 
 
 def shard_range(n_items, rank, world):

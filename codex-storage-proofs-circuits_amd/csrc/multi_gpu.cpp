@@ -186,6 +186,7 @@ extern "C" int cp2_multi_init(const int* devices, int n_dev, cp2_multi** out) tr
   if (const char* e = std::getenv("CODEX_P2_GATHER")) {                                                      // "rccl" / "host" / anything else: auto
     if (std::strcmp(e, "rccl") == 0) m->gather = CP2_GATHER_RCCL;
     else if (std::strcmp(e, "host") == 0) m->gather = CP2_GATHER_HOST;
+    else if (std::strcmp(e, "copy") == 0) m->gather = CP2_GATHER_COPY;
   }
   *out = m.release();
   return CP2_OK;
@@ -212,7 +213,7 @@ extern "C" const char* cp2_multi_last_error(const cp2_multi* m) { return m ? m->
 extern "C" const char* cp2_multi_gather_mode(const cp2_multi* m) { return m ? m->gather_note.c_str() : "no handle"; }
 
 extern "C" int cp2_multi_set_policy(cp2_multi* m, int gather, uint64_t min_cells_per_device) {
-  if (!m || gather < CP2_GATHER_AUTO || gather > CP2_GATHER_HOST) return CP2_ERR_INVALID;
+  if (!m || gather < CP2_GATHER_AUTO || gather > CP2_GATHER_COPY) return CP2_ERR_INVALID;
   m->gather = gather;
   m->min_cells = min_cells_per_device;
   return CP2_OK;
@@ -297,7 +298,9 @@ struct Exchanged {
 };
 
 // THE exchange step: every shard's roots to every device.  RCCL (device to device) when every shard sits on its own device and
-// librccl loads; host memory otherwise.  One shard and no RCCL by name: nothing moves.
+// librccl loads; host memory otherwise; by name also plain device-to-device copies (CP2_GATHER_COPY: the RCCL path's buffers,
+// layout and compaction with the collective written out as peer copies -- no library, any mix of devices).  One shard and no
+// RCCL by name: nothing moves.
 int exchange_roots(cp2_multi* m, const std::vector<RootsPart>& parts, uint64_t n, Exchanged& ex) {
   const size_t world = parts.size();
   ex.dev.assign(world, nullptr);
@@ -313,7 +316,8 @@ int exchange_roots(cp2_multi* m, const std::vector<RootsPart>& parts, uint64_t n
     for (size_t j = 0; j < i; ++j)
       if (parts[i].ctx->device == parts[j].ctx->device) distinct = false;
   std::string why;
-  bool use_rccl = m->gather != CP2_GATHER_HOST;
+  const bool use_copy = m->gather == CP2_GATHER_COPY;   // device-to-device copies, pair by pair: same layout and compaction as RCCL, no library
+  bool use_rccl = m->gather != CP2_GATHER_HOST && !use_copy;
   if (use_rccl && !distinct) { use_rccl = false; why = "a device holds more than one shard"; }
   if (use_rccl && !Rccl::get().ok()) { use_rccl = false; why = Rccl::get().why; }
   if (use_rccl) {
@@ -335,8 +339,7 @@ int exchange_roots(cp2_multi* m, const std::vector<RootsPart>& parts, uint64_t n
     m->err = "RCCL gather requested but unavailable: " + why;
     return CP2_ERR_INVALID;
   }
-  if (use_rccl) {
-    Rccl& r = Rccl::get();
+  if (use_rccl || use_copy) {
     uint64_t max_rows = 0;
     bool even = true;
     for (auto& p : parts) { max_rows = std::max(max_rows, p.count); even = even && p.count == parts[0].count; }
@@ -348,16 +351,36 @@ int exchange_roots(cp2_multi* m, const std::vector<RootsPart>& parts, uint64_t n
       CP2_TRY(ex.gath[i].scratch(ctx, world * max_rows * 32));
       CP2_HIP(ctx, hipMemcpyAsync(ex.gath[i].u8() + i * max_rows * 32, parts[i].d_roots, parts[i].count * 32, hipMemcpyDeviceToDevice, ctx->stream));
     }
-    ncclResult_t e = r.GroupStart();
-    for (size_t i = 0; i < world && e == ncclSuccess; ++i)
-      e = r.AllGather(ex.gath[i].u8() + i * max_rows * 32, ex.gath[i].p, max_rows * 32, ncclUint8, m->comms[i], parts[i].ctx->stream);   // in place
-    ncclResult_t e2 = r.GroupEnd();
-    if (e == ncclSuccess) e = e2;
-    if (e != ncclSuccess) {
-      m->err = std::string("ncclAllGather: ") + r.GetErrorString(e);
-      return CP2_ERR_HIP;
+    if (use_rccl) {
+      Rccl& r = Rccl::get();
+      ncclResult_t e = r.GroupStart();
+      for (size_t i = 0; i < world && e == ncclSuccess; ++i)
+        e = r.AllGather(ex.gath[i].u8() + i * max_rows * 32, ex.gath[i].p, max_rows * 32, ncclUint8, m->comms[i], parts[i].ctx->stream);   // in place
+      ncclResult_t e2 = r.GroupEnd();
+      if (e == ncclSuccess) e = e2;
+      if (e != ncclSuccess) {
+        m->err = std::string("ncclAllGather: ") + r.GetErrorString(e);
+        return CP2_ERR_HIP;
+      }
+      m->gather_note = "rccl (in-place ncclAllGather of " + std::to_string(max_rows * 32) + " bytes per rank over " + std::to_string(world) + " devices)";
+    } else {
+      // the same all-gather written out as world x (world - 1) peer copies: every shard's row block, once it is staged, into the
+      // same place of every other context's buffer, on the RECEIVING context's stream (what consumes it there follows in order)
+      for (auto& p : parts) {
+        CP2_HIP(p.ctx, hipSetDevice(p.ctx->device));
+        CP2_HIP(p.ctx, hipStreamSynchronize(p.ctx->stream));
+      }
+      for (size_t i = 0; i < world; ++i) {
+        cp2_ctx* ctx = parts[i].ctx;
+        CP2_HIP(ctx, hipSetDevice(ctx->device));
+        for (size_t j = 0; j < world; ++j)
+          if (j != i && parts[j].count)
+            CP2_HIP(ctx, hipMemcpyPeerAsync(ex.gath[i].u8() + j * max_rows * 32, ctx->device, ex.gath[j].u8() + j * max_rows * 32, parts[j].ctx->device,
+                                            parts[j].count * 32, ctx->stream));
+      }
+      m->gather_note = "copy (" + std::to_string(world * (world - 1)) + " device-to-device copies of at most " + std::to_string(max_rows * 32) + " bytes over " +
+                       std::to_string(world) + " contexts)";
     }
-    m->gather_note = "rccl (in-place ncclAllGather of " + std::to_string(max_rows * 32) + " bytes per rank over " + std::to_string(world) + " devices)";
     for (size_t i = 0; i < world; ++i) {
       cp2_ctx* ctx = parts[i].ctx;
       ex.dev[i] = ex.gath[i].p;
@@ -368,6 +391,12 @@ int exchange_roots(cp2_multi* m, const std::vector<RootsPart>& parts, uint64_t n
         CP2_HIP(ctx, hipMemcpyAsync(ex.all[i].u8() + parts[r2].first * 32, ex.gath[i].u8() + r2 * max_rows * 32, parts[r2].count * 32,
                                     hipMemcpyDeviceToDevice, ctx->stream));
       ex.dev[i] = ex.all[i].p;
+    }
+    // the exchange is COMPLETE when this returns: a context's buffers are read by its peers (RCCL kernels, peer copies), so none
+    // of them may go back to its pool on the strength of its own stream alone
+    for (auto& p : parts) {
+      CP2_HIP(p.ctx, hipSetDevice(p.ctx->device));
+      CP2_HIP(p.ctx, hipStreamSynchronize(p.ctx->stream));
     }
     ex.on_device = true;
     return CP2_OK;

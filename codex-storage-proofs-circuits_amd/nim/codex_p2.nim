@@ -295,7 +295,7 @@ proc engineDevices*(): int =
   int(cp2_multi_count(multi()))
 
 proc engineGatherMode*(): string =
-  ## what the last build's exchange of slot roots went through: "rccl (...)", "host (<why>)", "none (one shard ...)"
+  ## what the last build's exchange of slot roots went through: "rccl (...)", "host (<why>)", "copy (...)", "none (one shard ...)"
   $cp2_multi_gather_mode(multi())
 
 proc engineSetSplit*(unitsPerSlot: int) =
@@ -303,7 +303,7 @@ proc engineSetSplit*(unitsPerSlot: int) =
   check(cp2_multi_set_split(multi(), int64(unitsPerSlot)), "cp2_multi_set_split")
 
 proc engineSetPolicy*(gather: int, minCellsPerDevice: uint64) =
-  ## 0 auto / 1 RCCL / 2 host gather; cells of hashing a device must have to get a shard (0: one hash-kernel residency)
+  ## 0 auto / 1 RCCL / 2 host gather / 3 device-to-device copies; cells of hashing a device must have to get a shard (0: one hash-kernel residency)
   check(cp2_multi_set_policy(multi(), cint(gather), minCellsPerDevice), "cp2_multi_set_policy")
 
 iterator contexts(): Cp2Ctx =

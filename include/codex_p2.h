@@ -325,7 +325,7 @@ int cp2_write_circom_main(const cp2_config* cfg, const char* path);
  * the caller makes the same calls on a one-GPU and on an eight-GPU node.
  *   - librccl is opened at run time, and only when at least two distinct devices hold a shard.  Without it, or when a device
  *     index repeats (two contexts on one device), the roots are gathered through host memory instead (1 MiB at 32 768 slots);
- *     cp2_multi_gather_mode names what the last build did ("rccl (...)", "host (<why>)", "none (one shard ...)").
+ *     cp2_multi_gather_mode names what the last build did ("rccl (...)", "host (<why>)", "copy (...)", "none (one shard ...)").
  *   - Small datasets use fewer devices: a device gets a shard only when there is at least `min_cells_per_device` cells of
  *     hashing for it (default: one residency of the hash kernel, 768 x 256 cells -- a device with less finishes no sooner),
  *     so the reference's default run (11 slots x 512 cells, workflow/params.sh) stays on one GPU and pays one context.
@@ -340,7 +340,7 @@ int cp2_write_circom_main(const cp2_config* cfg, const char* path);
  *     (streamed builds keep whole slots); cp2_multi_set_split / CODEX_P2_SPLIT override (1 = whole slots only). */
 typedef struct cp2_multi cp2_multi;
 typedef struct cp2_multi_dataset cp2_multi_dataset;
-enum { CP2_GATHER_AUTO = 0, CP2_GATHER_RCCL = 1, CP2_GATHER_HOST = 2 };
+enum { CP2_GATHER_AUTO = 0, CP2_GATHER_RCCL = 1, CP2_GATHER_HOST = 2, CP2_GATHER_COPY = 3 };
 /* devices: n_dev HIP device indices (an index may repeat: several contexts on one device).  n_dev = 0: the environment
  * variable CODEX_P2_GPUS ("<count>" = the first <count> visible devices, or a comma-separated index list), else every
  * visible gfx950 device.  CODEX_P2_GPUS, CODEX_P2_MIN_CELLS and CODEX_P2_SPLIT are read here; a value that is not what
@@ -354,7 +354,9 @@ cp2_ctx* cp2_multi_ctx(cp2_multi* m, int i);              /* NULL when the devic
 const char* cp2_multi_last_error(const cp2_multi* m);
 const char* cp2_multi_gather_mode(const cp2_multi* m);
 /* gather: CP2_GATHER_AUTO (RCCL when possible, else host), CP2_GATHER_RCCL (fail with CP2_ERR_INVALID when impossible),
- * CP2_GATHER_HOST; cp2_multi_init reads the environment variable CODEX_P2_GATHER ("rccl" / "host") as the initial value.  min_cells_per_device: 0 = the default above (or the environment variable CODEX_P2_MIN_CELLS, read by
+ * CP2_GATHER_HOST, CP2_GATHER_COPY (the all-gather written out as device-to-device copies, hipMemcpyPeerAsync pair by pair,
+ * through the RCCL path's own buffers, padded layout and compaction: no library, any mix of devices, repeated ones included);
+ * cp2_multi_init reads the environment variable CODEX_P2_GATHER ("rccl" / "host" / "copy") as the initial value.  min_cells_per_device: 0 = the default above (or the environment variable CODEX_P2_MIN_CELLS, read by
  * cp2_multi_init); 1 = always spread over every device. */
 int cp2_multi_set_policy(cp2_multi* m, int gather, uint64_t min_cells_per_device);
 /* units per slot for cp2_multi_dataset_build: 0 = choose (above; or the environment variable CODEX_P2_SPLIT), 1 = whole slots

@@ -38,7 +38,8 @@ def _threads():
 
 
 @pytest.mark.parametrize("name,devices,gather", [("cheap", [0], "rccl"), ("cheap", [0, 0], "auto"), ("odd", [0, 0], "auto"),
-                                                  ("odd", [0, 0, 0], "host"), ("cheap", [0], "auto")])
+                                                  ("odd", [0, 0, 0], "host"), ("cheap", [0], "auto"),
+                                                  ("odd", [0, 0, 0], "copy"), ("cheap", [0, 0], "copy"), ("odd", [0] * 7, "copy")])
 def test_multi_dataset_at_config5_scale_vs_oracle_fixture(pkg, golden, name, devices, gather):
     """32 768 / 32 767 slots (maxLog2NSlots = 15) through cp2_multi_dataset_build: sha256 over all slot roots, the dataset
     root as EVERY shard's device computed it, input.json byte-exact (sha256 of the oracle's text) on every shard edge."""
@@ -47,7 +48,7 @@ def test_multi_dataset_at_config5_scale_vs_oracle_fixture(pkg, golden, name, dev
     cfg = pkg.make_config(**c)
     m = pkg.Multi(devices)
     assert m.count == len(devices) and m.devices() == devices
-    m.set_policy({"auto": pkg.GATHER_AUTO, "rccl": pkg.GATHER_RCCL, "host": pkg.GATHER_HOST}[gather], 0)
+    m.set_policy({"auto": pkg.GATHER_AUTO, "rccl": pkg.GATHER_RCCL, "host": pkg.GATHER_HOST, "copy": pkg.GATHER_COPY}[gather], 0)
     ds = m.dataset(cfg)
     shards = ds.shards()
     world = len(devices)
@@ -57,6 +58,10 @@ def test_multi_dataset_at_config5_scale_vs_oracle_fixture(pkg, golden, name, dev
         assert mode.startswith("rccl"), mode                     # a one-rank communicator: the RCCL code path itself ran
     elif world == 1:
         assert mode.startswith("none"), mode
+    elif gather == "copy":
+        # device-to-device copies through the RCCL path's own buffers: with 32 767 slots the shards differ by one row, so the
+        # padded layout AND its compaction run here (the only parts of the RCCL path a one-GPU box cannot reach through RCCL)
+        assert mode.startswith("copy (%d device-to-device copies" % (world * (world - 1))), mode
     else:
         assert mode.startswith("host") and ("more than one shard" in mode or "requested" in mode), mode
     assert sha(ds.slot_roots()) == g["slot_roots_sha256"]
@@ -100,6 +105,13 @@ def test_multi_over_every_real_device_rccl_vs_oracle_fixture(pkg, golden, name):
     for slot in (0, n - 1):
         assert tsha(ds.proof_input(slot, g["entropy"]).json()) == g["inputs"][str(slot)]["json_sha256"]
     ds.free()
+    m.set_policy(pkg.GATHER_COPY, 1)                              # the same exchange as peer copies between the real devices
+    ds = m.dataset(pkg.make_config(**c))
+    assert m.gather_mode().startswith("copy") and sha(ds.slot_roots()) == g["slot_roots_sha256"]
+    for i in range(world):
+        assert hexroot(ds.shard_root(i)) == g["dataset_root_hex"], i
+    ds.free()
+    m.set_policy(pkg.GATHER_RCCL, 1)
     # few, large slots over all devices: the reference's default run cut by units, RCCL carrying the unit roots
     m0 = golden("proof_inputs.json")["inputs"]["params_default"]
     m.set_split(0)
@@ -264,7 +276,8 @@ def test_cli_twin_spreads_over_contexts_without_a_new_flag(pkg, golden, tmp_path
     args = ["--depth=32", "--maxslots=256", "--cellsize=2048", "--blocksize=65536", "--nsamples=5", "--entropy=1234567",
             "--seed=12345", "--nslots=11", "--ncells=512", "--index=3", "--field=bn254", "--hash=poseidon2"]
     want = golden("input_params_default.json")
-    for env_extra, marker in (({}, "none"), ({"CODEX_P2_GPUS": "0,0", "CODEX_P2_MIN_CELLS": "1"}, "host"), ({"CODEX_P2_GPUS": "1"}, "none")):
+    for env_extra, marker in (({}, "none"), ({"CODEX_P2_GPUS": "0,0", "CODEX_P2_MIN_CELLS": "1"}, "host"), ({"CODEX_P2_GPUS": "1"}, "none"),
+                              ({"CODEX_P2_GPUS": "0,0,0", "CODEX_P2_MIN_CELLS": "1", "CODEX_P2_GATHER": "copy"}, "copy")):
         out = str(tmp_path / ("input_%s.json" % marker))
         r = subprocess.run([pkg.CLI_PATH] + args + ["-v", "--output=" + out], capture_output=True, text=True, timeout=300,
                            env=dict(os.environ, CP2_TRACE="1", **env_extra))

@@ -40,7 +40,7 @@ while time.time() - t0 < budget:
     m = handles[n_ctx]
     # min cells per device 1: every context gets a shard (as many as there are slots); a random larger value: fewer shards
     min_cells = int(rng.choice([1, 1, 1, nc * max(1, n_slots // 2), 1 << 30]))
-    m.set_policy(int(rng.choice([pkg.GATHER_AUTO, pkg.GATHER_HOST])), min_cells)
+    m.set_policy(int(rng.choice([pkg.GATHER_AUTO, pkg.GATHER_HOST, pkg.GATHER_COPY])), min_cells)
     split = int(rng.choice([2, 4, 8] if UNITS else [0, 0, 1, 2, 4]))   # choose / whole slots only / every slot cut into 2, 4 (8) units
     m.set_split(split)
     keep = int(rng.choice([-1, -1, 0, 2]))                     # now and then roots-only / compact datasets
