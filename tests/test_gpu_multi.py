@@ -39,7 +39,7 @@ def _threads():
 
 @pytest.mark.parametrize("name,devices,gather", [("cheap", [0], "rccl"), ("cheap", [0, 0], "auto"), ("odd", [0, 0], "auto"),
                                                   ("odd", [0, 0, 0], "host"), ("cheap", [0], "auto"),
-                                                  ("odd", [0, 0, 0], "copy"), ("cheap", [0, 0], "copy"), ("odd", [0] * 7, "copy")])
+                                                  ("odd", [0, 0, 0], "copy"), ("cheap", [0, 0], "copy"), ("odd", [0] * 5, "copy")])
 def test_multi_dataset_at_config5_scale_vs_oracle_fixture(pkg, golden, name, devices, gather):
     """32 768 / 32 767 slots (maxLog2NSlots = 15) through cp2_multi_dataset_build: sha256 over all slot roots, the dataset
     root as EVERY shard's device computed it, input.json byte-exact (sha256 of the oracle's text) on every shard edge."""
