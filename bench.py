@@ -854,6 +854,40 @@ def inprocess_child(n_dev):
         ds = m.dataset(cfg)                        # a second build on the warm handle: contexts, code objects and communicators exist
         t4 = time.perf_counter()
         ds.free()
+        # N > 1: the exchange of slot roots every way the library has (RCCL all-gather, peer copies, host memory), each asked
+        # for BY NAME so that nothing falls back silently -- what each did, how long the warm build took, and whether every
+        # device ended with the fixture's dataset root; then a dataset of few, large slots (11 x 2^18 cells), which is cut by
+        # units, against the same dataset built whole on the first device
+        ways = {}
+        if n_dev > 1:
+            for name, policy in (("rccl", pkg.GATHER_RCCL), ("copy", pkg.GATHER_COPY), ("host", pkg.GATHER_HOST)):
+                try:
+                    m.set_policy(policy, 0)
+                    ta = time.perf_counter()
+                    d2 = m.dataset(cfg)
+                    tb = time.perf_counter()
+                    r2 = d2.root()
+                    ok = bool((r2 == root).all()) and all(bool((d2.shard_root(i) == root).all()) for i in range(len(d2.shards())))
+                    ways[name] = {"mode": m.gather_mode(), "warm_build_s": round(tb - ta, 4), "shards": len(d2.shards()), "every_device_has_the_root": ok}
+                    d2.free()
+                except Exception as e:            # e.g. RCCL by name on a rehearsal box whose contexts share one device: refused, with the reason
+                    ways[name] = {"error": str(e)[:300]}
+            try:
+                m.set_policy(pkg.GATHER_AUTO, 0)
+                few = pkg.make_config(maxDepth=32, maxLog2NSlots=8, cellSize=2048, blockSize=65536, nSlots=11, nCells=1 << 18, nSamples=100, seed=777)
+                ta = time.perf_counter()
+                d3 = m.dataset(few)
+                tb = time.perf_counter()
+                whole = m.ctx(0).dataset(few)
+                tc = time.perf_counter()
+                text3 = d3.proof_input(10, 424242).json()
+                ways["few_large_slots"] = {"workload": "11 slots x 2^18 cells x 2048 B (5.9 GB)", "units_per_slot": d3.units_per_slot, "shards": len(d3.shards()),
+                                           "mode": m.gather_mode(), "build_s": round(tb - ta, 4), "one_device_build_s": round(tc - tb, 4),
+                                           "root_and_input_json_equal_one_device": bool((d3.root() == whole.root()).all()) and text3 == whole.proof_input(10, 424242).json()}
+                whole.free()
+                d3.free()
+            except Exception as e:
+                ways["few_large_slots"] = {"error": str(e)[:300]}
     perms = n_slots * (35 * n_cells - 1) + (n_slots - 1) * n_dev + 200
     root_hex = root.tobytes()[::-1].hex()
     gold = None
@@ -865,7 +899,7 @@ def inprocess_child(n_dev):
     res = {"devices": n_dev, "shards": n_shards, "gather": m.gather_mode(), "handle_init_s": round(t1 - t0, 4),
            "first_build_s": round(t2 - t1, 4), "warm_build_s": round(t4 - t3, 4), "one_proof_input_json_s": round(t3 - t2, 4),
            "perms_per_s_first": perms / (t2 - t0), "perms_per_s_warm": perms / (t4 - t3), "slots_per_s_warm": n_slots / (t4 - t3),
-           "all_devices_agree": bool(agree), "dataset_root_hex": root_hex,
+           "all_devices_agree": bool(agree), "dataset_root_hex": root_hex, "exchange_every_way": ways or None,
            "equals_oracle_fixture": (root_hex == gold["dataset_root_hex"] and
                                      hashlib.sha256(text.encode()).hexdigest() == gold["inputs"][str(n_slots - 1)]["json_sha256"]) if gold else None}
     m.close()
