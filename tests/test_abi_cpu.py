@@ -211,3 +211,47 @@ def test_bench_self_spawn_fails_fast_without_gpus(tmp_path):
                        capture_output=True, text=True, timeout=240, env=dict(os.environ, TMPDIR=str(tmp_path)))
     assert r.returncode == 1 and r.stdout == "" and time.time() - t < 120
     assert glob.glob(str(tmp_path / "cp2_bench_rdv_*")) == []
+
+
+def test_multi_plan_and_shard_range_properties(pkg):
+    """Property test (hypothesis) of the host-only sharding arithmetic, cp2_multi_plan + cp2_shard_range: whatever the dataset
+    and the device count, the plan uses between one and all devices, never more shards than there are items to deal, cuts
+    slots only into powers of two of at least two whole blocks, never makes the balance worse by cutting, honours "whole slots
+    only", and the ranges tile the items contiguously with sizes that differ by at most one."""
+    from hypothesis import given, settings, strategies as st
+
+    def imbalance(items, world):
+        return -(-items // world) * world / items
+
+    @settings(max_examples=400, deadline=None)
+    @given(n_slots=st.integers(1, 5000), log_cells=st.integers(1, 26), log_cpb=st.integers(0, 5), n_dev=st.integers(1, 16),
+           min_cells=st.sampled_from([0, 1, 1 << 10, 1 << 20, 1 << 34]), split=st.sampled_from([0, 0, 1, 2, 8, 64]),
+           pow2_cells=st.booleans())
+    def check(n_slots, log_cells, log_cpb, n_dev, min_cells, split, pow2_cells):
+        cpb = 1 << min(log_cpb, log_cells)
+        n_cells = 1 << log_cells
+        if not pow2_cells:
+            n_cells = cpb * 3                                                 # a geometry that is never cut
+        cfg = pkg.make_config(maxDepth=32, maxLog2NSlots=16, cellSize=64, blockSize=64 * cpb, nSlots=n_slots, nCells=n_cells, nSamples=5, seed=1)
+        world, units = pkg.multi_plan(cfg, n_dev, min_cells_per_device=min_cells, units_per_slot=split)
+        assert 1 <= world <= n_dev and units >= 1 and units & (units - 1) == 0
+        assert world <= n_slots * units
+        if split == 1 or not pow2_cells:
+            assert units == 1
+        if units > 1:
+            assert n_cells % units == 0 and (n_cells // units) // cpb >= 2    # a unit is at least two whole blocks
+            if split == 0:                                                    # chosen, not forced: cutting never makes the balance worse
+                assert imbalance(n_slots * units, world) <= imbalance(n_slots, world) + 1e-12
+        if split > 1 and pow2_cells and n_cells // cpb >= 2 * split:
+            assert units == split                                             # a forced split the geometry allows is taken
+        need = min_cells or 768 * 256
+        assert world <= max(1, -(-n_slots * n_cells // need))                 # a device gets a shard only with `need` cells of hashing for it
+        items, covered, sizes = n_slots * units, 0, []
+        for r in range(world):
+            first, count = pkg.shard_range(items, r, world)
+            assert first == covered
+            covered += count
+            sizes.append(count)
+        assert covered == items and max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+    check()
