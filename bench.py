@@ -44,6 +44,7 @@ import glob
 import json
 import os
 import socket
+import shutil
 import subprocess
 import sys
 import time
@@ -747,6 +748,9 @@ def cpu_baseline(C, np, torch, dev):
                       "%d states on %d threads; single-thread rate on %d states reported beside it; states from the GPU leg's own generator "
                       "(uniform in [0, r))" % (nm, cores, n1),
             "single_thread_value": single,
+            # "probe `nim --version` there" -- the reference is Nim over un-vendored packages; with no compiler on
+            # the box there is nothing of it to time, and the port stands in
+            "reference_toolchain_on_this_box": {"nim": shutil.which("nim"), "nimble": shutil.which("nimble")},
             "slot_root_2p16_cells": {"seconds": round(slot_s, 3), "perms_per_s": (35 * nc3 - 1) / slot_s,
                                      "note": "config 3 scaled to 2^16 cells of 2048 B (fake data generated, hashed and treed on %d threads)" % cores}}
 
