@@ -17,9 +17,7 @@ def test_device_arithmetic_on_host_with_sanitizers(tmp_path):
     assert ", 0 mismatches, no bound violations" in r.stdout
 
 
-def _build_text_check(tmp_path, sanitize=("-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"), name="host_text_check"):
-    import importlib
-    pkg = importlib.import_module("codex-storage-proofs-circuits_amd")
+def _build_text_check(pkg, tmp_path, sanitize=("-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"), name="host_text_check"):
     libdir = os.path.dirname(pkg.LIB_PATH)
     exe = str(tmp_path / name)
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", *sanitize,
@@ -37,7 +35,7 @@ def _run(exe, *args):
     return r.stdout
 
 
-def test_host_text_and_body_store_with_sanitizers(tmp_path):
+def test_host_text_and_body_store_with_sanitizers(pkg, tmp_path):
     """The product's host-side hot loops -- the byte-exact JSON formatter (csrc/json_text.hpp; json/bn254.nim:57-74,
     json/shared.nim:17-25, types/bn254.nim:29-43) and the streamed build's body store with its private spill files
     (csrc/body_store.hpp) -- compiled from the product's own headers under AddressSanitizer + UBSan.  No GPU."""
@@ -45,7 +43,7 @@ def test_host_text_and_body_store_with_sanitizers(tmp_path):
     import sys
     sys.path.insert(0, ROOT)
     from oracle import poseidon2_ref as ref
-    exe = _build_text_check(tmp_path)
+    exe = _build_text_check(pkg, tmp_path)
 
     # 1. 256-bit integers to decimal: every edge of the base-10^19 chunking and of the reciprocal division, then random
     rnd = random.Random(20261004)
@@ -91,9 +89,9 @@ def test_host_text_and_body_store_with_sanitizers(tmp_path):
     assert list(spill.iterdir()) == []
 
 
-def test_body_store_workers_with_thread_sanitizer(tmp_path):
+def test_body_store_workers_with_thread_sanitizer(pkg, tmp_path):
     """put() runs on the formatting workers: the same harness under ThreadSanitizer (four workers spilling at once)."""
-    exe = _build_text_check(tmp_path, sanitize=("-fsanitize=thread",), name="host_text_check_tsan")
+    exe = _build_text_check(pkg, tmp_path, sanitize=("-fsanitize=thread",), name="host_text_check_tsan")
     spill = tmp_path / "spill"
     spill.mkdir()
     r = subprocess.run([exe, "store", str(spill)], capture_output=True, timeout=600)
