@@ -8,6 +8,15 @@
 `python bench.py --gpus N` with N > 1 and no launcher spawns the N rank processes itself (before anything touches the
 GPU) and relays rank 0's JSON line.
 
+Nothing after the timed region can lose the line (section "Orchestration" below): everything after the headline runs under ONE
+deadline (--extra-budget-s, default 240 s: a leg starts only if its worst case fits what is left, else it is recorded as
+"skipped: budget"); at N > 1 every wait after the headline is a bounded wait on the rendezvous store and the one data-path
+collective of the legs (the gather of slot roots) is bounded too, so a dead or hung rank costs seconds and is named in
+extra.rank_failures; a watchdog thread prints the line with whatever has finished when the deadline passes or when the launcher
+sends SIGTERM (what torchrun does to the surviving ranks when one dies); the line is printed BEFORE the process group is torn
+down.  BENCH_INJECT=rank_exit|rank_hang|gather_error[@rank]|child_hang injects those faults (rehearsals only:
+profiles/r05_bench_2rank_inject_*.json).
+
 A "step" is one pass of the hot path over one batch: the batched permutation kernel over 2^24 states
 (BASELINE.json configs[1], 1.5 GiB in + 1.5 GiB out, already resident in HBM when the clock starts; every element
 uniform in [0, r) by rejection).  With N ranks every rank runs the same-sized batch on its own GPU (weak scaling, no
@@ -72,48 +81,417 @@ def _stdout_to_stderr():
         os.close(saved)
 
 
-def spawn_ranks(n):
+# ======================================================================================================================
+# Orchestration: nothing after the headline may lose the headline.
+#
+# At N > 1 the legs after the timed region have never run on two real devices (this pipeline's GPU boxes hold one), so the
+# first N-GPU run is also their first run.  Everything below exists so that such a run cannot lose its one JSON line and
+# names what went wrong instead:
+#   Budget     one deadline for everything after the headline (--extra-budget-s): a leg starts only if its worst case fits
+#              what is left, else it is recorded as "skipped: budget".
+#   Coord      every N > 1 wait after the headline is a BOUNDED wait on the rendezvous store (torchrun's TCPStore, or the file
+#              store of self-spawned ranks), never dist.barrier(): a dead or hung rank costs seconds and is named in
+#              extra.rank_failures; rank 0 decides which legs run and publishes the decision, so all ranks take the same path.
+#   BoundedDist  the data-path collectives of the legs (the gather of slot roots) run async with a bounded wait; one that does
+#              not complete is named, and no later collective is attempted on the abandoned communicator.
+#   Lifeline   a watchdog thread: when the deadline passes, or SIGTERM arrives (torchrun ends the surviving ranks that way when
+#              one rank dies), rank 0 prints the line with what it has -- the headline and every finished leg -- and exits.
+#              The main thread may be stuck inside a collective or a HIP call at that moment; the thread is not.
+# tests/test_bench_orchestration.py exercises all four on the CPU (gloo, world 2, injected faults).
+# ======================================================================================================================
+class Budget:
+    """One deadline for everything after the headline."""
+
+    def __init__(self, total_s, clock=time.monotonic):
+        self.total_s, self.clock, self.t0 = float(total_s), clock, clock()
+
+    def elapsed(self):
+        return self.clock() - self.t0
+
+    def remaining(self):
+        return max(0.0, self.total_s - self.elapsed())
+
+    def fits(self, worst_s):
+        return float(worst_s) <= self.remaining()
+
+    def child_timeout(self, cap_s=120.0, reserve_s=5.0):
+        """Timeout for a child process: what is left (minus a reserve for printing the line), never more than `cap_s`."""
+        return max(0.0, min(float(cap_s), self.remaining() - reserve_s))
+
+
+def leg_decision(budget, worst_s, needs_all_ranks, failed_ranks, needs_collective=False, collectives_broken=False):
+    """"go", or the reason a leg is skipped -- pure arithmetic (rank 0 evaluates it, every rank follows it)."""
+    if needs_all_ranks and failed_ranks:
+        return "skipped: rank(s) %s failed earlier" % sorted(failed_ranks)
+    if needs_collective and collectives_broken:
+        return "skipped: a collective did not complete earlier (the communicator is abandoned)"
+    if not budget.fits(worst_s):
+        return "skipped: budget (worst case %.0f s, %.0f s left of %.0f)" % (worst_s, budget.remaining(), budget.total_s)
+    return "go"
+
+
+class CollectiveTimeout(RuntimeError):
+    pass
+
+
+class Coord:
+    """Bounded rank coordination through the rendezvous store.  world == 1 (store None): everything is immediate."""
+
+    def __init__(self, store, rank, world, sync_timeout_s=30.0, poll_s=0.002, dead_dir=None, clock=time.monotonic, prefix="cp2b"):
+        self.store, self.rank, self.world = store, rank, world
+        self.sync_timeout_s, self.poll_s, self.dead_dir, self.clock, self.prefix = sync_timeout_s, poll_s, dead_dir, clock, prefix
+        self.failures = {}             # rank -> why (first reason wins); a failed rank is never waited for again
+        self.collectives_broken = False
+        self.bail_name = None          # set by LegRunner while a leg runs: a rank that has posted this (its "leg done", i.e. it left
+                                       # the leg early with an error) is not waited for inside the leg -- and is NOT a failed rank
+        self._seq = {}
+
+    def _key(self, name, rank=None):
+        return "%s/%s" % (self.prefix, name) if rank is None else "%s/%s/%d" % (self.prefix, name, rank)
+
+    def _uniq(self, name):
+        """The same name used twice (a leg run in a loop) must not see the previous round's keys."""
+        n = self._seq.get(name, 0)
+        self._seq[name] = n + 1
+        return name if n == 0 else "%s#%d" % (name, n)
+
+    def _poll_dead(self):
+        """Self-spawned ranks: the parent drops a marker file when a rank process exits non-zero."""
+        if not self.dead_dir:
+            return
+        for r in range(self.world):
+            if r not in self.failures:
+                p = os.path.join(self.dead_dir, "dead_%d" % r)
+                if os.path.exists(p):
+                    try:
+                        why = open(p).read().strip() or "exited"
+                    except OSError:
+                        why = "exited"
+                    self.failures[r] = "rank process %s" % why
+
+    def post(self, name, value="ok", rank_key=True):
+        if self.store is not None:
+            self.store.set(self._key(name, self.rank if rank_key else None), str(value))
+
+    def collect(self, name, timeout_s=None, ranks=None):
+        """Wait (bounded) until every rank in `ranks` (default: all) has posted `name`.  Returns ({rank: value}, [missing]).
+        Ranks that already failed are not waited for; ranks that do not show up are recorded in self.failures."""
+        if self.store is None:
+            return {}, []
+        timeout_s = self.sync_timeout_s if timeout_s is None else timeout_s
+        ranks = list(range(self.world)) if ranks is None else list(ranks)
+        got, deadline = {}, self.clock() + timeout_s
+        while True:
+            self._poll_dead()
+            for r in ranks:
+                if r not in got and r not in self.failures and self.store.check([self._key(name, r)]):
+                    got[r] = self.store.get(self._key(name, r)).decode()
+            pending = [r for r in ranks if r not in got and r not in self.failures]
+            if self.bail_name and name != self.bail_name:
+                pending = [r for r in pending if not self.store.check([self._key(self.bail_name, r)])]
+            if not pending:
+                break
+            if self.clock() >= deadline:
+                for r in pending:
+                    self.failures[r] = "silent: nothing posted for '%s' within %.0f s" % (name, timeout_s)
+                break
+            time.sleep(self.poll_s)
+        return got, [r for r in ranks if r not in got]
+
+    def decide(self, name, fn, timeout_s=None):
+        """Rank 0 waits (bounded) for every live rank to arrive at `name`, evaluates fn() and publishes the result; the other
+        ranks wait (bounded) for it.  No word from rank 0 in time: "skipped: no decision from rank 0"."""
+        if self.store is None:
+            return fn()
+        name = self._uniq(name)
+        timeout_s = self.sync_timeout_s if timeout_s is None else timeout_s
+        self.post(name + "/at")
+        if self.rank == 0:
+            self.collect(name + "/at", timeout_s)
+            d = str(fn())
+            self.post(name + "/go", d, rank_key=False)
+            return d
+        deadline = self.clock() + 2 * timeout_s + 5.0          # rank 0 may itself be waiting `timeout_s` for a silent rank
+        key = self._key(name + "/go")
+        while not self.store.check([key]):
+            self._poll_dead()
+            if 0 in self.failures or self.clock() >= deadline:
+                self.failures.setdefault(0, "silent: no decision for '%s'" % name)
+                return "skipped: no decision from rank 0"
+            time.sleep(self.poll_s)
+        return self.store.get(key).decode()
+
+    def all_ok(self, name, err=None, timeout_s=None):
+        """Every rank says whether its local step worked; raises (on every rank alike) when one did not or stayed silent --
+        BEFORE anyone enters the collective that would otherwise wait for it."""
+        if self.store is None:
+            if err:
+                raise err
+            return
+        self.post(name, "ok" if err is None else "error: %r" % (err,))
+        got, missing = self.collect(name, timeout_s)
+        bad = {r: v for r, v in got.items() if v != "ok"}
+        if bad or missing:
+            raise RuntimeError("step '%s': %s" % (name, "; ".join(["rank %d %s" % (r, v) for r, v in sorted(bad.items())] +
+                                                                  ["rank %d %s" % (r, self.failures.get(r, "left the leg early")) for r in missing])))
+
+    def exchange(self, name, value, timeout_s=None):
+        """Every rank posts a small value; returns {rank: value} of the ranks that did (bounded)."""
+        if self.store is None:
+            return {0: str(value)}
+        self.post(name, value)
+        got, _ = self.collect(name, timeout_s)
+        return got
+
+
+class BoundedDist:
+    """torch.distributed's collectives with a bounded wait (async_op + polling is_completed): what distributed.py is handed
+    instead of the module.  A collective that does not complete raises CollectiveTimeout and marks the communicator abandoned."""
+
+    def __init__(self, dist, coord, timeout_s=20.0, poll_s=0.001, before=None):
+        self.dist, self.coord, self.timeout_s, self.poll_s, self.before = dist, coord, timeout_s, poll_s, before
+
+    def get_backend(self):
+        return self.dist.get_backend()
+
+    def _wait(self, work, what):
+        deadline = time.monotonic() + self.timeout_s
+        while not work.is_completed():
+            if time.monotonic() >= deadline:
+                self.coord.collectives_broken = True
+                raise CollectiveTimeout("%s did not complete within %.0f s (a rank never entered it?)" % (what, self.timeout_s))
+            time.sleep(self.poll_s)
+        work.wait()
+
+    def _run(self, what, fn):
+        if self.coord.collectives_broken:
+            raise CollectiveTimeout("%s not attempted: an earlier collective did not complete" % what)
+        if self.before:
+            self.before(what)                                   # fault injection (tests, rehearsals)
+        self._wait(fn(), what)
+
+    def all_gather_into_tensor(self, out, inp):
+        self._run("all_gather_into_tensor", lambda: self.dist.all_gather_into_tensor(out, inp, async_op=True))
+
+    def all_gather(self, outs, inp):
+        self._run("all_gather", lambda: self.dist.all_gather(outs, inp, async_op=True))
+
+
+class Lifeline:
+    """Guarantees the one JSON line.  arm() starts a watchdog thread; it fires when `deadline_s` passes or SIGTERM / SIGINT
+    arrives, and then -- on rank 0 -- prints the line built from the headline and whatever legs have finished, names the
+    phase the main thread was in, and ends the process.  Other ranks just end.  finish() is the normal way out: the main
+    thread takes the line itself and the watchdog stands down."""
+
+    def __init__(self, rank=0, emit=None, exit_fn=os._exit, clock=time.monotonic):
+        import threading
+        self.rank, self.exit_fn, self.clock = rank, exit_fn, clock
+        # the watchdog writes to a duplicate of the ORIGINAL stdout descriptor: immune to a redirect of fd 1 in force at that moment
+        # (_stdout_to_stderr) and to whatever holds Python's buffered stdout
+        self._out_fd = os.dup(1)
+        self.emit = emit or (lambda s: os.write(self._out_fd, (s + "\n").encode()))
+        self.lock = threading.Lock()
+        self.out, self.extra, self.phase_name, self.t0 = None, {}, "start", clock()
+        self.deadline, self.printed, self._thread, self._rfd, self._wfd = None, False, None, None, None
+        self.coord = None
+
+    def phase(self, name):
+        self.phase_name = name
+
+    def headline(self, out, deadline_s):
+        """The headline is computed: from now on a line can always be printed.  deadline_s counts from now."""
+        with self.lock:
+            self.out = out
+            self.deadline = self.clock() + deadline_s
+
+    def record(self, part):
+        with self.lock:
+            self.extra.update(part)
+
+    def leg_seconds(self, name, seconds):
+        with self.lock:
+            self.extra.setdefault("leg_seconds", {})[name] = round(seconds, 2)
+
+    def arm(self, hard_limit_s, signals=True):
+        """Start the watchdog.  Before headline() the only deadline is `hard_limit_s` (no line exists yet: a diagnostic goes to
+        stderr and the exit code is 1)."""
+        import signal
+        import threading
+        self.deadline = self.clock() + hard_limit_s
+        self._rfd, self._wfd = os.pipe()
+        os.set_blocking(self._wfd, False)
+        if signals and threading.current_thread() is threading.main_thread():
+            for sig in (signal.SIGTERM, signal.SIGINT):
+                signal.signal(sig, lambda *_: None)        # the C-level handler writes the signal number to the wakeup fd
+            signal.set_wakeup_fd(self._wfd, warn_on_full_buffer=False)
+        self._thread = threading.Thread(target=self._watch, name="bench-lifeline", daemon=True)
+        self._thread.start()
+
+    def _watch(self):
+        import select
+        while True:
+            with self.lock:
+                left = self.deadline - self.clock()
+                done = self.printed
+            if done:
+                return
+            if left <= 0:
+                return self._fire("deadline")
+            r, _, _ = select.select([self._rfd], [], [], min(left, 1.0))
+            if r:
+                b = os.read(self._rfd, 64)
+                if b == b"q":
+                    return
+                return self._fire("signal %d" % b[0] if b else "signal")
+
+    def line(self, aborted=None):
+        out = dict(self.out)
+        extra = dict(self.extra)
+        if self.coord is not None and self.coord.failures:
+            extra["rank_failures"] = {str(r): w for r, w in sorted(self.coord.failures.items())}
+        if aborted:
+            extra["bench_aborted"] = aborted
+        for k in ("roofline_hash_cells", "cpu_baseline"):        # top-level blocks some legs produce
+            if k in extra:
+                out[k] = extra.pop(k)
+        if extra:
+            out["extra"] = extra
+        return json.dumps(out, default=str)
+
+    def _fire(self, reason):
+        with self.lock:
+            if self.printed:
+                return
+            self.printed = True
+            at = round(self.clock() - self.t0, 1)
+            if self.rank == 0 and self.out is not None:
+                self.emit(self.line({"reason": reason, "phase": self.phase_name, "at_s": at,
+                                     "note": "the watchdog printed this line: the main thread was still in `phase`"}))
+                code = 0
+            else:
+                if self.out is None:
+                    sys.stderr.write(json.dumps({"bench_error": "no headline", "reason": reason, "phase": self.phase_name, "rank": self.rank,
+                                                 "at_s": at}) + "\n")
+                    sys.stderr.flush()
+                code = 0 if self.out is not None else 1
+        self.exit_fn(code)
+
+    def finish(self):
+        """Normal completion: returns the line (rank 0) or None; the watchdog stands down.  None when the watchdog got there first."""
+        with self.lock:
+            if self.printed:
+                return None
+            self.printed = True
+            text = self.line() if (self.rank == 0 and self.out is not None) else ""
+        if self._wfd is not None:
+            try:
+                os.write(self._wfd, b"q")
+            except OSError:
+                pass
+        return text
+
+
+class LegRunner:
+    """Runs the legs after the headline: rank 0 decides (budget, failed ranks, abandoned communicator) and every rank follows the
+    same decision; a leg's result or error lands in the line at once (Lifeline.record: the watchdog can print it whenever it has
+    to); every rank reports how the leg went through the store (bounded)."""
+
+    def __init__(self, coord, budget, life, rank, world, after_leg=None):
+        self.coord, self.budget, self.life, self.rank, self.world, self.after_leg = coord, budget, life, rank, world, after_leg
+        self.decisions = {}
+
+    def run(self, name, fn, worst_s, all_ranks=True, collective=False, only_rank0=False):
+        coord, life = self.coord, self.life
+        life.phase("extra leg: " + name)
+        d = coord.decide("leg/" + name, lambda: leg_decision(self.budget, worst_s, all_ranks and self.world > 1, set(coord.failures),
+                                                             collective, coord.collectives_broken))
+        self.decisions[name] = d
+        if d != "go":
+            life.record({name + "_skipped": d})
+            return False
+        t_leg = time.perf_counter()
+        err = None
+        coord.bail_name = "leg/" + name + "/done"
+        try:
+            if not only_rank0 or self.rank == 0:
+                part = fn()
+                if part:
+                    life.record(part)
+        except Exception as e:   # never lose the headline line to an extra leg
+            err = e
+            life.record({name + "_error": repr(e)})
+        if self.after_leg:
+            self.after_leg()
+        if self.world > 1:
+            got = coord.exchange("leg/" + name + "/done", "ok" if err is None else "error: %r" % (err,))
+            coord.bail_name = None
+            bad = {r: v for r, v in got.items() if v != "ok"}
+            if collective and (bad or len(got) < self.world):
+                coord.collectives_broken = True          # a rank may have left a collective half-entered: no further collective
+            if self.rank == 0 and bad:
+                life.record({name + "_rank_errors": {str(r): v[:300] for r, v in sorted(bad.items())}})
+        life.leg_seconds(name, time.perf_counter() - t_leg)
+        return err is None
+
+
+def spawn_ranks(n, argv=None, script=None, extra_env=None):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (nothing in THIS process has touched
-    the GPU), relay rank 0's stdout, fail if any rank fails.  No exec: children are ordinary subprocesses.  All children
-    are polled: the first one that exits non-zero ends the others (a dead rank would otherwise leave the rest waiting in
-    the rendezvous until its timeout)."""
+    the GPU), relay rank 0's stdout.  No exec: children are ordinary subprocesses.  All children are polled.
+    A rank that exits non-zero is named in a marker file the surviving ranks' bounded waits read ("dead_<rank>"); if that
+    happens BEFORE rank 0 has its headline (flag file) nothing can be printed and every rank is stopped; after it, rank 0 is
+    left to finish on its own deadline (its extra legs skip what needs the dead rank) and the others are stopped once it is out."""
+    import shutil
     import tempfile
     # rendezvous through a file store in a private directory: no port is picked here that another process could take
     # before the children bind it (MASTER_ADDR / MASTER_PORT stay set for anything that reads them)
-    rdv = os.path.join(tempfile.mkdtemp(prefix="cp2_bench_rdv_"), "store")
+    rdv_dir = tempfile.mkdtemp(prefix="cp2_bench_rdv_")
+    rdv, flag = os.path.join(rdv_dir, "store"), os.path.join(rdv_dir, "headline")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     procs = []
     out0 = tempfile.TemporaryFile()
+    argv = sys.argv[1:] if argv is None else argv
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_INIT_TIMEOUT_S="120", BENCH_INIT_FILE=rdv)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_INIT_TIMEOUT_S="120", BENCH_INIT_FILE=rdv,
+                   BENCH_DEAD_DIR=rdv_dir, BENCH_HEADLINE_FLAG=flag)
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=out0 if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    live = list(procs)
-    while live and not rc:
-        time.sleep(0.2)
-        for p in list(live):
+    live = {r: p for r, p in enumerate(procs)}
+    stop_all = False
+    while 0 in live and not stop_all:
+        time.sleep(0.1)
+        for r, p in list(live.items()):
             code = p.poll()
-            if code is not None:
-                live.remove(p)
-                rc = rc or code
-    for p in live:             # a rank failed: stop the ones still running (exactly the processes started above)
+            if code is None:
+                continue
+            del live[r]
+            if code != 0:
+                with open(os.path.join(rdv_dir, "dead_%d.tmp" % r), "w") as f:
+                    f.write("exited with code %d" % code)
+                os.replace(os.path.join(rdv_dir, "dead_%d.tmp" % r), os.path.join(rdv_dir, "dead_%d" % r))
+                if r == 0 or not os.path.exists(flag):
+                    stop_all = True          # no headline yet (or rank 0 itself is gone): nothing left to wait for
+    rc0 = procs[0].poll()
+    for p in live.values():      # rank 0 is out (or nothing can be printed): stop exactly the processes started above
         p.terminate()
-    for p in live:
+    for p in live.values():
         try:
             p.wait(timeout=20)
         except subprocess.TimeoutExpired:
             p.kill()
-    import shutil
-    shutil.rmtree(os.path.dirname(rdv), ignore_errors=True)
+    if rc0 is None:
+        rc0 = procs[0].wait()
+    shutil.rmtree(rdv_dir, ignore_errors=True)
     out0.seek(0)
-    sys.stdout.write(out0.read().decode())
+    text = out0.read().decode()
+    sys.stdout.write(text)
     sys.stdout.flush()
-    sys.exit(1 if rc else 0)
+    has_line = any(l.startswith("{") for l in text.splitlines())
+    sys.exit(0 if (rc0 == 0 or has_line) and has_line else 1)
 
 
 def uniform_felts_device(torch, dev, m, gen):
@@ -149,6 +527,29 @@ def newest_profile(pattern):
     return fs[-1] if fs else None
 
 
+# worst-case seconds of each extra leg (what the budget check uses; measured times are a third of these or less:
+# DESIGN.md section 6): a function of the world size where the work is sharded
+LEG_WORST_S = {
+    "cpu_baseline": lambda w: 40.0,
+    "slot_root": lambda w: 15.0,
+    "witnesses": lambda w: 40.0,
+    "ingest": lambda w: 70.0,
+    "dataset": lambda w: 15.0 + 15.0 / w,
+    "dataset_big_slots": lambda w: 15.0 + 10.0 / w,
+    "dataset_inprocess": lambda w: 15.0 + 20.0 / w,          # per child process (main / rccl / copy / host / few)
+    "cli_default": lambda w: 25.0,
+}
+
+
+def inject(what):
+    """BENCH_INJECT=<fault>[@rank] (test / rehearsal only): is fault `what` to be injected in THIS process?"""
+    v = os.environ.get("BENCH_INJECT", "")
+    if not v:
+        return False
+    name, _, r = v.partition("@")
+    return name == what and int(r or "1") == int(os.environ.get("RANK", "0"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,24 +560,37 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-child-legs", action="store_true",
                     help="skip the legs that start child processes (dataset_inprocess, cli_default): for runs under a counter-collecting profiler")
+    ap.add_argument("--legs", default="", help="comma-separated names of the extra legs to run (default: all): " + ", ".join(sorted(LEG_WORST_S)))
+    ap.add_argument("--extra-budget-s", type=float, default=240.0,
+                    help="ONE deadline for everything after the headline: a leg starts only if its worst case fits what is left; when it "
+                         "passes, the line is printed with what is there (default 240)")
+    ap.add_argument("--hard-limit-s", type=float, default=560.0,
+                    help="no headline after this many seconds (stuck in rendezvous / communicator creation): say where and exit 1")
     ap.add_argument("--inprocess-leg", type=int, default=0, metavar="N",
                     help="(child mode of the dataset_inprocess leg) build config 5's scale-down on N devices in THIS process through cp2_multi_* and print one JSON object")
+    ap.add_argument("--inprocess-what", default="main", choices=["main", "rccl", "copy", "host", "few"],
+                    help="(child mode) main: first + warm build, automatic exchange; rccl / copy / host: one build with that exchange asked for "
+                         "BY NAME; few: a dataset of few, large slots cut by units")
     args = ap.parse_args()
 
     if args.inprocess_leg:
-        return inprocess_child(args.inprocess_leg)
+        return inprocess_child(args.inprocess_leg, args.inprocess_what)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args.gpus)
-
-    import torch
-    import torch.distributed as dist
-    import __graft_entry__ as g
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d but --gpus=%d" % (world, args.gpus))
+    life = Lifeline(rank)
+    life.arm(args.hard_limit_s)
+    life.phase("import torch")
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
+
     # Rehearsal knobs (not used by the driver): BENCH_BACKEND=gloo + BENCH_SHARE_GPU=1 run N ranks on ONE GPU with
     # CPU-side collectives, to exercise the multi-rank logic on a one-GPU box (RCCL refuses two ranks per GPU).
     backend = os.environ.get("BENCH_BACKEND", "nccl")
@@ -185,12 +599,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
+    store = None
     if world > 1:
         # RCCL printf()s a version banner on STDOUT when NCCL_DEBUG is set (the GPU boxes export NCCL_DEBUG=VERSION,
         # and NCCL_DEBUG_FILE does not catch it); stdout must carry exactly one JSON line, so file descriptor 1 points
         # at stderr while the communicator is created.
         import datetime
         kw = {}
+        life.phase("rendezvous")
         if os.environ.get("BENCH_INIT_FILE"):                        # self-spawned ranks: file store instead of a TCP port
             # Only the RENDEZVOUS is bounded (a rank that never comes up must not leave the others waiting): every rank
             # announces itself in the store and waits for all the others under BENCH_INIT_TIMEOUT_S.  The process group keeps
@@ -200,6 +616,7 @@ def main():
             store.wait(["cp2_bench_up_%d" % r for r in range(world)],
                        datetime.timedelta(seconds=int(os.environ.get("BENCH_INIT_TIMEOUT_S", "120"))))
             kw.update(store=store, rank=rank, world_size=world)
+        life.phase("communicator creation (%s)" % backend)
         with _stdout_to_stderr():
             if backend == "nccl":
                 try:
@@ -212,12 +629,19 @@ def main():
             dist.all_reduce(warm)                                    # forces communicator creation inside the redirect
             if coll_dev.type == "cuda":
                 torch.cuda.synchronize()
+        if store is None:
+            store = dist.distributed_c10d._get_default_store()       # torchrun: the agent's TCPStore (it outlives any rank)
+    coord = Coord(store if world > 1 else None, rank, world, sync_timeout_s=float(os.environ.get("BENCH_SYNC_TIMEOUT_S", "30")),
+                  dead_dir=os.environ.get("BENCH_DEAD_DIR"))
+    life.coord = coord
 
+    life.phase("library + context")
     pkg = g.load_package()
     ctx = pkg.Context(local_rank)                        # raises without a gfx950 GPU: no fallback
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
 
+    life.phase("input generation")
     n = args.states
     gen = torch.Generator(device=dev).manual_seed(0xC0DE + rank)
     x = uniform_felts_device(torch, dev, 3 * n, gen).reshape(n, 96)
@@ -231,6 +655,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    life.phase("timed region")
     for _ in range(args.warmup):
         step()
     barrier()
@@ -253,14 +678,13 @@ def main():
 
     # ---- sanity: the result of the timed kernel is the reference permutation (a strided sample, vs the oracle).
     # Rank 0 only: the oracle is a checker built on demand, N ranks must not race its build.
+    life.phase("oracle check of the timed kernel's output")
     import numpy as np
     C = None
     if rank == 0:
         C, P = g.load_oracle()
         idx = torch.cat([torch.tensor([0, 1, n // 2, n - 1], device=dev), torch.arange(0, n, max(1, n // 2048), device=dev)])
         assert np.array_equal(y[idx].cpu().numpy(), C.permute_batch(x[idx].cpu().numpy(), threads=4)), "bench output != oracle"
-    if world > 1:
-        dist.barrier()
 
     avg_ms = sum(kernel_ms) / len(kernel_ms)
     achieved = BYTES_PER_PERM * n / (avg_ms * 1e-3) / 1e9
@@ -301,71 +725,83 @@ def main():
     if valu:
         out["valu_issue"] = valu
 
-    # ---- extra legs (outside the timed region) -------------------------------------------------------
-    extra = {}
+    # ---- the headline exists: from here on the line cannot be lost -----------------------------------------
+    budget = Budget(args.extra_budget_s)
+    life.headline(out, args.extra_budget_s + 10.0)           # the watchdog's deadline: the budget plus time to print
+    if rank == 0 and os.environ.get("BENCH_HEADLINE_FLAG"):
+        open(os.environ["BENCH_HEADLINE_FLAG"], "w").close()  # (self-spawned ranks) tells the parent that rank 0 can finish alone
     del x, y
     torch.cuda.empty_cache()
+    def before_collective(what):
+        if inject("gather_error"):          # (rehearsal) this rank fails right where the others enter the collective
+            raise RuntimeError("injected: gather_error before %s" % what)
+
+    bdist = BoundedDist(dist, coord, timeout_s=float(os.environ.get("BENCH_COLLECTIVE_TIMEOUT_S", "20")), before=before_collective) if world > 1 else None
+    legs = LegRunner(coord, budget, life, rank, world, after_leg=torch.cuda.empty_cache)
+
+    only = set(x for x in args.legs.split(",") if x)
+    if only - set(LEG_WORST_S):
+        raise SystemExit("--legs: unknown leg(s) %s" % sorted(only - set(LEG_WORST_S)))
+
+    def run_leg(name, fn, **kw):
+        if only and name not in only:
+            return False
+        return legs.run(name, fn, LEG_WORST_S[name](world), **kw)
+
+    if not args.no_cpu_baseline and world == 1:
+        run_leg("cpu_baseline", lambda: {"cpu_baseline": cpu_baseline(C, np, torch, dev)})
     if not args.no_extra:
-        try:
+        def slot_root():
             leg, hash_roof = slot_root_leg(torch, ctx, pkg, dev, stream)
-            extra.update(leg)
-            out["roofline_hash_cells"] = hash_roof
-        except Exception as e:   # never lose the headline line to an extra leg
-            extra["slot_root_error"] = repr(e)
-        torch.cuda.empty_cache()
+            return dict(leg, roofline_hash_cells=hash_roof)
+        run_leg("slot_root", slot_root, all_ranks=False)
         if world == 1:
-            try:
-                extra.update(witness_leg(torch, ctx, pkg))
-            except Exception as e:
-                extra["witness_error"] = repr(e)
-            try:
-                extra.update(ingest_leg(torch, ctx, pkg, dev))
-            except Exception as e:
-                extra["ingest_error"] = repr(e)
-        try:
-            extra.update(dataset_leg(torch, dist, ctx, pkg, coll_dev, rank, world))
-        except Exception as e:
-            extra["dataset_error"] = repr(e)
-        try:
-            extra.update(big_slots_leg(torch, dist, ctx, pkg, coll_dev, rank, world))
-        except Exception as e:
-            extra["dataset_big_slots_error"] = repr(e)
-        try:
-            if not args.no_child_legs:
-                extra.update(inprocess_leg(torch, dist, ctx, rank, world))
-        except Exception as e:
-            extra["dataset_inprocess_error"] = repr(e)
-        if world == 1 and not args.no_child_legs:
-            try:
-                extra.update(cli_default_leg(pkg, g))
-            except Exception as e:
-                extra["cli_default_error"] = repr(e)
+            run_leg("witnesses", lambda: witness_leg(torch, ctx, pkg))
+            run_leg("ingest", lambda: ingest_leg(torch, ctx, pkg, dev))
+        run_leg("dataset", lambda: dataset_leg(torch, bdist, coord, ctx, pkg, coll_dev, rank, world), collective=world > 1)
+        run_leg("dataset_big_slots", lambda: big_slots_leg(torch, bdist, coord, ctx, pkg, coll_dev, rank, world), collective=world > 1)
+        if not args.no_child_legs:
+            run_leg("dataset_inprocess", lambda: inprocess_leg(torch, coord, budget, ctx, rank, world))
+            if world == 1:
+                run_leg("cli_default", lambda: cli_default_leg(pkg, g))
+    life.phase("committed records")
     # config 5 at its nominal slot size (one GPU's share, 32 TiB: 13 minutes, so not run here): the committed record, named as such
     rec = newest_profile("r*_config5_nominal_share.txt")
     if rec and rank == 0:
         try:
             last = [l for l in open(rec).read().splitlines() if l.startswith("{")][-1]
-            extra["config5_nominal_share_record"] = dict(json.loads(last), source="%s (tools/config5_share.py; NOT measured in this run)" % os.path.relpath(rec, ROOT),
-                                                         workload="configs[4] at its nominal slot size, one GPU's share: 4096 slots x 2^22 cells x 2048 B = 32 TiB, roots-only build")
+            life.record({"config5_nominal_share_record": dict(json.loads(last), source="%s (tools/config5_share.py; NOT measured in this run)" % os.path.relpath(rec, ROOT),
+                                                              workload="configs[4] at its nominal slot size, one GPU's share: 4096 slots x 2^22 cells x 2048 B = 32 TiB; what the build kept of the trees is the record's tree_mode (2 = compact, 0 = roots only)")})
         except Exception:
             pass
     rec = newest_profile("r*_config4_nominal.txt")
     if rec and rank == 0:
         try:
             last = [l for l in open(rec).read().splitlines() if l.startswith("{")][-1]
-            extra["config4_nominal_record"] = dict(json.loads(last), source="%s (tools/config4_nominal.py; NOT measured in this run)" % os.path.relpath(rec, ROOT),
-                                                   workload="configs[3] at configs[2]'s slot size: 4096 slots x 8 GiB, nSamples=100, maxDepth=32, every input.json, streamed roots-only")
+            life.record({"config4_nominal_record": dict(json.loads(last), source="%s (tools/config4_nominal.py; NOT measured in this run)" % os.path.relpath(rec, ROOT),
+                                                        workload="configs[3] at configs[2]'s slot size: 4096 slots x 8 GiB, nSamples=100, maxDepth=32, every input.json, streamed build; what it kept of the trees is the record's tree_mode (2 = compact, 0 = roots only)")})
         except Exception:
             pass
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(C, np, torch, dev)
-    if extra:
-        out["extra"] = extra
+    if legs.decisions:
+        life.record({"legs": legs.decisions, "extra_budget_s": args.extra_budget_s, "extra_seconds_used": round(budget.elapsed(), 1)})
+    # ---- the line first, the teardown after it (destroy_process_group must not be able to block the print) -------------
+    life.phase("print")
+    text = life.finish()
+    if text:
+        print(text, flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+        life.phase("teardown")
+        clean = not coord.collectives_broken and not coord.failures
+        if clean:
+            import threading
+            th = threading.Thread(target=lambda: dist.destroy_process_group(), daemon=True)
+            th.start()
+            th.join(15.0)
+            clean = not th.is_alive()
+        if not clean:
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)              # an abandoned communicator (or a dead peer) can block interpreter shutdown: the line is out, leave
 
 
 def host_threads():
@@ -430,12 +866,22 @@ def slot_root_leg(torch, ctx, pkg, dev, stream):
             source = "%s (rocprofv3 --pmc, separate passes; not measured in this run)" % os.path.relpath(tpath, ROOT)
         except Exception:
             traffic = None
+    h_valu = None
+    if tpath:
+        try:
+            h_valu = json.load(open(tpath)).get("valu_issue")      # the issue-side record of THIS kernel: one PMC pass + its own ISA (tools/profile_summarize.py)
+            if h_valu:
+                h_valu = dict(h_valu, source=os.path.relpath(tpath, ROOT))
+        except Exception:
+            h_valu = None
     roof = {"bound": "hbm", "achieved": round(h_ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(h_ach / HBM_PEAK_GBPS, 5),
             "traffic": traffic, "traffic_source": source, "kernel": "k_hash_cells", "avg_launch_ms": round(h_avg, 3),
             "launch_ms_min_max": [round(min(hash_ms), 3), round(max(hash_ms), 3)], "algorithmic_bytes_per_launch": h_alg,
             "perms_per_launch": 34 * n_cells, "perms_per_s": 34 * n_cells / (h_avg * 1e-3),
             "note": "one launch over the 8 GiB slot of configs[2] (2^22 cells x 2048 B read, 2^22 x 32 B written); VALU-issue bound like "
                     "k_permute_batch: 34 permutations per 2080 B"}
+    if h_valu:
+        roof["valu_issue"] = h_valu
     return leg, roof
 
 
@@ -634,13 +1080,16 @@ def ingest_table(ctx, pkg, np, cells, cfg, cs, bs, nc, nbytes, want, table):
                       "roots_match_device_build": ok_h and ok_f})
 
 
-def dataset_leg(torch, dist, ctx, pkg, dev, rank, world):
+def dataset_leg(torch, bdist, coord, ctx, pkg, dev, rank, world):
     """Config 5's shape at SURVEY.md 8(d)'s stated scale-down: 32 768 slots (maxLog2NSlots = 15) of 2^12 cells x 2048 B (256 GiB
     of fake data, generated and hashed on the devices) sharded over the ranks in contiguous ranges; each rank builds its slot
     trees with no communication, ONE all-gather of the 32-byte slot roots (RCCL over xGMI; none at N = 1), the 15-level dataset
     tree on every rank, one proof input (slotProof of depth 15) for the first slot of every rank.  Strong scaling: the 32 768
     slots are fixed, every rank must end with the same dataset root (and with the oracle's, when the committed fixture
-    tests/golden/config5.json carries this shape)."""
+    tests/golden/config5.json carries this shape).
+    Ranks start together (the leg's go decision, a bounded store wait); `seconds` is the MAX over ranks of each rank's own
+    start-to-finish time.  The only collective is the gather itself (bdist: bounded); everything else the ranks tell each other
+    goes through the store (coord), so a rank that fails or dies is named within seconds."""
     import importlib
     d = importlib.import_module("codex_storage_proofs_circuits_amd.distributed")
     n_slots, n_cells = 32768, 1 << 12
@@ -648,77 +1097,64 @@ def dataset_leg(torch, dist, ctx, pkg, dev, rank, world):
                           nSamples=100, seed=12345)
     ctx.reset_stream()
     torch.cuda.synchronize()
-
-    def all_ranks_ok(err):
-        """Every rank reaches every collective: a rank whose local step failed says so in an all-reduce instead of leaving
-        the others waiting in the gather (which would cost the whole JSON line)."""
-        if world > 1:
-            flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            if int(flag.item()):
-                raise RuntimeError("a rank failed in the dataset leg: %r" % (err,))
-        elif err:
-            raise err
-
-    if world > 1:
-        dist.barrier()
+    if inject("rank_exit"):
+        os._exit(3)                                                  # (rehearsal) this rank dies at the start of the leg
+    if inject("rank_hang"):
+        time.sleep(1e6)                                              # (rehearsal) ... or hangs there
     t0 = time.perf_counter()
     backend = d.HipBackend(pkg, ctx)
     first, count = d.shard_range(n_slots, rank, world)
     on_device = dev.type == "cuda"                                   # RCCL: the roots never leave HBM; gloo rehearsal: host arrays
     err, local = None, None
     try:
+        try:
+            if on_device:
+                backend.build_local(cfg, first, count)               # this rank's slot trees: no communication
+            else:
+                local = backend.local_slot_roots(cfg, first, count)
+        except Exception as e:
+            err = e
+        # every rank reaches the collective or none does: a rank whose build failed says so in the store first
+        coord.all_ok("dataset/built", err)
+        # THE exchange step: device to device (copy inside HBM -> all_gather_into_tensor over RCCL/xGMI -> cp2_dataset_set_roots_dev)
         if on_device:
-            backend.build_local(cfg, first, count)                   # this rank's slot trees: no communication
-        else:
-            local = backend.local_slot_roots(cfg, first, count)
-    except Exception as e:
-        err = e
-    all_ranks_ok(err)
-    # THE exchange step: device to device (copy inside HBM -> all_gather_into_tensor over RCCL/xGMI -> cp2_dataset_set_roots_dev)
-    if on_device:
-        all_dev = d.gather_slot_roots_dev(backend.dataset, ctx, n_slots, rank, world, dist if world > 1 else None, dev)
-    else:
-        all_roots = d.gather_slot_roots(local, n_slots, rank, world, dist if world > 1 else None, dev)
-    err, root, text = None, None, ""
-    try:
-        if on_device:
+            all_dev = d.gather_slot_roots_dev(backend.dataset, ctx, n_slots, rank, world, bdist if world > 1 else None, dev)
             backend.dataset.set_roots_dev(all_dev.data_ptr())        # 15-level dataset tree on every rank
             root = backend.dataset.root()
         else:
+            all_roots = d.gather_slot_roots(local, n_slots, rank, world, bdist if world > 1 else None, dev)
             root = backend.dataset_root(cfg, all_roots)
         t1 = time.perf_counter()
         text = backend.dataset.proof_input(first, 1234567).json()    # a proof input for one of this rank's own slots
         torch.cuda.synchronize()
-    except Exception as e:
-        err = e
-    all_ranks_ok(err)
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    same = True
-    if world > 1:
-        r = torch.from_numpy(root.copy()).to(dev)
-        rs = [torch.empty_like(r) for _ in range(world)]
-        dist.all_gather(rs, r)
-        same = all(torch.equal(rs[0], q) for q in rs)
-    backend.dataset.free()
-    ctx.trim()
-    perms = n_slots * (35 * n_cells - 1) + (n_slots - 1) * world + 200 * world
+        dt = time.perf_counter() - t0
+    finally:
+        if backend.dataset is not None:
+            backend.dataset.free()
+        ctx.trim()
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     root_hex = root.tobytes()[::-1].hex()
+    # what every rank ended with, through the store: its root, its time
+    said = coord.exchange("dataset/result", json.dumps({"root": root_hex, "s": dt, "tree_s": t1 - t0}))
+    results = {r: json.loads(v) for r, v in said.items()}
+    same = len(results) == world and all(v["root"] == root_hex for v in results.values())
+    dt_max = max(v["s"] for v in results.values())
+    tree_max = max(v["tree_s"] for v in results.values())
+    perms = n_slots * (35 * n_cells - 1) + (n_slots - 1) * world + 200 * world
     gold = None
     try:
         gold = json.load(open(os.path.join(ROOT, "tests", "golden", "config5.json")))["scaled"]["dataset_root_hex"]
     except Exception:
         pass
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     return {"dataset": {"workload": "configs[4] shape, SURVEY.md 8(d) scale-down: 32768 slots x 2^12 cells x 2048 B sharded over %d GPU(s) "
                                     "(%d slots on rank 0), one gather of slot roots -> 15-level dataset tree on every rank, one proof input per rank"
                                     % (world, count),
-                        "exchange": ("device to device (all_gather_into_tensor, %s)" % dist.get_backend() if world > 1 and on_device else
-                                     "none (one rank)" if world == 1 else "host arrays (%s rehearsal)" % dist.get_backend()),
-                        "scaling": "strong", "seconds": round(dt, 4), "roots_and_dataset_tree_s": round(t1 - t0, 4), "perms_per_s": perms / dt,
-                        "slots_per_s": n_slots / dt, "all_ranks_agree": bool(same), "ranks": world,
+                        "exchange": ("device to device (all_gather_into_tensor, %s)" % bdist.get_backend() if world > 1 and on_device else
+                                     "none (one rank)" if world == 1 else "host arrays (%s rehearsal)" % bdist.get_backend()),
+                        "scaling": "strong", "seconds": round(dt_max, 4), "seconds_is": "max over ranks of each rank's own start-to-finish time",
+                        "roots_and_dataset_tree_s": round(tree_max, 4), "perms_per_s": perms / dt_max,
+                        "slots_per_s": n_slots / dt_max, "all_ranks_agree": bool(same), "ranks": world, "ranks_reporting": len(results),
+                        "per_rank_seconds": {str(r): round(v["s"], 4) for r, v in sorted(results.items())},
                         "proof_input_json_bytes": len(text), "dataset_root_hex": root_hex,
                         "equals_oracle_fixture": (root_hex == gold) if gold else None}}
 
@@ -755,39 +1191,40 @@ def cpu_baseline(C, np, torch, dev):
                                      "note": "config 3 scaled to 2^16 cells of 2048 B (fake data generated, hashed and treed on %d threads)" % cores}}
 
 
-def big_slots_leg(torch, dist, ctx, pkg, dev, rank, world):
+def big_slots_leg(torch, bdist, coord, ctx, pkg, dev, rank, world):
     """Config 5's OTHER stated scale-down ("8 x k slots x 2^22 cells"): 8 slots at the nominal 8 GiB slot size
     (64 GiB generated and hashed on the devices; every slot crosses four 2 GiB staging chunks), sharded over the ranks like the
-    32 768-slot leg (strong scaling), one exchange of slot roots, dataset tree, one proof input per rank; against the
-    oracle-only fixture tests/golden/bigslots.json."""
+    32 768-slot leg (strong scaling), one exchange of slot roots, dataset tree, one proof input per rank that holds a slot;
+    against the oracle-only fixture tests/golden/bigslots.json.  Coordination as in dataset_leg: the gather is the only
+    collective and it is bounded; `seconds` = max over ranks."""
     import importlib
     d = importlib.import_module("codex_storage_proofs_circuits_amd.distributed")
     n_slots, n_cells = 8, 1 << 22
-    if world > n_slots:
-        return {"dataset_big_slots": {"skipped": "more ranks than slots"}}
     cfg = pkg.make_config(maxDepth=32, maxLog2NSlots=3, cellSize=2048, blockSize=65536, nSlots=n_slots, nCells=n_cells, nSamples=100, seed=12345)
     ctx.reset_stream()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
     t0 = time.perf_counter()
     backend = d.HipBackend(pkg, ctx)
-    err, root, text, first, count = None, None, "", 0, 0
+    text, first, count = "", 0, 0
     try:
-        root, all_roots, (first, count) = d.dataset_root_sharded(backend, cfg, rank, world, dist if world > 1 else None,
-                                                                 dev if dev.type == "cuda" else "cpu")
+        root, all_roots, (first, count) = d.dataset_root_sharded(backend, cfg, rank, world, bdist if world > 1 else None,
+                                                                 dev if dev.type == "cuda" else "cpu",
+                                                                 on_built=lambda err: coord.all_ok("big_slots/built", err))
         t1 = time.perf_counter()
-        text = backend.dataset.proof_input(first, 1234567).json()
-    except Exception as e:          # a rank that failed BEFORE the collective leaves the others waiting there: bounded by the collective timeout
-        err = e
-    if world > 1:
-        flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag.item()):
-            raise RuntimeError("a rank failed in the big-slots leg: %r" % (err,))
-    elif err:
-        raise err
-    dt = time.perf_counter() - t0
+        if count:
+            text = backend.dataset.proof_input(first, 1234567).json()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    except Exception:
+        if backend.dataset is not None:
+            backend.dataset.free()
+        ctx.trim()
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        raise
+    said = coord.exchange("big_slots/result", json.dumps({"s": dt, "tree_s": t1 - t0, "root": root.tobytes()[::-1].hex()}))
+    results = {r: json.loads(v) for r, v in said.items()}
+    dt, t_tree = max(v["s"] for v in results.values()), max(v["tree_s"] for v in results.values())
+    agree = len(results) == world and len({v["root"] for v in results.values()}) == 1
     import hashlib
     gold = None
     try:
@@ -821,127 +1258,163 @@ def big_slots_leg(torch, dist, ctx, pkg, dev, rank, world):
             cds.free()
         finally:
             ctx.set_keep_trees(-1)
-    else:
+    elif backend.dataset is not None:
         backend.dataset.free()
     ctx.trim()
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    perms = n_slots * (35 * n_cells - 1) + (n_slots - 1) * world + 200 * world
+    perms = n_slots * (35 * n_cells - 1) + (n_slots - 1) * world + 200 * min(world, n_slots)
     root_hex = root.tobytes()[::-1].hex()
     return {"dataset_big_slots": {"workload": "configs[4] shape, SURVEY.md 8(d)'s other scale-down: 8 slots x 2^22 cells x 2048 B (nominal 8 GiB slots) sharded "
                                               "over %d GPU(s) (%d slots on rank 0), one exchange of slot roots, dataset tree, one proof input per rank" % (world, count),
-                                  "scaling": "strong", "seconds": round(dt, 4), "roots_and_dataset_tree_s": round(t1 - t0, 4),
+                                  "scaling": "strong", "seconds": round(dt, 4), "seconds_is": "max over ranks of each rank's own start-to-finish time",
+                                  "roots_and_dataset_tree_s": round(t_tree, 4), "all_ranks_agree": bool(agree), "ranks_reporting": len(results),
                                   "perms_per_s": perms / dt, "GB_per_s_hashed": round(n_slots * n_cells * 2048 / dt / 1e9, 2),
                                   "dataset_root_hex": root_hex, "proof_input_latency": latency,
                                   "equals_oracle_fixture": (root_hex == gold["dataset_root_hex"] and
                                                             hashlib.sha256(text.encode()).hexdigest() == gold["inputs"][str(first)]["json_sha256"]) if gold else None}}
 
 
-def inprocess_child(n_dev):
-    """Child mode (`bench.py --inprocess-leg N`): ONE process, N devices, through the C ABI's own multi-GPU entry points
-    (cp2_multi_init / cp2_multi_dataset_build / cp2_multi_proof_input_generate: exactly what the cli twin and a Nim caller
-    get).  Config 5's shape at SURVEY.md 8(d)'s scale-down; prints one JSON object."""
+def inprocess_child(n_dev, what="main"):
+    """Child mode (`bench.py --inprocess-leg N --inprocess-what W`): ONE process, N devices, through the C ABI's own multi-GPU
+    entry points (cp2_multi_init / cp2_multi_dataset_build / cp2_multi_proof_input_generate: exactly what the cli twin and a
+    Nim caller get).  Config 5's shape at SURVEY.md 8(d)'s scale-down; prints one JSON object.
+      main              first build of the process (context creation, code-object load, communicator creation) + a proof input +
+                        a second build on the warm handle; the exchange chosen automatically
+      rccl, copy, host  ONE build with that exchange asked for BY NAME (nothing can fall back silently): what it did, how long,
+                        whether every device ended with the same root as the fixture
+      few               a dataset of few, large slots (11 x 2^18 cells), which is cut by units, against the same built whole on one device
+    One process per question: a way that hangs (RCCL's first contact with two real devices) costs its own timeout, not the others' answers."""
+    if os.environ.get("BENCH_INJECT") == "child_hang" and what == ("rccl" if n_dev > 1 else "main"):
+        time.sleep(1e6)                             # (rehearsal) the leg's first child hangs: the parent's timeout has to end it
+    import hashlib
     import __graft_entry__ as g
     pkg = g.load_package()
     n_slots, n_cells = 32768, 1 << 12
     cfg = pkg.make_config(maxDepth=32, maxLog2NSlots=15, cellSize=2048, blockSize=65536, nSlots=n_slots, nCells=n_cells, nSamples=100, seed=12345)
-    with _stdout_to_stderr():                      # RCCL prints its version banner on stdout when NCCL_DEBUG is set
-        t0 = time.perf_counter()
-        # rehearsal on a one-GPU box (BENCH_SHARE_GPU, as for the ranks): n_dev contexts on device 0, the host-gather branch
-        m = pkg.Multi([0] * n_dev if os.environ.get("BENCH_SHARE_GPU") else list(range(n_dev)))
-        t1 = time.perf_counter()
-        ds = m.dataset(cfg)                        # includes context creation, code-object load and (N > 1) communicator creation
-        t2 = time.perf_counter()
-        text = ds.proof_input(n_slots - 1, 1234567).json()
-        t3 = time.perf_counter()
-        root = ds.root()
-        n_shards = len(ds.shards())
-        agree = all((ds.shard_root(i) == root).all() for i in range(n_shards)) if ds.units_per_slot == 1 else True
-        ds.free()
-        ds = m.dataset(cfg)                        # a second build on the warm handle: contexts, code objects and communicators exist
-        t4 = time.perf_counter()
-        ds.free()
-        # N > 1: the exchange of slot roots every way the library has (RCCL all-gather, peer copies, host memory), each asked
-        # for BY NAME so that nothing falls back silently -- what each did, how long the warm build took, and whether every
-        # device ended with the fixture's dataset root; then a dataset of few, large slots (11 x 2^18 cells), which is cut by
-        # units, against the same dataset built whole on the first device
-        ways = {}
-        if n_dev > 1:
-            for name, policy in (("rccl", pkg.GATHER_RCCL), ("copy", pkg.GATHER_COPY), ("host", pkg.GATHER_HOST)):
-                try:
-                    m.set_policy(policy, 0)
-                    ta = time.perf_counter()
-                    d2 = m.dataset(cfg)
-                    tb = time.perf_counter()
-                    r2 = d2.root()
-                    ok = bool((r2 == root).all()) and all(bool((d2.shard_root(i) == root).all()) for i in range(len(d2.shards())))
-                    ways[name] = {"mode": m.gather_mode(), "warm_build_s": round(tb - ta, 4), "shards": len(d2.shards()), "every_device_has_the_root": ok}
-                    d2.free()
-                except Exception as e:            # e.g. RCCL by name on a rehearsal box whose contexts share one device: refused, with the reason
-                    ways[name] = {"error": str(e)[:300]}
-            try:
-                m.set_policy(pkg.GATHER_AUTO, 0)
-                few = pkg.make_config(maxDepth=32, maxLog2NSlots=8, cellSize=2048, blockSize=65536, nSlots=11, nCells=1 << 18, nSamples=100, seed=777)
-                ta = time.perf_counter()
-                d3 = m.dataset(few)
-                tb = time.perf_counter()
-                whole = m.ctx(0).dataset(few)
-                tc = time.perf_counter()
-                text3 = d3.proof_input(10, 424242).json()
-                ways["few_large_slots"] = {"workload": "11 slots x 2^18 cells x 2048 B (5.9 GB)", "units_per_slot": d3.units_per_slot, "shards": len(d3.shards()),
-                                           "mode": m.gather_mode(), "build_s": round(tb - ta, 4), "one_device_build_s": round(tc - tb, 4),
-                                           "root_and_input_json_equal_one_device": bool((d3.root() == whole.root()).all()) and text3 == whole.proof_input(10, 424242).json()}
-                whole.free()
-                d3.free()
-            except Exception as e:
-                ways["few_large_slots"] = {"error": str(e)[:300]}
-    perms = n_slots * (35 * n_cells - 1) + (n_slots - 1) * n_dev + 200
-    root_hex = root.tobytes()[::-1].hex()
     gold = None
     try:
         gold = json.load(open(os.path.join(ROOT, "tests", "golden", "config5.json")))["scaled"]
     except Exception:
         pass
-    import hashlib
-    res = {"devices": n_dev, "shards": n_shards, "gather": m.gather_mode(), "handle_init_s": round(t1 - t0, 4),
-           "first_build_s": round(t2 - t1, 4), "warm_build_s": round(t4 - t3, 4), "one_proof_input_json_s": round(t3 - t2, 4),
-           "perms_per_s_first": perms / (t2 - t0), "perms_per_s_warm": perms / (t4 - t3), "slots_per_s_warm": n_slots / (t4 - t3),
-           "all_devices_agree": bool(agree), "dataset_root_hex": root_hex, "exchange_every_way": ways or None,
-           "equals_oracle_fixture": (root_hex == gold["dataset_root_hex"] and
-                                     hashlib.sha256(text.encode()).hexdigest() == gold["inputs"][str(n_slots - 1)]["json_sha256"]) if gold else None}
-    m.close()
+    # rehearsal on a one-GPU box (BENCH_SHARE_GPU, as for the ranks): n_dev contexts on device 0, the host-gather branch
+    devices = [0] * n_dev if os.environ.get("BENCH_SHARE_GPU") else list(range(n_dev))
+    with _stdout_to_stderr():                      # RCCL prints its version banner on stdout when NCCL_DEBUG is set
+        t0 = time.perf_counter()
+        m = pkg.Multi(devices)
+        t1 = time.perf_counter()
+        if what == "main":
+            ds = m.dataset(cfg)                        # includes context creation, code-object load and (N > 1) communicator creation
+            t2 = time.perf_counter()
+            text = ds.proof_input(n_slots - 1, 1234567).json()
+            t3 = time.perf_counter()
+            root = ds.root()
+            n_shards = len(ds.shards())
+            agree = all((ds.shard_root(i) == root).all() for i in range(n_shards)) if ds.units_per_slot == 1 else True
+            mode_first = m.gather_mode()
+            ds.free()
+            ds = m.dataset(cfg)                        # a second build on the warm handle: contexts, code objects and communicators exist
+            t4 = time.perf_counter()
+            ds.free()
+            perms = n_slots * (35 * n_cells - 1) + (n_slots - 1) * n_dev + 200
+            root_hex = root.tobytes()[::-1].hex()
+            res = {"devices": n_dev, "shards": n_shards, "gather": mode_first, "handle_init_s": round(t1 - t0, 4),
+                   "first_build_s": round(t2 - t1, 4), "warm_build_s": round(t4 - t3, 4), "one_proof_input_json_s": round(t3 - t2, 4),
+                   "perms_per_s_first": perms / (t2 - t0), "perms_per_s_warm": perms / (t4 - t3), "slots_per_s_warm": n_slots / (t4 - t3),
+                   "all_devices_agree": bool(agree), "dataset_root_hex": root_hex,
+                   "equals_oracle_fixture": (root_hex == gold["dataset_root_hex"] and
+                                             hashlib.sha256(text.encode()).hexdigest() == gold["inputs"][str(n_slots - 1)]["json_sha256"]) if gold else None}
+        elif what in ("rccl", "copy", "host"):
+            m.set_policy({"rccl": pkg.GATHER_RCCL, "copy": pkg.GATHER_COPY, "host": pkg.GATHER_HOST}[what], 0)
+            try:
+                ta = time.perf_counter()
+                d2 = m.dataset(cfg)
+                tb = time.perf_counter()
+                r2 = d2.root()
+                same = all(bool((d2.shard_root(i) == r2).all()) for i in range(len(d2.shards())))
+                res = {"mode": m.gather_mode(), "first_build_s": round(tb - ta, 4), "handle_init_s": round(t1 - t0, 4), "shards": len(d2.shards()),
+                       "every_device_has_the_same_root": same, "dataset_root_hex": r2.tobytes()[::-1].hex(),
+                       "equals_oracle_fixture": (r2.tobytes()[::-1].hex() == gold["dataset_root_hex"]) if gold else None}
+                d2.free()
+            except Exception as e:            # e.g. RCCL by name on a rehearsal box whose contexts share one device: refused, with the reason
+                res = {"error": str(e)[:400]}
+        else:
+            few = pkg.make_config(maxDepth=32, maxLog2NSlots=8, cellSize=2048, blockSize=65536, nSlots=11, nCells=1 << 18, nSamples=100, seed=777)
+            ta = time.perf_counter()
+            d3 = m.dataset(few)
+            tb = time.perf_counter()
+            whole = m.ctx(0).dataset(few)
+            tc = time.perf_counter()
+            text3 = d3.proof_input(10, 424242).json()
+            res = {"workload": "11 slots x 2^18 cells x 2048 B (5.9 GB)", "units_per_slot": d3.units_per_slot, "shards": len(d3.shards()),
+                   "mode": m.gather_mode(), "build_s": round(tb - ta, 4), "one_device_build_s": round(tc - tb, 4),
+                   "root_and_input_json_equal_one_device": bool((d3.root() == whole.root()).all()) and text3 == whole.proof_input(10, 424242).json()}
+            whole.free()
+            d3.free()
+        m.close()
     print(json.dumps(res), flush=True)
     return 0
 
 
-def inprocess_leg(torch, dist, ctx, rank, world):
+def run_child(argv, timeout_s, env=None):
+    """A fresh subprocess (never a re-exec of this process, which has touched the GPU) with a hard timeout: terminated, then killed.
+    Returns the last JSON object it printed, or {"error": ...} naming how it ended."""
+    if timeout_s < 1.0:
+        return {"skipped": "budget (%.0f s left for a child process)" % timeout_s}
+    t0 = time.perf_counter()
+    p = subprocess.Popen(argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    try:
+        so, se = p.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        p.terminate()
+        try:
+            so, se = p.communicate(timeout=5)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            so, se = p.communicate()
+        return {"error": "timed out after %.0f s (child terminated)" % timeout_s, "stderr_tail": (se or "")[-400:]}
+    line = [l for l in so.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not line:
+        return {"error": "rc %d" % p.returncode, "stderr_tail": (se or "")[-600:]}
+    return dict(json.loads(line[-1]), child_wall_s=round(time.perf_counter() - t0, 2))
+
+
+def inprocess_leg(torch, coord, budget, ctx, rank, world):
     """The same 32 768 x 2^12 dataset as `dataset`, but through cp2_multi_* in ONE fresh process over all `world` devices (the
-    drop-in's path: no launcher, no torch.distributed).  Rank 0 starts the child once every rank has released its device memory;
-    the other ranks wait on the rendezvous store (a host-side wait: no collective kernel spins on their GPUs meanwhile)."""
-    import datetime
+    drop-in's path: no launcher, no torch.distributed).  Rank 0 starts the children once every rank has released its device
+    memory; the other ranks wait on the rendezvous store (a bounded host-side wait: nothing spins on their GPUs meanwhile).
+    N > 1: RCCL is asked for FIRST and BY NAME, in a process of its own -- if the in-process communicator (ncclCommInitAll) is
+    what fails on first contact with real devices, that is what the record says, and the other ways still answer."""
     ctx.trim()
     torch.cuda.empty_cache()
-    store = None
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-        store = dist.distributed_c10d._get_default_store()
+    torch.cuda.synchronize()
+    coord.exchange("inprocess/released", "ok")          # every rank's device memory is back (bounded; a silent rank is named)
     res = None
     if rank == 0:
+        me = [sys.executable, os.path.abspath(__file__), "--inprocess-leg", str(world)]
+        cap = float(os.environ.get("BENCH_CHILD_CAP_S", "120"))
+        worst = LEG_WORST_S["dataset_inprocess"](world)
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--inprocess-leg", str(world)], capture_output=True, text=True, timeout=420)
-            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            res = json.loads(line[-1]) if r.returncode == 0 and line else {"error": "rc %d: %s" % (r.returncode, r.stderr[-600:])}
-        except subprocess.TimeoutExpired:
-            res = {"error": "timed out after 420 s"}
+            ways = {}
+            if world > 1:
+                for name in ("rccl", "copy", "host"):
+                    ways[name] = run_child(me + ["--inprocess-what", name], budget.child_timeout(cap)) if budget.fits(worst) else {"skipped": "budget"}
+            res = run_child(me + ["--inprocess-what", "main"], budget.child_timeout(cap)) if budget.fits(worst) else {"skipped": "budget"}
+            if world > 1:
+                ways["few_large_slots"] = run_child(me + ["--inprocess-what", "few"], budget.child_timeout(cap)) if budget.fits(worst) else {"skipped": "budget"}
+                res["exchange_every_way"] = ways
         finally:
-            if store is not None:
-                store.set("cp2_bench_inprocess_done", "1")
-    elif store is not None:
-        store.wait(["cp2_bench_inprocess_done"], datetime.timedelta(seconds=480))
+            coord.post("inprocess/done", "ok", rank_key=False)
+    elif coord.store is not None:
+        deadline = time.monotonic() + budget.remaining()      # rank 0 is bounded by the same budget
+        key = coord._key("inprocess/done")
+        while not coord.store.check([key]) and time.monotonic() < deadline and 0 not in coord.failures:
+            coord._poll_dead()
+            time.sleep(0.05)
     if res is None:
         return {}
     res["workload"] = ("configs[4] shape (32768 slots x 2^12 cells x 2048 B) through cp2_multi_* in ONE process over %d device(s): contiguous slot ranges, "
-                       "one host thread + context per device, one device-to-device exchange of slot roots, dataset tree on every device" % world)
+                       "one host thread + context per device, one device-to-device exchange of slot roots, dataset tree on every device; one fresh child "
+                       "process per question (main / rccl / copy / host / few), each under its own timeout" % world)
     return {"dataset_inprocess": res}
 
 

@@ -91,18 +91,37 @@ def gather_slot_roots_dev(dataset, ctx, n_slots, rank, world, dist, device):
     return all_roots
 
 
-def dataset_root_sharded(backend, cfg, rank, world, dist=None, device="cpu"):
+def dataset_root_sharded(backend, cfg, rank, world, dist=None, device="cpu", on_built=None):
     """Returns (dataset_root (32,) uint8, all_roots (n_slots, 32) uint8, (first, count)).
     With a HipBackend on a CUDA/HIP device the gather is device to device; otherwise (the CPU tests' oracle-backed backend,
-    gloo rehearsals) it goes through host arrays."""
+    gloo rehearsals) it goes through host arrays.  Every rank issues the SAME collective, also a rank that holds no slot
+    (world > n_slots): it contributes an empty block and computes the root from the gathered roots.
+    on_built(err): called on every rank after its local build and before the collective, with the exception the build raised or
+    None -- the caller's chance to agree across ranks that everyone will enter the collective (bench.py: a bounded exchange
+    through the rendezvous store) and to raise on all ranks alike otherwise.  Without it a local failure is raised at once."""
     n_slots = int(cfg.n_slots)
     first, count = shard_range(n_slots, rank, world)
     on_device = isinstance(backend, HipBackend) and str(device).startswith("cuda")
-    if on_device and count:
-        backend.build_local(cfg, first, count)
+    err, local = None, None
+    try:
+        if on_device:
+            backend.build_local(cfg, first, count)
+        else:
+            local = backend.local_slot_roots(cfg, first, count)
+    except Exception as e:
+        if on_built is None:
+            raise
+        err = e
+    if on_built is not None:
+        on_built(err)
+        if err is not None:
+            raise err
+    if on_device:
         all_dev = gather_slot_roots_dev(backend.dataset, backend.ctx, n_slots, rank, world, dist, device)
-        backend.dataset.set_roots_dev(all_dev.data_ptr())
-        return backend.dataset.root(), all_dev.cpu().numpy(), (first, count)
-    local = backend.local_slot_roots(cfg, first, count)
+        all_roots = all_dev.cpu().numpy()
+        if backend.dataset is not None:
+            backend.dataset.set_roots_dev(all_dev.data_ptr())
+            return backend.dataset.root(), all_roots, (first, count)
+        return backend.ctx.merkle_root(all_roots), all_roots, (first, count)      # a rank without slots: the tree over the gathered roots
     all_roots = gather_slot_roots(local, n_slots, rank, world, dist, device)
     return backend.dataset_root(cfg, all_roots), all_roots, (first, count)

@@ -126,6 +126,9 @@ if os.path.exists(cls_path):
     mad_rate = mad["measured_saturated_cycles"] or 4.0
     lane_mul_per_cycle = mad["per_permutation"] * n / cyc                   # 64-bit multiply-accumulates per shader cycle, whole chip
     peak_per_cycle = 1024 * 64 / mad_rate
+    if "SQ_WAVE_CYCLES" in counters:
+        v["waves_per_simd"] = {"by_vgprs": "102 VGPRs -> 4 (hipcc -Rpass-analysis=kernel-resource-usage)",
+                               "measured_SQ_WAVE_CYCLES_x4_over_cycles_x_1024_simds": round(counters["SQ_WAVE_CYCLES"]["per_launch_avg"] * 4 / (cyc * 1024), 2)}
     v["int_mul"] = {"v_mad_u64_u32_per_permutation": mad["per_permutation"], "of_which_in_the_80_sboxes": 33120,
                     "lane_multiplies_per_cycle_chip": round(lane_mul_per_cycle, 1),
                     "ubench_peak_per_cycle_chip": round(peak_per_cycle, 1), "saturated_cycles_per_v_mad_u64_u32": mad_rate,
@@ -165,6 +168,56 @@ if f_med and w_med:
          "hbm_read_bytes_per_launch": int(rd), "hbm_write_bytes_per_launch": int(wr),
          "algorithmic_read_bytes": 1 << 33, "algorithmic_write_bytes": (1 << 22) * 32,
          "read_over_algorithmic": rd / (1 << 33), "correction": res["correction"]}
+    # ---- the issue side of THIS kernel, from its own `hsq` pass and its own ISA (tools/valu_roof.py -> <round>_valu_classes_hash_cells.json)
+    hc = counters_of(("hsq", "hsq2"), "cp2k::k_hash_cells", grid=1 << 22)
+    h_pass_ms = hc.pop("_pass_kernel_ms")
+    if "SQ_INSTS_VALU" in hc and "GRBM_GUI_ACTIVE" in hc:
+        n_cells, steps = 1 << 22, 34
+        waves_h = n_cells / 64
+        cyc_h = hc["GRBM_GUI_ACTIVE"]["per_launch_avg"] / 8
+        insts_h = hc["SQ_INSTS_VALU"]["per_launch_avg"]
+        cyc_wave_cell = cyc_h * 1024 / waves_h
+        hv = {"bound": "valu-issue", "pass": "hsq (rocprofv3 --pmc SQ_INSTS_VALU ... GRBM_GUI_ACTIVE, one pass, the %d launches over the whole 8 GiB slot)" % hc["SQ_INSTS_VALU"]["launches"],
+              "valu_insts_per_cell": insts_h / waves_h, "valu_insts_per_permutation": insts_h / waves_h / steps,
+              "cycles_per_wave_cell": round(cyc_wave_cell, 1), "cycles_per_wave_permutation": round(cyc_wave_cell / steps, 1),
+              "cycles_per_valu_instruction": round(cyc_h * 1024 / insts_h, 4),
+              "shader_cycles_per_launch": cyc_h, "valu_wave_insts_per_launch": insts_h,
+              "kernel_ms_in_this_pass": h_pass_ms.get("hsq"),
+              "shader_clock_GHz_in_this_pass": (cyc_h / (h_pass_ms["hsq"] * 1e-3) / 1e9) if h_pass_ms.get("hsq") else None,
+              "waves_per_simd": {"by_lds": 3, "measured_SQ_WAVE_CYCLES_x4_over_cycles_x_1024_simds":
+                                 round(hc["SQ_WAVE_CYCLES"]["per_launch_avg"] * 4 / (cyc_h * 1024), 2) if "SQ_WAVE_CYCLES" in hc else None},
+              "other_counters_per_launch": {k: v["per_launch_avg"] for k, v in hc.items() if k not in ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE")}}
+        hcls_path = os.path.join(P, "%s_valu_classes_hash_cells.json" % R)
+        if os.path.exists(hcls_path):
+            cl = json.load(open(hcls_path))
+            mad = next(r for r in cl["opcodes"] if r["opcode"] == "v_mad_u64_u32")
+            n_isa = cl["valu_insts_per_permutation_from_isa"]
+            floors = {"nominal_per_opcode": cl["class_floor_cycles_nominal"],
+                      "nominal_if_every_non_multiply_issued_in_2": 4.0 * mad["per_permutation"] + 2.0 * (n_isa - mad["per_permutation"]),
+                      "homogeneous_stream_prices_per_opcode_NOT_a_floor": cl["class_floor_cycles_measured"]}
+            per_perm = cyc_wave_cell / steps
+            hv["instruction_classes_per_permutation"] = {k: round(v, 1) for k, v in cl["per_class"].items()}
+            hv["isa_count_vs_counter"] = {"valu_insts_per_cell_from_isa": cl["valu_insts_per_cell_from_isa"], "SQ_INSTS_VALU_per_wave_cell": insts_h / waves_h,
+                                          "isa_over_counter": round(cl["valu_insts_per_cell_from_isa"] / (insts_h / waves_h), 4),
+                                          "note": "the ISA count walks the kernel's loop nest at cellSize 2048 (17 lines, 34 absorb steps); the staging blocks outside the absorb loop "
+                                                  "(0.5 % of the stream) are priced approximately"}
+            hv["class_floor_cycles"] = {k: (round(x, 1) if x else None) for k, x in floors.items()}
+            hv["frac_of_class_floor"] = {k: (round(x / per_perm, 4) if x else None) for k, x in floors.items()}
+            hv["classes_source"] = "profiles/%s_valu_classes_hash_cells.json (tools/valu_roof.py)" % R
+            ub3 = None
+            ub_path = os.path.join(P, "%s_ubench_classes_pmc.json" % R)
+            if os.path.exists(ub_path):
+                ub3 = json.load(open(ub_path)).get("by_occupancy", {}).get("v_mad_u64_u32", {})
+            mad_rate = mad["measured_saturated_cycles"] or 4.0
+            lane_mul_per_cycle = mad["per_permutation"] * steps * n_cells / cyc_h
+            peak_per_cycle = 1024 * 64 / mad_rate
+            hv["int_mul"] = {"v_mad_u64_u32_per_permutation": round(mad["per_permutation"], 1),
+                             "lane_multiplies_per_cycle_chip": round(lane_mul_per_cycle, 1), "ubench_peak_per_cycle_chip": round(peak_per_cycle, 1),
+                             "saturated_cycles_per_v_mad_u64_u32": mad_rate, "frac_of_ubench_peak": round(lane_mul_per_cycle / peak_per_cycle, 4),
+                             "v_mad_u64_u32_cycles_at_this_kernels_occupancy": (ub3 or {}).get("waves_per_simd_3"),
+                             "frac_of_ubench_rate_at_3_waves": round(lane_mul_per_cycle / (1024 * 64 / ub3["waves_per_simd_3"]), 4) if ub3 and ub3.get("waves_per_simd_3") else None,
+                             "share_of_issue_cycles": round(mad["per_permutation"] * mad_rate / per_perm, 4)}
+        h["valu_issue"] = hv
     json.dump(h, open(os.path.join(P, "%s_hash_cells_traffic.json" % R), "w"), indent=1)
     print(json.dumps(h))
 for r in rows:

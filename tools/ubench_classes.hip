@@ -4,7 +4,9 @@
 // and tools/ubench_classes_summarize.py turns the counter CSV into cycles per wave-instruction per SIMD
 // (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs / SQ_INSTS_VALU), one figure per kernel = per opcode.
 // Every kernel runs a loop of 32 independent instructions of ONE kind (inline asm, 8 accumulators); the grid puts
-// W waves on every SIMD (256 CUs x 4 SIMDs): W = 5 is k_permute_batch's own occupancy (102 VGPRs), W = 8 the most a SIMD holds.
+// W waves on every SIMD (256 CUs x 4 SIMDs): W = 4 is k_permute_batch's own occupancy (102 VGPRs -> 4 waves: the compiler's
+// kernel-resource-usage remark and SQ_WAVE_CYCLES agree; rounds 1-4 said 5), W = 3 k_hash_cells' (LDS ring: three workgroups per CU),
+// W = 5 and 8 (the most a SIMD holds) for the trend.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -69,7 +71,7 @@ int main() {
   CK(hipEventCreate(&e1));
   printf("device %s  CUs=%d  clock=%d kHz; wall-derived cycles per wave-instruction per SIMD at that nominal clock (the PMC figures come from the profiler)\n",
          prop.gcnArchName, cus, prop.clockRate);
-  const int waves[] = {5, 8};
+  const int waves[] = {3, 4, 5, 8};
   for (int w : waves) {                                 // grid = cus * w blocks of 4 waves: w waves on every SIMD
     for (const Entry& e : ks) {
       hipLaunchKernelGGL(e.k, dim3(cus * w), dim3(256), 0, 0, out, 3u, 5u);   // warm-up (also the first launch's code load)

@@ -27,7 +27,8 @@ best = {op: min(t.values()) for op, t in table.items()}
 out = {"round": R, "tool": "tools/ubench_classes.hip under rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES (one pass)",
        "unit": "shader cycles per wave-instruction per SIMD = GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs / SQ_INSTS_VALU; loops of 32 independent instructions of one kind",
        "by_occupancy": table, "cycles_per_instruction": best,
-       "note": "cycles_per_instruction = the lower (saturated) of the 5- and 8-waves-per-SIMD figures; 5 is k_permute_batch's own occupancy"}
+       "note": "cycles_per_instruction = the lowest (saturated) figure over the occupancies run (3, 4, 5, 8 waves per SIMD); k_permute_batch runs at 4 "
+               "(102 VGPRs), k_hash_cells at 3 (LDS ring): by_occupancy holds the price list at each"}
 json.dump(out, open(os.path.join(ROOT, "profiles", "%s_ubench_classes_pmc.json" % R), "w"), indent=1, sort_keys=True)
 for op, t in sorted(table.items(), key=lambda kv: -best[kv[0]]):
     print("%-16s %s" % (op, t))
