@@ -96,6 +96,7 @@ def load_library():
         "cp2_strerror": (cp, [i32]),
         "cp2_last_error": (cp, [vp]),
         "cp2_device_is_native": (i32, [vp]),
+        "cp2_check_environment": (i32, [cp, sz]),
         "cp2_set_ingest": (i32, [vp, i32, i32, sz]),
         "cp2_set_ingest_direct": (i32, [vp, i32]),
         "cp2_trim": (i32, [vp]),
@@ -198,6 +199,13 @@ def load_library():
     L._cp2_signatures = sigs
     _lib = L
     return L
+
+
+def check_environment():
+    """cp2_check_environment: None when every CODEX_P2_* variable holds what it takes, else the message naming the first that does not."""
+    L = load_library()
+    buf = ctypes.create_string_buffer(512)
+    return None if L.cp2_check_environment(buf, len(buf)) == CP2_OK else buf.value.decode()
 
 
 def exported_symbols():

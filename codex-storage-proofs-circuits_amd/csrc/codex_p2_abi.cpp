@@ -9,8 +9,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "trees.hpp"
@@ -18,11 +20,146 @@
 using namespace cp2i;
 
 // ---------------------------------------------------------------------------------------------
+// the environment, parsed strictly; device-memory accounting (internal.hpp)
+// ---------------------------------------------------------------------------------------------
+namespace cp2i {
+
+bool env_decimal(const char* name, uint64_t* value, bool* set) {
+  if (set) *set = false;
+  const char* e = std::getenv(name);
+  if (!e || !*e) return true;
+  const std::string t(e);
+  if (t.size() > 18 || t.find_first_not_of("0123456789") != std::string::npos) return false;
+  if (value) *value = std::strtoull(e, nullptr, 10);
+  if (set) *set = true;
+  return true;
+}
+
+bool env_keep_trees(int* mode) {
+  if (mode) *mode = -1;
+  const char* e = std::getenv("CODEX_P2_KEEP_TREES");
+  if (!e || !*e || std::strcmp(e, "auto") == 0) return true;
+  if ((e[0] == '0' || e[0] == '1' || e[0] == '2') && e[1] == 0) {
+    if (mode) *mode = e[0] - '0';
+    return true;
+  }
+  return false;
+}
+
+size_t mem_limit_bytes() {
+  uint64_t mb = 0;
+  bool set = false;
+  if (!env_decimal("CODEX_P2_MEM_LIMIT_MB", &mb, &set) || !set) return 0;   // (a malformed value is refused by cp2_check_environment before any build)
+  return (size_t)mb << 20;
+}
+
+namespace {
+struct DevLedger {
+  std::mutex mu;
+  std::unordered_map<void*, std::pair<int, size_t>> blocks;   // pointer -> (device, bytes)
+  size_t held[64] = {};
+};
+DevLedger& ledger() {
+  static DevLedger* l = new DevLedger();   // never destroyed: frees may still arrive while the process shuts down
+  return *l;
+}
+}  // namespace
+
+hipError_t dev_malloc(void** p, size_t n) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+  dev &= 63;
+  const size_t limit = mem_limit_bytes();
+  DevLedger& l = ledger();
+  if (limit) {
+    std::lock_guard<std::mutex> lk(l.mu);
+    if (l.held[dev] + n > limit) return hipErrorOutOfMemory;      // the cap behaves like the device running out
+  }
+  hipError_t e = hipMalloc(p, n);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(l.mu);
+  l.blocks[*p] = {dev, n};
+  l.held[dev] += n;
+  return hipSuccess;
+}
+
+void dev_free(void* p, size_t) {
+  if (!p) return;
+  {
+    DevLedger& l = ledger();
+    std::lock_guard<std::mutex> lk(l.mu);
+    auto it = l.blocks.find(p);
+    if (it != l.blocks.end()) {
+      l.held[it->second.first] -= it->second.second;
+      l.blocks.erase(it);
+    }
+  }
+  (void)hipFree(p);
+}
+
+size_t dev_bytes_held() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+  DevLedger& l = ledger();
+  std::lock_guard<std::mutex> lk(l.mu);
+  return l.held[dev & 63];
+}
+
+}  // namespace cp2i
+
+// Host-only: every CODEX_P2_* variable holds what it takes, or the first one that does not is named in `msg`.
+extern "C" int cp2_check_environment(char* msg, size_t msg_len) try {
+  auto fail = [&](const char* var, const char* takes) {
+    if (msg && msg_len) std::snprintf(msg, msg_len, "%s=\"%s\" is not what the variable takes: %s", var, std::getenv(var) ? std::getenv(var) : "", takes);
+    return CP2_ERR_INVALID;
+  };
+  if (msg && msg_len) msg[0] = 0;
+  if (const char* e = std::getenv("CODEX_P2_GPUS")) {
+    const std::string s(e);
+    bool ok = !s.empty();
+    if (s == "all") {
+      ok = true;
+    } else if (s.find(',') == std::string::npos) {
+      ok = ok && s.size() <= 6 && s.find_first_not_of("0123456789") == std::string::npos && std::strtol(s.c_str(), nullptr, 10) >= 1;
+    } else {
+      size_t at = 0, n = 0;
+      while (ok && at < s.size()) {
+        size_t c = s.find(',', at);
+        if (c == std::string::npos) c = s.size();
+        if (c > at) {
+          const std::string t = s.substr(at, c - at);
+          ok = t.size() <= 6 && t.find_first_not_of("0123456789") == std::string::npos;
+          ++n;
+        }
+        at = c + 1;
+      }
+      ok = ok && n > 0;
+    }
+    if (*e && !ok) return fail("CODEX_P2_GPUS", "\"all\", a device count (\"4\") or a comma-separated list of device indices (\"0,2,3\"; \"2,\" = device 2 only)");
+  }
+  uint64_t v = 0;
+  bool set = false;
+  if (!env_decimal("CODEX_P2_MIN_CELLS", &v, &set)) return fail("CODEX_P2_MIN_CELLS", "a decimal number of cells");
+  if (!env_decimal("CODEX_P2_SPLIT", &v, &set) || (set && v > 1 && (v & (v - 1)))) return fail("CODEX_P2_SPLIT", "0 (choose), 1 (whole slots) or a power of two (units per slot)");
+  if (!env_decimal("CODEX_P2_MEM_LIMIT_MB", &v, &set)) return fail("CODEX_P2_MEM_LIMIT_MB", "a decimal number of MiB (0 = no cap)");
+  if (!env_decimal("CODEX_P2_EXCHANGE_TIMEOUT_S", &v, &set)) return fail("CODEX_P2_EXCHANGE_TIMEOUT_S", "a decimal number of seconds (0 = wait for ever)");
+  if (const char* e = std::getenv("CODEX_P2_GATHER"))
+    if (*e && std::strcmp(e, "auto") && std::strcmp(e, "rccl") && std::strcmp(e, "host") && std::strcmp(e, "copy"))
+      return fail("CODEX_P2_GATHER", "\"auto\", \"rccl\", \"copy\" or \"host\"");
+  int mode = -1;
+  if (!env_keep_trees(&mode)) return fail("CODEX_P2_KEEP_TREES", "\"auto\", \"1\" (every node), \"2\" (compact) or \"0\" (roots only)");
+  return CP2_OK;
+} catch (...) {
+  return CP2_ERR_INVALID;
+}
+
+// ---------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------
 extern "C" int cp2_init(int device, cp2_ctx** out) try {
   if (!out) return CP2_ERR_INVALID;
   *out = nullptr;
+  if (cp2_check_environment(nullptr, 0) != CP2_OK) return CP2_ERR_INVALID;   // a mistyped CODEX_P2_* knob is refused, never read as "automatic"
   StageTimer trace;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return CP2_ERR_NO_DEVICE;

@@ -16,6 +16,23 @@
 
 namespace cp2i {
 
+// ---- the environment, parsed strictly (environment.cpp lives in codex_p2_abi.cpp) ----------------------------------------------
+// Every CODEX_P2_* variable either holds exactly what it takes or the call that reads it fails with CP2_ERR_INVALID and a message
+// that names the variable: a mistyped knob must never silently mean "automatic" (cp2_check_environment, include/codex_p2.h).
+//   env_decimal  unset / empty: true, *set = false.  A plain decimal number of at most 18 digits: true, *set = true.  Else false.
+bool env_decimal(const char* name, uint64_t* value, bool* set);
+// CODEX_P2_KEEP_TREES: "0" / "1" / "2", or "auto" (= unset).  false when it holds anything else.  *mode = -1 when automatic.
+bool env_keep_trees(int* mode);
+// CODEX_P2_MEM_LIMIT_MB (tests, rehearsals): a cap on the device memory this PROCESS may hold per device through the library's own
+// allocations, in MiB; 0 / unset = none.  The automatic residency choice sees min(what the device has free, what the cap leaves),
+// and an allocation that would exceed the cap fails like a real out-of-memory -- so the three residency modes and the fallback
+// between them can be reached on a device with 288 GB free.
+size_t mem_limit_bytes();
+// device allocations of this process through the library, per HIP device (for the cap and for the residency estimate)
+hipError_t dev_malloc(void** p, size_t n);
+void dev_free(void* p, size_t n);
+size_t dev_bytes_held();            // on the current device
+
 // Per-context cache of device and pinned-host scratch blocks.  The host-pointer entry points (one hipMalloc +
 // hipFree pair per call before) and the staging buffers of the builders draw from it, so a context that is
 // called repeatedly stops allocating after its first calls.  Blocks are handed back only when no work that
@@ -43,12 +60,12 @@ class BlockPool {
     }
     size_t want = round_up(n);
     void* p = nullptr;
-    hipError_t e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+    hipError_t e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : dev_malloc(&p, want);
     if (e != hipSuccess) {   // make room and try the exact size once
       (void)hipGetLastError();
       trim();
       want = n;
-      e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+      e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : dev_malloc(&p, want);
       if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     }
     *got = want;
@@ -65,7 +82,7 @@ class BlockPool {
         return;
       }
     }
-    if (pinned) (void)hipHostFree(p); else (void)hipFree(p);
+    if (pinned) (void)hipHostFree(p); else dev_free(p, bytes);
   }
   void trim() {
     std::vector<Blk> d, h;
@@ -74,7 +91,7 @@ class BlockPool {
       d.swap(dev_); h.swap(pin_);
       cached_dev_ = cached_pin_ = 0;
     }
-    for (auto& b : d) (void)hipFree(b.p);
+    for (auto& b : d) dev_free(b.p, b.bytes);
     for (auto& b : h) (void)hipHostFree(b.p);
   }
 
@@ -106,6 +123,7 @@ struct cp2_ctx {
   size_t ingest_chunk = 0;
   int ingest_direct = -1;                    // SlotFile reads with O_DIRECT: 1 on, 0 off, -1 = environment CP2_INGEST_DIRECT (cp2_set_ingest_direct)
   size_t body_budget = 0;                    // streamed proof-input bodies kept in host memory; 0: CP2_BODY_BUDGET_MB or 4 GiB (cp2_set_body_budget)
+  int mem_share = 1;                         // how many contexts of this process build on this context's DEVICE at the same time (cp2_multi sets it): the automatic residency choice takes 1 / mem_share of what the device has free
   int keep_trees = -1;                       // what cp2_dataset_build keeps of the slot trees in device memory: 1 every node, 2 block roots and up, 0 roots only, -1 = CODEX_P2_KEEP_TREES or the most that fits (cp2_set_keep_trees)
   std::string spill_dir;                     // where bodies beyond the budget go; empty: $TMPDIR or /tmp
   std::string err;
@@ -134,33 +152,41 @@ struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
   cp2_ctx* owner = nullptr;   // non-null: pooled
+  bool borrowed = false;      // a view of memory someone else owns (a batch's nodes inside a pipeline's scratch): never freed from here
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
+  void borrow(void* q, size_t n) {
+    release();
+    p = q;
+    bytes = n;
+    borrowed = true;
+  }
   void release() {
-    if (p) {
+    if (p && !borrowed) {
       if (owner) {
         (void)hipStreamSynchronize(owner->stream);
         if (owner->aux_stream) (void)hipStreamSynchronize(owner->aux_stream);
         if (owner->aux2_stream) (void)hipStreamSynchronize(owner->aux2_stream);
         owner->pool->put(false, p, bytes);
       } else {
-        (void)hipFree(p);
+        dev_free(p, bytes);
       }
     }
     p = nullptr;
     bytes = 0;
     owner = nullptr;
+    borrowed = false;
   }
   int alloc(cp2_ctx* ctx, size_t n) {
     release();
     if (n == 0) n = 16;
-    hipError_t e = hipMalloc(&p, n);
+    hipError_t e = dev_malloc(&p, n);
     if (e != hipSuccess) {
       (void)hipGetLastError();
       ctx->pool->trim();        // cached scratch may be what is in the way
-      e = hipMalloc(&p, n);
+      e = dev_malloc(&p, n);
     }
     if (e != hipSuccess) {
       (void)hipGetLastError();   // reported here; must not resurface from a later hipGetLastError()

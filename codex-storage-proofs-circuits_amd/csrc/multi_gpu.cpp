@@ -18,6 +18,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <array>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -43,7 +46,7 @@ struct Rccl {
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
-  std::string why;   // why it could not be loaded
+  std::string why;   // why it could not be loaded -- or why it is no longer to be used (an initialisation that never returned)
 
   static Rccl& get() {
     static Rccl r;
@@ -51,7 +54,8 @@ struct Rccl {
     std::call_once(once, [] { r.load(); });
     return r;
   }
-  bool ok() const { return lib != nullptr; }
+  bool ok() const { return lib != nullptr && !abandoned; }
+  bool abandoned = false;   // ncclCommInitAll did not return in time: its thread still runs somewhere inside the library, hands off
 
  private:
   void load() {
@@ -118,13 +122,14 @@ struct cp2_multi {
   }
 };
 
-// device indices from the environment: CODEX_P2_GPUS = "<count>" (the first <count> visible devices) or a comma-separated
+// device indices from the environment: CODEX_P2_GPUS = "all", "<count>" (the first <count> visible devices) or a comma-separated
 // list of indices ("0,2,3"; "0,0" = two contexts on device 0; "2," = device 2 only)
-// returns 1 when the variable named devices, 0 when it is unset, -1 when it is set to something that is not a count or an index list
+// returns 1 when the variable named devices, 2 for "all", 0 when it is unset, -1 when it is set to anything else
 static int devices_from_env(int visible, std::vector<int>& out) {
   const char* e = std::getenv("CODEX_P2_GPUS");
   if (!e || !*e) return 0;
   const std::string s(e);
+  if (s == "all") return 2;                      // every visible gfx950 device
   auto number = [](const std::string& t, long* v) {
     if (t.empty() || t.size() > 6 || t.find_first_not_of("0123456789") != std::string::npos) return false;
     *v = std::strtol(t.c_str(), nullptr, 10);
@@ -152,38 +157,39 @@ static int devices_from_env(int visible, std::vector<int>& out) {
 extern "C" int cp2_multi_init(const int* devices, int n_dev, cp2_multi** out) try {
   if (!out || n_dev < 0 || (n_dev > 0 && !devices)) return CP2_ERR_INVALID;
   *out = nullptr;
+  // the environment first, before anything touches HIP: a mistyped knob is refused (and named by cp2_check_environment) whatever the box
+  if (cp2_check_environment(nullptr, 0) != CP2_OK) return CP2_ERR_INVALID;
   StageTimer trace;
   int visible = 0;
   if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) { (void)hipGetLastError(); return CP2_ERR_NO_DEVICE; }
   trace.lap("HIP runtime init (device count)");
   std::unique_ptr<cp2_multi> m(new cp2_multi());
   const int from_env = n_dev > 0 ? 0 : devices_from_env(visible, m->devices);
-  if (from_env < 0) return CP2_ERR_INVALID;      // CODEX_P2_GPUS is set but is neither "<count>" nor an index list: not guessed at
+  if (from_env < 0) return CP2_ERR_INVALID;      // CODEX_P2_GPUS is set but is neither "all", "<count>" nor an index list: not guessed at
   if (n_dev > 0) {
     m->devices.assign(devices, devices + n_dev);
-  } else if (from_env == 0) {
-    for (int d = 0; d < visible; ++d) {          // every visible gfx950 device
+  } else if (from_env == 0 || from_env == 2) {
+    // No device named: ONE device, the first visible gfx950 -- several devices are opt-in (CODEX_P2_GPUS=all | <count> | <list>, or an
+    // explicit device list from the caller) until the exchange between two REAL devices has a committed record (DESIGN.md section 7:
+    // this pipeline's GPU boxes hold one device; tests/test_gpu_multi.py -k real_device is the run that produces it).
+    for (int d = 0; d < visible; ++d) {
       hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, d) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) m->devices.push_back(d);
+      if (hipGetDeviceProperties(&prop, d) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) {
+        m->devices.push_back(d);
+        if (from_env == 0) break;
+      }
     }
   }
   if (m->devices.empty()) return CP2_ERR_NO_DEVICE;
   for (int d : m->devices)
     if (d < 0 || d >= visible) return CP2_ERR_NO_DEVICE;
   m->ctxs.assign(m->devices.size(), nullptr);
-  // CODEX_P2_MIN_CELLS (cp2_multi_set_policy) and CODEX_P2_SPLIT (cp2_multi_set_split): plain decimal numbers, or refused like CODEX_P2_GPUS
-  auto env_number = [](const char* name, uint64_t* v) {
-    const char* e = std::getenv(name);
-    if (!e || !*e) return true;
-    const std::string t(e);
-    if (t.size() > 18 || t.find_first_not_of("0123456789") != std::string::npos) return false;
-    *v = std::strtoull(e, nullptr, 10);
-    return true;
-  };
+  // CODEX_P2_MIN_CELLS (cp2_multi_set_policy), CODEX_P2_SPLIT (cp2_multi_set_split), CODEX_P2_GATHER: checked above, read here
   uint64_t split = 0;
-  if (!env_number("CODEX_P2_MIN_CELLS", &m->min_cells) || !env_number("CODEX_P2_SPLIT", &split) || (split > 1 && !is_pow2(split))) return CP2_ERR_INVALID;
+  (void)env_decimal("CODEX_P2_MIN_CELLS", &m->min_cells, nullptr);
+  (void)env_decimal("CODEX_P2_SPLIT", &split, nullptr);
   m->split = (int64_t)split;
-  if (const char* e = std::getenv("CODEX_P2_GATHER")) {                                                      // "rccl" / "host" / anything else: auto
+  if (const char* e = std::getenv("CODEX_P2_GATHER")) {
     if (std::strcmp(e, "rccl") == 0) m->gather = CP2_GATHER_RCCL;
     else if (std::strcmp(e, "host") == 0) m->gather = CP2_GATHER_HOST;
     else if (std::strcmp(e, "copy") == 0) m->gather = CP2_GATHER_COPY;
@@ -295,13 +301,101 @@ struct Exchanged {
   std::vector<const void*> dev;
   std::vector<uint8_t> host;
   bool on_device = false;
+  // work that may still be reading or writing these buffers could not be waited for (it timed out): they must never go back to
+  // a pool or to the device's allocator -- they are dropped from the books instead (a leak, said so in the error message)
+  void abandon() {
+    for (auto* v : {&gath, &all})
+      for (auto& b : *v) { b.p = nullptr; b.bytes = 0; b.owner = nullptr; }
+  }
 };
+
+// seconds an exchange may take before it is given up (CODEX_P2_EXCHANGE_TIMEOUT_S; 0 = wait for ever).  The exchange moves 1 MiB;
+// what this bounds is a collective that never completes on first contact with a machine (a peer that cannot be reached, a
+// communicator whose creation hangs) -- the caller gets an error that says so instead of a process that never returns.
+double exchange_timeout_s() {
+  uint64_t v = 120;
+  bool set = false;
+  if (env_decimal("CODEX_P2_EXCHANGE_TIMEOUT_S", &v, &set) && set) return (double)v;
+  return 120.0;
+}
+
+// Waits until every participating context's stream has drained.  Bounded: false when `timeout_s` (> 0) passed first.
+bool drain_streams(const std::vector<RootsPart>& parts, double timeout_s) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (auto& p : parts) {
+    (void)hipSetDevice(p.ctx->device);
+    if (timeout_s <= 0) { (void)hipStreamSynchronize(p.ctx->stream); continue; }
+    for (;;) {
+      hipError_t e = hipStreamQuery(p.ctx->stream);
+      if (e != hipErrorNotReady) { (void)hipGetLastError(); break; }
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+  }
+  return true;
+}
+
+// Whatever path leaves exchange_roots, the participating streams are drained before its buffers can be destroyed by the caller:
+// a context's gather buffer is read by its PEERS (RCCL kernels, peer copies), so its own stream alone says nothing.  When even the
+// bounded drain does not finish, the buffers are abandoned rather than handed back while something may still touch them.
+struct ExchangeGuard {
+  const std::vector<RootsPart>& parts;
+  Exchanged& ex;
+  double timeout_s;
+  bool done = false;                   // set on the success path, which drains (and checks) by itself
+  ~ExchangeGuard() {
+    if (done) return;
+    if (!drain_streams(parts, timeout_s)) ex.abandon();
+  }
+};
+
+// ncclCommInitAll on a helper thread, so that a creation that never returns (first contact with a machine's fabric) costs a
+// timeout and not the process: on timeout the thread is left behind with everything it references kept alive, RCCL is marked
+// abandoned for the rest of the process and the caller falls back (automatic mode) or reports it (RCCL by name).
+struct CommInit {
+  std::mutex mu;
+  std::condition_variable cv;
+  bool finished = false;
+  ncclResult_t result = ncclSuccess;
+  std::vector<ncclComm_t> comms;
+  std::vector<int> devices;
+};
+bool comm_init_all(Rccl& r, const std::vector<int>& devices, size_t world, double timeout_s, std::vector<ncclComm_t>& out, std::string& why) {
+  auto st = std::make_shared<CommInit>();
+  st->comms.assign(world, nullptr);
+  st->devices.assign(devices.begin(), devices.begin() + (long)world);
+  std::thread th([st, &r] {
+    ncclResult_t e = r.CommInitAll(st->comms.data(), (int)st->comms.size(), st->devices.data());
+    std::lock_guard<std::mutex> lk(st->mu);
+    st->result = e;
+    st->finished = true;
+    st->cv.notify_all();
+  });
+  std::unique_lock<std::mutex> lk(st->mu);
+  const bool in_time = timeout_s <= 0 ? (st->cv.wait(lk, [&] { return st->finished; }), true)
+                                      : st->cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return st->finished; });
+  if (!in_time) {
+    lk.unlock();
+    th.detach();                       // `st` stays alive through the thread's copy of the shared pointer
+    r.abandoned = true;
+    r.why = why = "ncclCommInitAll did not return within " + std::to_string((int)timeout_s) + " s (abandoned for the rest of this process)";
+    return false;
+  }
+  lk.unlock();
+  th.join();
+  if (st->result != ncclSuccess) {
+    why = std::string("ncclCommInitAll: ") + r.GetErrorString(st->result);
+    return false;
+  }
+  out = st->comms;
+  return true;
+}
 
 // THE exchange step: every shard's roots to every device.  RCCL (device to device) when every shard sits on its own device and
 // librccl loads; host memory otherwise; by name also plain device-to-device copies (CP2_GATHER_COPY: the RCCL path's buffers,
 // layout and compaction with the collective written out as peer copies -- no library, any mix of devices).  One shard and no
-// RCCL by name: nothing moves.
-int exchange_roots(cp2_multi* m, const std::vector<RootsPart>& parts, uint64_t n, Exchanged& ex) {
+// RCCL by name: nothing moves.  `force_host`: the automatic mode's second attempt after a device path failed its verification.
+int exchange_roots(cp2_multi* m, const std::vector<RootsPart>& parts, uint64_t n, Exchanged& ex, bool force_host = false) {
   const size_t world = parts.size();
   ex.dev.assign(world, nullptr);
   if (world == 1 && m->gather != CP2_GATHER_RCCL) {   // (RCCL asked for by name: a communicator of one rank, as a self-test of the path)
@@ -311,31 +405,31 @@ int exchange_roots(cp2_multi* m, const std::vector<RootsPart>& parts, uint64_t n
     return CP2_OK;
   }
   DeviceRestore restore;
+  const double timeout_s = exchange_timeout_s();
+  ExchangeGuard guard{parts, ex, timeout_s};
   bool distinct = true;                        // RCCL needs one rank per DISTINCT device
   for (size_t i = 0; i < world; ++i)
     for (size_t j = 0; j < i; ++j)
       if (parts[i].ctx->device == parts[j].ctx->device) distinct = false;
-  std::string why;
-  const bool use_copy = m->gather == CP2_GATHER_COPY;   // device-to-device copies, pair by pair: same layout and compaction as RCCL, no library
-  bool use_rccl = m->gather != CP2_GATHER_HOST && !use_copy;
+  std::string why = force_host ? "the device-to-device exchange failed its verification" : "";
+  const bool use_copy = m->gather == CP2_GATHER_COPY && !force_host;   // device-to-device copies, pair by pair: same layout and compaction as RCCL, no library
+  bool use_rccl = m->gather != CP2_GATHER_HOST && !use_copy && !force_host;
   if (use_rccl && !distinct) { use_rccl = false; why = "a device holds more than one shard"; }
   if (use_rccl && !Rccl::get().ok()) { use_rccl = false; why = Rccl::get().why; }
   if (use_rccl) {
     Rccl& r = Rccl::get();
     if (m->comm_world != (int)world) {          // shards are always devices[0 .. world)
       m->drop_comms();
-      m->comms.assign(world, nullptr);
-      ncclResult_t e = r.CommInitAll(m->comms.data(), (int)world, m->devices.data());
-      if (e != ncclSuccess) {
-        why = std::string("ncclCommInitAll: ") + r.GetErrorString(e);
-        m->comms.clear();
-        use_rccl = false;
-      } else {
+      std::vector<ncclComm_t> comms;
+      if (comm_init_all(r, m->devices, world, timeout_s, comms, why)) {
+        m->comms = comms;
         m->comm_world = (int)world;
+      } else {
+        use_rccl = false;
       }
     }
   }
-  if (!use_rccl && m->gather == CP2_GATHER_RCCL) {
+  if (!use_rccl && m->gather == CP2_GATHER_RCCL && !force_host) {
     m->err = "RCCL gather requested but unavailable: " + why;
     return CP2_ERR_INVALID;
   }
@@ -360,7 +454,7 @@ int exchange_roots(cp2_multi* m, const std::vector<RootsPart>& parts, uint64_t n
       if (e == ncclSuccess) e = e2;
       if (e != ncclSuccess) {
         m->err = std::string("ncclAllGather: ") + r.GetErrorString(e);
-        return CP2_ERR_HIP;
+        return CP2_ERR_HIP;                       // (the guard drains what was enqueued before the buffers go)
       }
       m->gather_note = "rccl (in-place ncclAllGather of " + std::to_string(max_rows * 32) + " bytes per rank over " + std::to_string(world) + " devices)";
     } else {
@@ -392,12 +486,30 @@ int exchange_roots(cp2_multi* m, const std::vector<RootsPart>& parts, uint64_t n
                                     hipMemcpyDeviceToDevice, ctx->stream));
       ex.dev[i] = ex.all[i].p;
     }
+    if (const char* fault = std::getenv("CODEX_P2_TEST_EXCHANGE_FAULT")) {
+      // test-only: flip one byte of the LAST context's gathered copy -- what a wrong rank-to-device mapping or a misplaced block
+      // would look like to the verification that follows the exchange (tests/test_gpu_multi.py)
+      if (std::strcmp(fault, "corrupt") == 0) {
+        cp2_ctx* ctx = parts[world - 1].ctx;
+        CP2_HIP(ctx, hipSetDevice(ctx->device));
+        CP2_HIP(ctx, hipMemsetAsync(const_cast<uint8_t*>(static_cast<const uint8_t*>(ex.dev[world - 1])) + 5, 0x5a, 1, ctx->stream));
+      }
+    }
     // the exchange is COMPLETE when this returns: a context's buffers are read by its peers (RCCL kernels, peer copies), so none
     // of them may go back to its pool on the strength of its own stream alone
-    for (auto& p : parts) {
+    if (!drain_streams(parts, timeout_s)) {
+      ex.abandon();
+      guard.done = true;
+      m->err = "the exchange of slot roots (" + m->gather_note + ") did not complete within " + std::to_string((int)timeout_s) +
+               " s; its device buffers are abandoned (CODEX_P2_EXCHANGE_TIMEOUT_S, CODEX_P2_GATHER=host)";
+      if (use_rccl) { Rccl::get().abandoned = true; Rccl::get().why = "an all-gather did not complete in time"; m->comms.clear(); m->comm_world = 0; }
+      return CP2_ERR_HIP;
+    }
+    for (auto& p : parts) {                       // a failed copy or kernel shows up here, not in the next unrelated call
       CP2_HIP(p.ctx, hipSetDevice(p.ctx->device));
       CP2_HIP(p.ctx, hipStreamSynchronize(p.ctx->stream));
     }
+    guard.done = true;
     ex.on_device = true;
     return CP2_OK;
   }
@@ -409,24 +521,72 @@ int exchange_roots(cp2_multi* m, const std::vector<RootsPart>& parts, uint64_t n
     CP2_HIP(p.ctx, hipMemcpyAsync(ex.host.data() + p.first * 32, p.d_roots, p.count * 32, hipMemcpyDeviceToHost, p.ctx->stream));
     CP2_HIP(p.ctx, hipStreamSynchronize(p.ctx->stream));
   }
+  guard.done = true;
   return CP2_OK;
 }
 
-// by slots: the exchange, then the dataset tree on every device
+// by slots: the exchange, then the dataset tree on every device -- and a check that costs one 32-byte-per-slot download per
+// shard: (1) every device finds ITS OWN roots at its own rows of the list it was handed, (2) every device computed the same
+// dataset root.  Together: every device holds the same list and every block of it is where its owner put it, i.e. the exchange
+// did what it is for -- whatever carried it.  A wrong rank-to-device mapping, a misplaced block of the padded layout or a peer
+// that delivered stale memory gives CP2_ERR_HIP here, never a wrong dataSetRoot in an input.json.  In the automatic mode a
+// device path that fails the check is retried once through host memory.
 int gather_roots_and_build_trees(cp2_multi_dataset* mds) {
   cp2_multi* m = mds->m;
   const size_t world = mds->shards.size();
   std::vector<RootsPart> parts;
   for (auto& s : mds->shards) parts.push_back({cp2_dataset_ctx(s.ds), cp2_dataset_local_roots_dev(s.ds), s.first, s.count});
-  Exchanged ex;
-  CP2_TRY(exchange_roots(m, parts, mds->cfg.n_slots, ex));
-  return for_each_shard(world, [&](size_t i) -> int {
-    return ex.on_device ? cp2_dataset_set_roots_dev(mds->shards[i].ds, ex.dev[i]) : cp2_dataset_set_roots(mds->shards[i].ds, ex.host.data());
-  });
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    Exchanged ex;
+    int st = exchange_roots(m, parts, mds->cfg.n_slots, ex, attempt == 1);
+    if (st != CP2_OK) {
+      if (attempt == 0 && m->gather == CP2_GATHER_AUTO && world > 1 && st == CP2_ERR_HIP) {   // the device path broke: host memory carries 1 MiB just as well
+        const std::string first = m->err;
+        m->err.clear();
+        Exchanged ex2;
+        st = exchange_roots(m, parts, mds->cfg.n_slots, ex2, true);
+        if (st != CP2_OK) { m->err = first; return st; }
+        m->gather_note += " [first attempt: " + first + "]";
+        CP2_TRY(for_each_shard(world, [&](size_t i) -> int { return cp2_dataset_set_roots(mds->shards[i].ds, ex2.host.data()); }));
+        attempt = 1;
+      } else {
+        return st;
+      }
+    } else {
+      CP2_TRY(for_each_shard(world, [&](size_t i) -> int {
+        return ex.on_device ? cp2_dataset_set_roots_dev(mds->shards[i].ds, ex.dev[i]) : cp2_dataset_set_roots(mds->shards[i].ds, ex.host.data());
+      }));
+    }
+    if (world == 1) return CP2_OK;
+    // ---- verification
+    std::vector<char> in_place(world, 1);
+    std::vector<std::array<uint8_t, 32>> roots(world);
+    CP2_TRY(for_each_shard(world, [&](size_t i) -> int {
+      bool ok = false;
+      CP2_TRY(dataset_own_roots_in_place(mds->shards[i].ds, &ok));
+      in_place[i] = ok ? 1 : 0;
+      return cp2_dataset_root(mds->shards[i].ds, roots[i].data());
+    }));
+    std::string bad;
+    for (size_t i = 0; i < world && bad.empty(); ++i) {
+      if (!in_place[i]) bad = "the device of shard " + std::to_string(i) + " does not find its own slot roots at rows " + std::to_string(mds->shards[i].first) + ".." +
+                              std::to_string(mds->shards[i].first + mds->shards[i].count) + " of the gathered list";
+      else if (roots[i] != roots[0]) bad = "shards 0 and " + std::to_string(i) + " computed different dataset roots from the gathered list";
+    }
+    if (bad.empty()) return CP2_OK;
+    if (attempt == 0 && m->gather == CP2_GATHER_AUTO && ex.on_device) {
+      if (std::getenv("CP2_TRACE")) std::fprintf(stderr, "[cp2 trace] exchange verification FAILED (%s: %s): once more through host memory\n", m->gather_note.c_str(), bad.c_str());
+      continue;
+    }
+    m->err = "exchange verification failed (" + m->gather_note + "): " + bad;
+    return CP2_ERR_HIP;
+  }
+  return CP2_ERR_HIP;   // not reached
 }
 
 // by units: the exchange of unit roots, then -- once, on the first device -- the log2 S upper layers of every slot tree
 // (inner layers of gen_input/bn254.nim:29's tree: keys 0, never the bottom rule) and the dataset tree over the slot roots.
+// Verified like the exchange of slot roots: every shard finds its own unit roots at its rows of the list the first device built from.
 int gather_unit_roots_and_build_upper(cp2_multi_dataset* mds) {
   cp2_multi* m = mds->m;
   const uint64_t S = mds->units_per_slot, n_slots = mds->cfg.n_slots, n_units = n_slots * S;
@@ -436,33 +596,59 @@ int gather_unit_roots_and_build_upper(cp2_multi_dataset* mds) {
     CP2_HIP(p.ctx, hipSetDevice(p.ctx->device));
     CP2_HIP(p.ctx, hipStreamSynchronize(p.ctx->stream));
   }
-  Exchanged ex;
-  CP2_TRY(exchange_roots(m, parts, n_units, ex));
   DeviceRestore restore;
   cp2_ctx* ctx = parts[0].ctx;
-  CP2_HIP(ctx, hipSetDevice(ctx->device));
   size_t levels = 0;
   while (((uint64_t)1 << levels) < S) ++levels;
   size_t total = 0;
   mds->upper_off.clear();
   for (size_t k = 0; k <= levels; ++k) { mds->upper_off.push_back(total); total += n_slots * (S >> k); }
-  DevBuf up, dtree;
-  CP2_TRY(up.scratch(ctx, total * 32));
-  if (ex.on_device) CP2_HIP(ctx, hipMemcpyAsync(up.p, ex.dev[0], n_units * 32, hipMemcpyDeviceToDevice, ctx->stream));
-  else CP2_HIP(ctx, hipMemcpyAsync(up.p, ex.host.data(), n_units * 32, hipMemcpyHostToDevice, ctx->stream));
-  for (size_t k = 0; k < levels; ++k)
-    CP2_HIP(ctx, cp2k::launch_compress_layer(up.u8() + mds->upper_off[k] * 32, up.u8() + mds->upper_off[k + 1] * 32, S >> k, n_slots, false,
-                                             S >> k, S >> (k + 1), ctx->stream));
-  mds->dsizes = layer_sizes_of(n_slots);
-  const size_t dtotal = cp2_merkle_total(n_slots);
-  CP2_TRY(dtree.scratch(ctx, dtotal * 32));
-  CP2_TRY(merkle_trees_dev(ctx, up.u8() + mds->upper_off[levels] * 32, n_slots, 1, dtree.p, false));   // gen_input/bn254.nim:49-50
-  mds->upper.assign(total * 32, 0);
-  mds->dlayers.assign(dtotal * 32, 0);
-  CP2_HIP(ctx, hipMemcpyAsync(mds->upper.data(), up.p, total * 32, hipMemcpyDeviceToHost, ctx->stream));
-  CP2_HIP(ctx, hipMemcpyAsync(mds->dlayers.data(), dtree.p, dtotal * 32, hipMemcpyDeviceToHost, ctx->stream));
-  CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return CP2_OK;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    Exchanged ex;
+    int st = exchange_roots(m, parts, n_units, ex, attempt == 1);
+    if (st != CP2_OK) {
+      if (attempt == 0 && m->gather == CP2_GATHER_AUTO && parts.size() > 1 && st == CP2_ERR_HIP) { m->gather_note += " [failed: " + m->err + "]"; m->err.clear(); continue; }
+      return st;
+    }
+    CP2_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf up, dtree;
+    CP2_TRY(up.scratch(ctx, total * 32));
+    if (ex.on_device) CP2_HIP(ctx, hipMemcpyAsync(up.p, ex.dev[0], n_units * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    else CP2_HIP(ctx, hipMemcpyAsync(up.p, ex.host.data(), n_units * 32, hipMemcpyHostToDevice, ctx->stream));
+    for (size_t k = 0; k < levels; ++k)
+      CP2_HIP(ctx, cp2k::launch_compress_layer(up.u8() + mds->upper_off[k] * 32, up.u8() + mds->upper_off[k + 1] * 32, S >> k, n_slots, false,
+                                               S >> k, S >> (k + 1), ctx->stream));
+    mds->dsizes = layer_sizes_of(n_slots);
+    const size_t dtotal = cp2_merkle_total(n_slots);
+    CP2_TRY(dtree.scratch(ctx, dtotal * 32));
+    CP2_TRY(merkle_trees_dev(ctx, up.u8() + mds->upper_off[levels] * 32, n_slots, 1, dtree.p, false));   // gen_input/bn254.nim:49-50
+    mds->upper.assign(total * 32, 0);
+    mds->dlayers.assign(dtotal * 32, 0);
+    CP2_HIP(ctx, hipMemcpyAsync(mds->upper.data(), up.p, total * 32, hipMemcpyDeviceToHost, ctx->stream));
+    CP2_HIP(ctx, hipMemcpyAsync(mds->dlayers.data(), dtree.p, dtotal * 32, hipMemcpyDeviceToHost, ctx->stream));
+    CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (parts.size() == 1) return CP2_OK;
+    // every shard's own unit roots against rows [first, first + count) of what the first device built from
+    std::string bad;
+    std::vector<uint8_t> own;
+    for (size_t i = 0; i < parts.size() && bad.empty(); ++i) {
+      own.resize(parts[i].count * 32);
+      CP2_HIP(parts[i].ctx, hipSetDevice(parts[i].ctx->device));
+      CP2_HIP(parts[i].ctx, hipMemcpyAsync(own.data(), parts[i].d_roots, own.size(), hipMemcpyDeviceToHost, parts[i].ctx->stream));
+      CP2_HIP(parts[i].ctx, hipStreamSynchronize(parts[i].ctx->stream));
+      if (std::memcmp(own.data(), &mds->upper[parts[i].first * 32], own.size()) != 0)
+        bad = "the unit roots of shard " + std::to_string(i) + " are not at rows " + std::to_string(parts[i].first) + ".." + std::to_string(parts[i].first + parts[i].count) +
+              " of the list the first device received";
+    }
+    if (bad.empty()) return CP2_OK;
+    if (attempt == 0 && m->gather == CP2_GATHER_AUTO && ex.on_device) {
+      if (std::getenv("CP2_TRACE")) std::fprintf(stderr, "[cp2 trace] exchange verification FAILED (%s: %s): once more through host memory\n", m->gather_note.c_str(), bad.c_str());
+      continue;
+    }
+    m->err = "exchange verification failed (" + m->gather_note + "): " + bad;
+    return CP2_ERR_HIP;
+  }
+  return CP2_ERR_HIP;   // not reached
 }
 
 double imbalance(uint64_t items, uint64_t world) { return (double)((items + world - 1) / world * world) / (double)items; }
@@ -509,6 +695,30 @@ int multi_build(cp2_multi* m, const cp2_config* cfg, BuildKind kind, const uint8
   // whole slots or units: streamed builds keep whole slots (their per-slot bodies live in a cp2_dataset)
   uint64_t world = 1, S = 1;
   plan_shards(*cfg, m->devices.size(), m->min_cells, kind == BuildKind::Streamed ? 1 : m->split, &world, &S);
+  // how many shards build on each PHYSICAL device at the same time (an index may repeat): each context's automatic residency choice
+  // takes its share of what that device has free, not all of it (proof_input.cpp dataset_tree_mode)
+  auto share_of = [&](uint64_t r, uint64_t w) { int k = 0; for (uint64_t q = 0; q < w; ++q) k += m->devices[q] == m->devices[r]; return k; };
+  if (S > 1 && m->split == 0) {
+    // Cut by units every node of every unit tree stays resident (the compact / roots-only modes exist for whole slots).  When that
+    // does not fit the devices -- many LARGE slots: 9 x 1 TiB over 8 GPUs -- the plan falls back to whole slots, whose datasets
+    // choose their residency themselves.  (A split the caller named is taken literally.)
+    DeviceRestore restore;
+    bool fits = true;
+    for (uint64_t r = 0; r < world && fits; ++r) {
+      uint64_t first = 0, count = 0;
+      cp2_shard_range(cfg->n_slots * S, (int)r, (int)world, &first, &count);
+      size_t free_b = 0, total_b = 0;
+      if (hipSetDevice(m->devices[r]) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); continue; }
+      if (const size_t limit = mem_limit_bytes()) { const size_t held = dev_bytes_held(); free_b = std::min(free_b, limit > held ? limit - held : 0); }
+      const unsigned __int128 need = (unsigned __int128)trees_node_bytes(1, cfg->cell_size, cfg->block_size, cfg->n_cells / S) * count +
+                                     3 * std::min<unsigned __int128>((unsigned __int128)count * (cfg->n_cells / S) * cfg->cell_size, (unsigned __int128)2 << 30) + ((unsigned __int128)1 << 30);
+      fits = need <= (unsigned __int128)(free_b / (size_t)share_of(r, world)) * 9 / 10;
+    }
+    if (!fits) {
+      if (std::getenv("CP2_TRACE")) std::fprintf(stderr, "[cp2 trace] cut by %llu units the unit trees would not fit the devices: whole slots instead\n", (unsigned long long)S);
+      plan_shards(*cfg, m->devices.size(), m->min_cells, 1, &world, &S);
+    }
+  }
   std::unique_ptr<cp2_multi_dataset> mds(new cp2_multi_dataset());
   mds->m = m;
   mds->cfg = *cfg;
@@ -527,6 +737,8 @@ int multi_build(cp2_multi* m, const cp2_config* cfg, BuildKind kind, const uint8
     int cst = CP2_OK;
     cp2_ctx* ctx = m->ctx_of(s.dev, &cst);
     if (!ctx) { errs[i] = "device " + std::to_string(m->devices[s.dev]) + ": " + cp2_strerror(cst); return cst; }
+    ctx->mem_share = share_of(i, world);
+    struct ShareReset { cp2_ctx* c; ~ShareReset() { c->mem_share = 1; } } share_reset{ctx};
     int r = CP2_OK;
     if (S > 1) {
       // cached: this shard's unit trees from "<cache>.units<S>.shard<i>of<world>" when that file is intact and describes exactly

@@ -141,21 +141,32 @@ static size_t compact_bytes(const cp2_config& c, size_t n_slots) {
 
 // What of its trees does this dataset keep?  1 every node, 2 the compact part, 0 the roots.  The caller's word (cp2_set_keep_trees /
 // CODEX_P2_KEEP_TREES), else the most that fits: a buffer must leave room for the builders' staging (two 2 GiB chunks), the batch in
-// flight and some slack in what the device has free right now.
-static int dataset_tree_mode(cp2_ctx* ctx, const cp2_config& c, uint64_t n_local) {
+// flight and some slack in what the device has free right now -- a SNAPSHOT (hipMemGetInfo), shared out among the contexts a
+// cp2_multi has placed on this device (ctx->mem_share) and capped by CODEX_P2_MEM_LIMIT_MB.  *automatic says whether the mode was
+// chosen here (then dataset_build may step down when the allocation fails after all) or named by the caller (never changed).
+static int dataset_tree_mode(cp2_ctx* ctx, const cp2_config& c, uint64_t n_local, bool* automatic = nullptr) {
+  if (automatic) *automatic = false;
   int mode = ctx->keep_trees;
-  if (mode < 0) {
-    const char* e = std::getenv("CODEX_P2_KEEP_TREES");
-    if (e && *e >= '0' && *e <= '2' && e[1] == 0) mode = *e - '0';
+  if (mode < 0 && !env_keep_trees(&mode)) {
+    ctx->err = "CODEX_P2_KEEP_TREES must be \"auto\", \"1\", \"2\" or \"0\"";
+    return -1;
   }
   if (mode >= 0) return mode;
+  if (automatic) *automatic = true;
+  if (const char* t = std::getenv("CODEX_P2_TEST_OPTIMISTIC"))   // test-only: start at "every node" without looking, so that the step-down chain is what finds the mode that fits
+    if (*t == '1') return 1;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 1; }
+  if (const size_t limit = mem_limit_bytes()) {
+    const size_t held = dev_bytes_held();
+    free_b = std::min(free_b, limit > held ? limit - held : 0);
+  }
+  free_b /= (size_t)std::max(1, ctx->mem_share);
   // slack: the builders' staging (two chunks of at most 2 GiB, never more than the data itself), the node batch in flight (about
   // 2 GiB for the transient modes) and 1 GiB of headroom
   const unsigned __int128 data = (unsigned __int128)n_local * c.n_cells * c.cell_size;
   const unsigned __int128 chunk = std::min<unsigned __int128>(data, (unsigned __int128)2 << 30);
-  const unsigned __int128 room = (unsigned __int128)free_b * 9 / 10, slack = 3 * chunk + ((unsigned __int128)1 << 30);
+  const unsigned __int128 room = (unsigned __int128)free_b * 9 / 10, slack = 3 * chunk + std::min<unsigned __int128>(data, (unsigned __int128)1 << 30);
   if ((unsigned __int128)trees_node_bytes(1, c.cell_size, c.block_size, c.n_cells) * n_local + slack <= room) return 1;
   if ((unsigned __int128)compact_bytes(c, 1) * n_local + slack <= room) return 2;
   return 0;
@@ -212,19 +223,41 @@ static int dataset_build_transient(cp2_dataset* ds, int mode, bool allocated = f
   return CP2_OK;
 }
 
+// One mode down after an allocation failure of an automatically chosen mode: everything of the failed attempt is gone by now (the
+// dataset object, its trees), the context's cached scratch goes too, and the trace / the error text say what happened.
+static bool step_down(cp2_ctx* ctx, int* mode, const char* what) {
+  if (*mode == 0) return false;
+  const int next = *mode == 1 ? 2 : 0;
+  (void)cp2_trim(ctx);
+  const std::string why = ctx->err;
+  if (std::getenv("CP2_TRACE"))
+    std::fprintf(stderr, "[cp2 trace] %s: keeping %s did not fit after all (%s): retrying with %s\n", what, *mode == 1 ? "every node" : "the compact layers",
+                 why.c_str(), next == 2 ? "the compact layers" : "the roots only");
+  ctx->err.clear();
+  *mode = next;
+  return true;
+}
+
 static int dataset_build(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local, bool always_keep_trees, cp2_dataset** out) {
   if (!ctx || !cfg || !out) return CP2_ERR_INVALID;
   *out = nullptr;
   CP2_TRY(dataset_check(cfg, first_slot, n_local));
-  std::unique_ptr<cp2_dataset> ds(dataset_new(ctx, cfg, first_slot, n_local));
-  if (!ds) return CP2_ERR_ALLOC;
   CP2_TRY(trees_check_geometry(cfg->cell_size, cfg->block_size, cfg->n_cells, n_local));
   CP2_HIP(ctx, hipSetDevice(ctx->device));
-  const int mode = always_keep_trees ? 1 : dataset_tree_mode(ctx, ds->cfg, n_local);
-  if (mode == 1) CP2_TRY(dataset_build_trees(ds.get(), 0, nullptr));
-  else CP2_TRY(dataset_build_transient(ds.get(), mode));
-  *out = ds.release();
-  return CP2_OK;
+  bool automatic = false;
+  int mode = always_keep_trees ? 1 : dataset_tree_mode(ctx, *cfg, n_local, &automatic);
+  if (mode < 0) return CP2_ERR_INVALID;
+  for (;;) {
+    std::unique_ptr<cp2_dataset> ds(dataset_new(ctx, cfg, first_slot, n_local));
+    if (!ds) return CP2_ERR_ALLOC;
+    const int st = mode == 1 ? dataset_build_trees(ds.get(), 0, nullptr) : dataset_build_transient(ds.get(), mode);
+    if (st == CP2_OK) {
+      *out = ds.release();
+      return CP2_OK;
+    }
+    ds.reset();                                   // (frees what the failed attempt holds before anything else is tried)
+    if (st != CP2_ERR_ALLOC || !automatic || !step_down(ctx, &mode, "dataset build")) return st;
+  }
 }
 
 extern "C" int cp2_dataset_build(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local,
@@ -236,8 +269,61 @@ extern "C" int cp2_dataset_build(cp2_ctx* ctx, const cp2_config* cfg, uint64_t f
   return CP2_ERR_INVALID;
 }
 
-// Same as cp2_dataset_build, but the slot trees are read from `cache_path` when that file exists, is intact and
-// matches the configuration AND (SlotFile source) the slot files' sizes and mtimes; written there after a build otherwise.
+// Same as cp2_dataset_build, but what the dataset keeps of its slot trees is read from the cache when a file there is intact and
+// matches the configuration AND (SlotFile source) the slot files' sizes and mtimes; built and written otherwise.
+//
+// Three representations can be cached -- every node ("CP2TREE3"), the compact layers or the roots ("CP2KEPT1", the mode in the
+// header) -- and which one a run WANTS depends on what the device has free at that moment (dataset_tree_mode), which another
+// tenant of the device can change from one run to the next.  So that such a change never costs a rebuild (hours at config 5's
+// nominal size) or evicts a good cache:
+//   * loading accepts ANY cached representation that is valid, describes this data and fits: the one wanted first, then the
+//     smaller ones (a run that wanted every node but finds the compact layers keeps the dataset compact; CP2_TRACE says so);
+//   * saving never overwrites a tree cache ("CP2TREE3") with the smaller kept form: that goes to "<cache_path>.kept" beside it,
+//     and loading looks there too.
+// To pin the representation, pin the mode: cp2_set_keep_trees / CODEX_P2_KEEP_TREES.
+namespace {
+
+bool file_has_magic(const char* path, const char* magic8) {
+  char m[8] = {};
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) return false;
+  const bool ok = pread(fd, m, 8, 0) == 8 && std::memcmp(m, magic8, 8) == 0;
+  close(fd);
+  return ok;
+}
+
+// the kept form of `mode` (2 compact, 0 roots) from `path`: CP2_OK with *out set, CP2_ERR_IO when the file is not that, other errors as they come
+int load_kept_dataset(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local, int mode, const char* path, cp2_dataset** out) {
+  if (!file_has_magic(path, "CP2KEPT1")) return CP2_ERR_IO;
+  std::unique_ptr<cp2_dataset> ds(dataset_new(ctx, cfg, first_slot, n_local));
+  if (!ds) return CP2_ERR_ALLOC;
+  CP2_TRY(dataset_alloc_kept(ds.get(), mode));
+  KeptMeta meta;
+  meta.n_slots = n_local; meta.cell_size = cfg->cell_size; meta.block_size = cfg->block_size; meta.n_cells = cfg->n_cells;
+  meta.src = (uint64_t)(ds->from_file ? CellSrc::File : CellSrc::Fake); meta.dataset_seed = cfg->seed; meta.first_slot = first_slot;
+  meta.mode = (uint64_t)mode; meta.file_base = ds->file_base;
+  void* buf = mode == 2 ? ds->compact.p : ds->local_roots.p;
+  const size_t bytes = mode == 2 ? compact_bytes(*cfg, n_local) : (size_t)n_local * 32;
+  CP2_TRY(kept_load(ctx, path, meta, buf, bytes));
+  *out = ds.release();
+  return CP2_OK;
+}
+
+int save_kept_dataset(cp2_dataset* ds, const char* cache_path) {
+  const cp2_config& c = ds->cfg;
+  KeptMeta meta;
+  meta.n_slots = ds->n_local; meta.cell_size = c.cell_size; meta.block_size = c.block_size; meta.n_cells = c.n_cells;
+  meta.src = (uint64_t)(ds->from_file ? CellSrc::File : CellSrc::Fake); meta.dataset_seed = c.seed; meta.first_slot = ds->first_slot;
+  meta.mode = (uint64_t)ds->tree_mode; meta.file_base = ds->file_base;
+  const void* buf = ds->tree_mode == 2 ? ds->compact.p : ds->local_roots.p;
+  const size_t bytes = ds->tree_mode == 2 ? compact_bytes(c, ds->n_local) : (size_t)ds->n_local * 32;
+  // a tree cache at the path is the richer representation: it stays, the kept form goes beside it
+  const std::string path = file_has_magic(cache_path, "CP2TREE3") ? std::string(cache_path) + ".kept" : std::string(cache_path);
+  return kept_save(ds->ctx, path.c_str(), meta, buf, bytes);
+}
+
+}  // namespace
+
 extern "C" int cp2_dataset_build_cached(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local,
                                         const char* cache_path, cp2_dataset** out) try {
   if (!ctx || !cfg || !out || !cache_path) return CP2_ERR_INVALID;
@@ -245,50 +331,55 @@ extern "C" int cp2_dataset_build_cached(cp2_ctx* ctx, const cp2_config* cfg, uin
   CP2_TRY(dataset_check(cfg, first_slot, n_local));
   CP2_TRY(trees_check_geometry(cfg->cell_size, cfg->block_size, cfg->n_cells, n_local));
   CP2_HIP(ctx, hipSetDevice(ctx->device));
-  const int mode = dataset_tree_mode(ctx, *cfg, n_local);
-  if (mode != 1) {
-    // A dataset that keeps its trees compact (or only their roots) caches exactly that: 8 MiB per 8 GiB slot -- a later run loads
-    // it and proves with the touched blocks alone, no slot is hashed again.
-    std::unique_ptr<cp2_dataset> ds(dataset_new(ctx, cfg, first_slot, n_local));
-    if (!ds) return CP2_ERR_ALLOC;
-    CP2_TRY(dataset_alloc_kept(ds.get(), mode));
-    KeptMeta meta;
-    meta.n_slots = n_local; meta.cell_size = cfg->cell_size; meta.block_size = cfg->block_size; meta.n_cells = cfg->n_cells;
-    meta.src = (uint64_t)(ds->from_file ? CellSrc::File : CellSrc::Fake); meta.dataset_seed = cfg->seed; meta.first_slot = first_slot;
-    meta.mode = (uint64_t)mode; meta.file_base = ds->file_base;
-    void* buf = mode == 2 ? ds->compact.p : ds->local_roots.p;
-    const size_t bytes = mode == 2 ? compact_bytes(*cfg, n_local) : (size_t)n_local * 32;
-    StageTimer trace;
-    if (kept_load(ctx, cache_path, meta, buf, bytes) == CP2_OK) {
-      trace.lap(mode == 2 ? "compact layers loaded from the cache" : "slot roots loaded from the cache");
-    } else {
-      CP2_TRY(dataset_build_transient(ds.get(), mode, true));
-      CP2_TRY(kept_save(ctx, cache_path, meta, buf, bytes));
-      trace.lap("built and written to the cache");
+  bool automatic = false;
+  int mode = dataset_tree_mode(ctx, *cfg, n_local, &automatic);
+  if (mode < 0) return CP2_ERR_INVALID;
+  const std::string beside = std::string(cache_path) + ".kept";
+  StageTimer trace;
+  // ---- load: the representation wanted, else (automatic choice only) any smaller one that is there
+  if (mode == 1) {
+    cp2_slot_trees* t = nullptr;
+    const int lst = cp2_slot_trees_load(ctx, cache_path, &t);
+    if (lst == CP2_OK) {
+      const bool from_file = cfg->file_base != nullptr;
+      bool match = t->n_slots == n_local && t->cell_size == cfg->cell_size && t->block_size == cfg->block_size &&
+                   t->n_cells == cfg->n_cells && t->first_slot == first_slot && t->units_per_slot == 1 &&
+                   (from_file ? (t->src == CellSrc::File && t->file_base == cfg->file_base)
+                              : (t->src == CellSrc::Fake && t->dataset_seed == cfg->seed));
+      if (match) {
+        cp2_dataset* ds = dataset_new(ctx, cfg, first_slot, n_local);
+        if (!ds) { cp2_slot_trees_free(t); return CP2_ERR_ALLOC; }
+        ds->trees = t;
+        *out = ds;
+        return CP2_OK;
+      }
+      cp2_slot_trees_free(t);
+    } else if (lst == CP2_ERR_ALLOC && automatic) {
+      (void)step_down(ctx, &mode, "cached build (loading the tree cache)");   // the nodes do not fit after all: what is smaller may
     }
-    *out = ds.release();
-    return CP2_OK;
   }
-  cp2_slot_trees* t = nullptr;
-  if (cp2_slot_trees_load(ctx, cache_path, &t) == CP2_OK) {
-    const bool from_file = cfg->file_base != nullptr;
-    bool match = t->n_slots == n_local && t->cell_size == cfg->cell_size && t->block_size == cfg->block_size &&
-                 t->n_cells == cfg->n_cells && t->first_slot == first_slot &&
-                 (from_file ? (t->src == CellSrc::File && t->file_base == cfg->file_base)
-                            : (t->src == CellSrc::Fake && t->dataset_seed == cfg->seed));
-    if (match) {
-      cp2_dataset* ds = dataset_new(ctx, cfg, first_slot, n_local);
-      if (!ds) { cp2_slot_trees_free(t); return CP2_ERR_ALLOC; }
-      ds->trees = t;
-      *out = ds;
-      return CP2_OK;
+  for (int m2 : {2, 0}) {
+    if (m2 > mode || (m2 != mode && !automatic)) continue;       // never a representation larger than what fits; a named mode is taken literally
+    for (const char* path : {cache_path, beside.c_str()}) {
+      cp2_dataset* ds = nullptr;
+      const int lst = load_kept_dataset(ctx, cfg, first_slot, n_local, m2, path, &ds);
+      if (lst == CP2_OK) {
+        if (trace.on && m2 != mode) std::fprintf(stderr, "[cp2 trace] the cache holds %s (this run would have kept %s): taken as it is\n",
+                                                 m2 == 2 ? "the compact layers" : "the slot roots", mode == 1 ? "every node" : "the compact layers");
+        trace.lap(m2 == 2 ? "compact layers loaded from the cache" : "slot roots loaded from the cache");
+        *out = ds;
+        return CP2_OK;
+      }
+      if (lst != CP2_ERR_IO && lst != CP2_ERR_ALLOC) return lst;
     }
-    cp2_slot_trees_free(t);
   }
-  CP2_TRY(dataset_build(ctx, cfg, first_slot, n_local, true, out));   // what is cached IS the trees
-  int st = cp2_slot_trees_save((*out)->trees, cache_path);
-  if (st != CP2_OK) { cp2_dataset_free(*out); *out = nullptr; }
-  return st;
+  // ---- build (stepping down when an automatic choice does not fit after all) and write what the dataset keeps
+  CP2_TRY(dataset_build(ctx, cfg, first_slot, n_local, mode == 1 && !automatic, out));
+  cp2_dataset* ds = *out;
+  int st = ds->trees ? cp2_slot_trees_save(ds->trees, cache_path) : save_kept_dataset(ds, cache_path);
+  if (st != CP2_OK) { cp2_dataset_free(ds); *out = nullptr; return st; }
+  trace.lap("built and written to the cache");
+  return CP2_OK;
 } catch (const std::bad_alloc&) {
   return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
 } catch (...) {
@@ -361,6 +452,15 @@ extern "C" int cp2_dataset_set_roots_dev(cp2_dataset* ds, const void* d_all_root
   return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
 } catch (...) {
   return CP2_ERR_INVALID;
+}
+
+int cp2i::dataset_own_roots_in_place(cp2_dataset* ds, bool* ok) {
+  *ok = false;
+  if (!ds->have_roots) return CP2_ERR_INVALID;
+  std::vector<uint8_t> own(ds->n_local * 32);
+  CP2_TRY(cp2_dataset_local_roots(ds, own.data()));
+  *ok = std::memcmp(own.data(), &ds->dlayers[ds->first_slot * 32], own.size()) == 0;   // layer 0 of the dataset tree = all slot roots
+  return CP2_OK;
 }
 
 extern "C" const void* cp2_dataset_local_roots_dev(const cp2_dataset* ds) { return ds ? dataset_roots_dev(ds) : nullptr; }
@@ -760,6 +860,17 @@ extern "C" int cp2_proof_inputs_generate_batch(cp2_dataset* ds, const uint64_t* 
     CP2_HIP(ctx, hipSetDevice(ctx->device));
     CP2_TRY(dataset_transient_trees(ds, (size_t)(slot_idx[0] - ds->first_slot), 1, &transient.t));
     t = transient.t;
+    // slotRoot, slotProof and dataSetRoot come from the STORED roots; indices, paths and cells from the tree just rebuilt: the two must
+    // be the same slot.  A slot file that changed since the build (or since the cache was written) is an I/O error, like the compact
+    // mode's block check, never an input.json over mixed data.
+    uint8_t rebuilt[32], stored[32];
+    CP2_TRY(cp2_slot_trees_roots(t, rebuilt));
+    CP2_HIP(ctx, hipMemcpyAsync(stored, static_cast<const uint8_t*>(dataset_roots_dev(ds)) + (slot_idx[0] - ds->first_slot) * 32, 32, hipMemcpyDeviceToHost, ctx->stream));
+    CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (std::memcmp(rebuilt, stored, 32) != 0) {
+      ctx->err = "slot " + std::to_string(slot_idx[0]) + " does not hash to its stored root (slot data changed since the build?)";
+      return CP2_ERR_IO;
+    }
   }
   const uint64_t local_base = ds->trees ? ds->first_slot : slot_idx[0];  // index inside `t` = slot index - local_base
   if (!ds->have_roots) CP2_TRY(cp2_dataset_set_roots(ds, nullptr));
@@ -1077,8 +1188,9 @@ struct StreamRing {
 
 }  // namespace
 
-extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local,
-                                          const uint8_t entropy_in[32], int threads, size_t group_slots, cp2_dataset** out) try {
+// the streamed build keeping its trees as `tree_mode` says (1 every node, 2 compact, 0 roots only)
+static int build_streamed_in_mode(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local,
+                                  const uint8_t entropy_in[32], int threads, size_t group_slots, int tree_mode, cp2_dataset** out) {
   if (!ctx || !cfg || !out || !entropy_in) return CP2_ERR_INVALID;
   uint8_t entropy[32];
   canonical_felt(entropy_in, entropy);
@@ -1199,7 +1311,6 @@ extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, u
     };
 
     int st = CP2_OK;
-    const int tree_mode = dataset_tree_mode(ctx, cfgv, n_local);
     if (tree_mode == 1) {
       st = dataset_build_trees(dsp, group_slots, on_done);
       trace.lap("trees (sampling overlapped)");
@@ -1246,6 +1357,21 @@ extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, u
   ds->prepared = true;
   *out = ds.release();
   return CP2_OK;
+}
+
+extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local,
+                                          const uint8_t entropy_in[32], int threads, size_t group_slots, cp2_dataset** out) try {
+  if (!ctx || !cfg || !out || !entropy_in) return CP2_ERR_INVALID;
+  *out = nullptr;
+  CP2_TRY(dataset_check(cfg, first_slot, n_local));
+  CP2_HIP(ctx, hipSetDevice(ctx->device));
+  bool automatic = false;
+  int mode = dataset_tree_mode(ctx, *cfg, n_local, &automatic);
+  if (mode < 0) return CP2_ERR_INVALID;
+  for (;;) {   // the same step-down chain as cp2_dataset_build: an automatic choice that does not fit after all is retried one mode down
+    const int st = build_streamed_in_mode(ctx, cfg, first_slot, n_local, entropy_in, threads, group_slots, mode, out);
+    if (st != CP2_ERR_ALLOC || !automatic || !step_down(ctx, &mode, "streamed build")) return st;
+  }
 } catch (const std::bad_alloc&) {
   return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
 } catch (...) {

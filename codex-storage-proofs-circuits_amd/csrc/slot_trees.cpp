@@ -73,7 +73,15 @@ int trees_check_geometry(size_t cell_size, size_t block_size, size_t n_cells, si
 
 }  // namespace cp2i
 
-static int trees_layout(cp2_slot_trees* t) {
+cp2i::BuildScratch::~BuildScratch() {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
+  if (ctx->aux2_stream) (void)hipStreamSynchronize(ctx->aux2_stream);
+}
+
+static int trees_layout(cp2_slot_trees* t, cp2i::DevBuf* borrow_from = nullptr) {
   t->bsizes = layer_sizes_of(t->cpb);
   t->tsizes = layer_sizes_of(t->nblocks);
   if (t->bsizes.size() > (size_t)cp2k::TreeGeom::MAX_LAYERS || t->tsizes.size() > (size_t)cp2k::TreeGeom::MAX_LAYERS) return CP2_ERR_INVALID;
@@ -89,6 +97,11 @@ static int trees_layout(cp2_slot_trees* t) {
   for (size_t k = 0; k < t->tsizes.size(); ++k) {
     t->toff.push_back(off);
     off += t->n_slots * t->tsizes[k];
+  }
+  if (borrow_from) {            // a pipeline's node buffer: (re)allocated only when too small (the first batch is the largest)
+    if (borrow_from->bytes < off * 32) CP2_TRY(borrow_from->scratch(t->ctx, off * 32));
+    t->nodes.borrow(borrow_from->p, off * 32);
+    return CP2_OK;
   }
   return t->pooled_nodes ? t->nodes.scratch(t->ctx, off * 32) : t->nodes.alloc(t->ctx, off * 32);
 }
@@ -158,10 +171,11 @@ struct LayerScheduler {
   bool take_all = false;                     // groups of varying size (the fake builder's ramp-down): every complete slot goes at once
   hipStream_t hs[2] = {nullptr, nullptr};
   hipEvent_t ev[2] = {nullptr, nullptr};     // the latest hashing enqueued on each stream
+  bool detached = false;                     // pipelined batches (BuildScratch): nothing is waited for here, the pipeline's owner does
   ~LayerScheduler() {
     for (int i = 0; i < 2; ++i) {
-      if (hs[i]) (void)hipStreamSynchronize(hs[i]);
-      if (ev[i]) (void)hipEventDestroy(ev[i]);
+      if (hs[i] && !detached) (void)hipStreamSynchronize(hs[i]);
+      if (ev[i]) (void)hipEventDestroy(ev[i]);   // (an event that is still pending is released once it has completed)
     }
   }
   int init() {
@@ -200,6 +214,7 @@ struct LayerScheduler {
   }
   int finish() {   // everything of both streams done
     cp2_ctx* ctx = t->ctx;
+    if (detached) return CP2_OK;
     CP2_HIP(ctx, hipStreamSynchronize(hs[0]));
     CP2_HIP(ctx, hipStreamSynchronize(hs[1]));
     return CP2_OK;
@@ -209,7 +224,7 @@ struct LayerScheduler {
 
 int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_slot, size_t n_slots, size_t cell_size,
                            size_t block_size, size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out,
-                           uint64_t units_per_slot, bool pooled_nodes) {
+                           uint64_t units_per_slot, bool pooled_nodes, BuildScratch* scratch, int node_slot) {
   *out = nullptr;
   if (units_per_slot == 0) return CP2_ERR_INVALID;
   CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
@@ -222,21 +237,24 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
   t->units_per_slot = units_per_slot;
   t->pooled_nodes = pooled_nodes;
   StageTimer trace;
-  CP2_TRY(trees_layout(t.get()));
+  if (scratch) scratch->ctx = ctx;
+  CP2_TRY(trees_layout(t.get(), scratch ? &scratch->nodes[node_slot & 1] : nullptr));
   const size_t total_cells = n_slots * n_cells;
   // staging chunk: up to 2 GiB of generated cells, a whole number of slots when slots are smaller than that
   size_t chunk = std::max<size_t>(1, std::min(total_cells, ctx->stage_bytes / cell_size));
   if (chunk > n_cells) chunk -= chunk % n_cells;
   if (group && chunk > group * n_cells) chunk = group * n_cells;
   const bool two = total_cells > chunk && group == 0;          // a second staging buffer only when chunks alternate between the streams
-  DevBuf stage[2];
-  CP2_TRY(stage[0].scratch(ctx, chunk * cell_size));
-  if (two) CP2_TRY(stage[1].scratch(ctx, chunk * cell_size));
+  DevBuf own_stage[2];
+  DevBuf* stage = scratch ? scratch->stage : own_stage;        // a pipeline's staging outlives this call (its last chunks may still be hashing)
+  if (stage[0].bytes < chunk * cell_size) CP2_TRY(stage[0].scratch(ctx, chunk * cell_size));
+  if (two && stage[1].bytes < chunk * cell_size) CP2_TRY(stage[1].scratch(ctx, chunk * cell_size));
   trace.lap("fake slots: node + staging buffers");
   // whole slots: the seed of the batch's first slot, the generator counts slots from there; units: the seed of slot 0 of the
   // dataset, the generator places unit first_slot + i inside slot (first_slot + i) / units_per_slot
   const uint64_t seed0 = cp2_slot_seed(dataset_seed, units_per_slot > 1 ? 0 : first_slot);
   LayerScheduler sched{t.get(), group, done};
+  sched.detached = scratch != nullptr;
   // Groups (the streamed proof-input path): what follows a group on the host -- the JSON bodies of its slots -- overlaps the
   // hashing of the NEXT group, so the last group's formatting overlaps nothing.  When a chunk is a whole number of slots the
   // last groups are therefore halved down to one residency of the hash kernel (768 x 256 cells): 256, 256, ..., 128, 64, 48
@@ -995,6 +1013,7 @@ extern "C" int cp2_slot_trees_attach_cells(cp2_slot_trees* t, const uint8_t* hos
 
 extern "C" void cp2_slot_trees_free(cp2_slot_trees* t) {
   if (!t) return;
+  if (t->nodes.borrowed) { delete t; return; }   // a pipelined batch: its nodes belong to the pipeline's scratch, whose owner does the waiting
   (void)hipSetDevice(t->ctx->device);
   (void)hipStreamSynchronize(t->ctx->stream);
   if (t->ctx->aux_stream) (void)hipStreamSynchronize(t->ctx->aux_stream);

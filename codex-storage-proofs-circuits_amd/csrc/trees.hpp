@@ -37,13 +37,26 @@ constexpr uint64_t NO_ROW = ~0ULL;
 // of those slots on that stream while later slots are still hashing on the context's stream.
 using SlotsDone = std::function<int(cp2_slot_trees* t, size_t s0, size_t s1, hipStream_t st)>;
 
+// Scratch that outlives one builder call, so that consecutive batches of a transient (compact / roots-only) build PIPELINE instead of
+// draining the device between them: two staging buffers for generated cells and two node buffers used alternately.  With it
+// trees_build_fake returns with its work ENQUEUED (nothing synchronised, the batch's nodes a borrowed view of nodes[node_slot]):
+// the next batch's generation and hashing start on the context's second stream while this batch's layer passes and copy-outs
+// still run on the first.  The owner waits for whatever reads nodes[b] before it hands slot b to another batch, and drains the
+// context's streams before the scratch goes (its destructor does).
+struct BuildScratch {
+  cp2_ctx* ctx = nullptr;
+  DevBuf stage[2], nodes[2];
+  ~BuildScratch();
+};
+
 int trees_check_geometry(size_t cell_size, size_t block_size, size_t n_cells, size_t n_slots);
 // fake-data or slot-file trees; `group` = how many finished slots to batch per layer pass / callback (0: all at the end)
 // units_per_slot > 1: first_slot / n_slots / n_cells count UNITS and the cells of one unit (cp2_slot_trees above)
 // pooled_nodes: the node buffer comes from (and goes back to) the context's scratch pool instead of hipMalloc / hipFree
+// scratch != nullptr: pipelined (BuildScratch above); the returned batch borrows scratch->nodes[node_slot]
 int trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_slot, size_t n_slots, size_t cell_size, size_t block_size,
                      size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out, uint64_t units_per_slot = 1,
-                     bool pooled_nodes = false);
+                     bool pooled_nodes = false, BuildScratch* scratch = nullptr, int node_slot = 0);
 int trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t first_slot, size_t n_slots, size_t cell_size,
                       size_t block_size, size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out,
                       uint64_t units_per_slot = 1, bool pooled_nodes = false);
@@ -66,6 +79,10 @@ struct KeptMeta {
 };
 int kept_save(cp2_ctx* ctx, const char* path, const KeptMeta& meta, const void* d_buf, size_t bytes);
 int kept_load(cp2_ctx* ctx, const char* path, const KeptMeta& want, void* d_buf, size_t bytes);
+
+// After cp2_dataset_set_roots*: do rows [first_slot, first_slot + n_local) of the dataset tree's bottom layer hold THIS dataset's own
+// slot roots?  One small download.  The multi-device exchange is verified with it (multi_gpu.cpp).
+int dataset_own_roots_in_place(cp2_dataset* ds, bool* ok);
 
 // stage timings on stderr when CP2_TRACE is set (the reference's only tracing is shell `time`, workflow/prove.sh:30-37)
 struct StageTimer {

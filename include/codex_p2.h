@@ -55,6 +55,20 @@ const char* cp2_strerror(int status);
 const char* cp2_last_error(const cp2_ctx* ctx);
 /* 1 when the library's kernels were built for the device of `ctx` (gfx950). */
 int cp2_device_is_native(const cp2_ctx* ctx);
+/* The environment variables the library reads are parsed STRICTLY: each holds exactly what it takes, or cp2_init / cp2_multi_init
+ * fail with CP2_ERR_INVALID -- a mistyped knob is never read as "automatic".  cp2_check_environment (host only: no device is
+ * touched, so it also answers on a box without a GPU) returns CP2_OK, or CP2_ERR_INVALID with the first offending variable, its
+ * value and what it takes in `msg` (may be NULL).  The variables:
+ *   CODEX_P2_GPUS        "all" | a device count | a comma-separated list of device indices      (cp2_multi_init)
+ *   CODEX_P2_GATHER      "auto" | "rccl" | "copy" | "host"                                       (cp2_multi_set_policy)
+ *   CODEX_P2_MIN_CELLS   a decimal number                                                        (cp2_multi_set_policy)
+ *   CODEX_P2_SPLIT       0, 1 or a power of two                                                  (cp2_multi_set_split)
+ *   CODEX_P2_KEEP_TREES  "auto" | "1" | "2" | "0"                                                (cp2_set_keep_trees)
+ *   CODEX_P2_EXCHANGE_TIMEOUT_S  seconds the exchange of slot roots may take (default 120; 0 = no limit)
+ *   CODEX_P2_MEM_LIMIT_MB        (tests) a cap, in MiB per device, on the device memory this process may hold through the library:
+ *                        the automatic residency choice sees min(free, cap left) and an allocation beyond the cap fails like a real
+ *                        out-of-memory, so all residency modes and the fallback between them can be reached on an empty 288 GB device */
+int cp2_check_environment(char* msg, size_t msg_len);
 /* Tuning of the host -> GPU ingestion pipe used by cp2_slot_trees_build_host, cp2_hash_cells (large inputs) and the
  * SlotFile data source (the reference reads one cell per call, reference/nim/proof_input/src/slot.nim:57-68):
  * host threads filling the pinned ring, ring depth (2..8) and bytes per chunk.  0 = keep the default
@@ -89,8 +103,13 @@ int cp2_set_body_budget(cp2_ctx* ctx, size_t max_resident_bytes, const char* spi
  *   0  ROOTS ONLY: the 32-byte slot roots stay; cp2_proof_input_generate rebuilds the whole tree of the slot it proves (0.2 s per
  *      8 GiB slot; the reference rebuilds it once per SAMPLE, gen_input/bn254.nim:57).
  * For 2 and 0 the trees are built batch by batch (about 2 GiB of nodes) in the context's scratch, what is kept is copied out, the
- * rest dropped.  mode -1 (default): the environment variable CODEX_P2_KEEP_TREES ("0" / "1" / "2"), else the most that fits what
- * the device has free (1, else 2, else 0).  cp2_dataset_keeps_trees tells what a built dataset did.  The streamed build follows
+ * rest dropped (the copy-out of one batch overlaps the hashing of the next).  mode -1 (default): the environment variable
+ * CODEX_P2_KEEP_TREES ("0" / "1" / "2"; "auto" = unset), else the most that fits what the device has free (1, else 2, else 0) --
+ * divided by the number of contexts a cp2_multi has placed on that device.  The figure is a snapshot: another tenant of the
+ * device (a second process, a framework's caching allocator) can take the memory between the choice and the allocation.  When
+ * the mode was chosen AUTOMATICALLY and the build then fails with CP2_ERR_ALLOC, everything is freed, the context's cached
+ * scratch is handed back (cp2_trim) and the build is retried one mode down (1 -> 2 -> 0); CP2_TRACE says so, and
+ * cp2_dataset_keeps_trees tells what a built dataset did.  A mode the caller named is never changed.  The streamed build follows
  * the same rule (the bodies of a batch of slots are made while its trees exist: every proof input of 4096 slots of 8 GiB in one
  * pass over the data).  cp2_dataset_build_cached caches what the dataset keeps: every node, or -- 1/32 of that -- the compact
  * layers, or the roots; a later run loads them and, compact, proves from the touched blocks alone.  On a roots-only dataset every
@@ -326,6 +345,13 @@ int cp2_write_circom_main(const cp2_config* cfg, const char* path);
  *   - librccl is opened at run time, and only when at least two distinct devices hold a shard.  Without it, or when a device
  *     index repeats (two contexts on one device), the roots are gathered through host memory instead (1 MiB at 32 768 slots);
  *     cp2_multi_gather_mode names what the last build did ("rccl (...)", "host (<why>)", "copy (...)", "none (one shard ...)").
+ *   - The exchange is VERIFIED, whatever carried it: every device must find its own slot roots at its own rows of the list it
+ *     received, and all devices must compute the same dataset root (one 32-byte-per-slot download per shard) -- a wrong
+ *     rank-to-device mapping or a misplaced block is CP2_ERR_HIP ("exchange verification failed ..."), never a wrong
+ *     dataSetRoot.  It is also BOUNDED: communicator creation and the collective itself are given CODEX_P2_EXCHANGE_TIMEOUT_S
+ *     seconds (default 120); one that does not return is an error that says so (its buffers are abandoned, RCCL is not used again
+ *     in this process).  In the automatic mode a device path that fails either way is retried once through host memory, and
+ *     cp2_multi_gather_mode says that it was; a way asked for by name is never replaced.
  *   - Small datasets use fewer devices: a device gets a shard only when there is at least `min_cells_per_device` cells of
  *     hashing for it (default: one residency of the hash kernel, 768 x 256 cells -- a device with less finishes no sooner),
  *     so the reference's default run (11 slots x 512 cells, workflow/params.sh) stays on one GPU and pays one context.
@@ -342,9 +368,11 @@ typedef struct cp2_multi cp2_multi;
 typedef struct cp2_multi_dataset cp2_multi_dataset;
 enum { CP2_GATHER_AUTO = 0, CP2_GATHER_RCCL = 1, CP2_GATHER_HOST = 2, CP2_GATHER_COPY = 3 };
 /* devices: n_dev HIP device indices (an index may repeat: several contexts on one device).  n_dev = 0: the environment
- * variable CODEX_P2_GPUS ("<count>" = the first <count> visible devices, or a comma-separated index list), else every
- * visible gfx950 device.  CODEX_P2_GPUS, CODEX_P2_MIN_CELLS and CODEX_P2_SPLIT are read here; a value that is not what
- * the variable takes (a count / an index list; a decimal number; 0, 1 or a power of two) is CP2_ERR_INVALID, not guessed at. */
+ * variable CODEX_P2_GPUS ("all" = every visible gfx950 device, "<count>" = the first <count> visible devices, or a
+ * comma-separated index list), else ONE device: the first visible gfx950.  Several devices are OPT-IN -- by the variable or by
+ * an explicit list -- until the exchange between two real devices has a committed record (this pipeline's GPU boxes hold one
+ * device).  Every CODEX_P2_* variable is checked here (cp2_check_environment): a value that is not what
+ * its variable takes is CP2_ERR_INVALID, not guessed at. */
 int cp2_multi_init(const int* devices, int n_dev, cp2_multi** out);
 /* frees the handle, its contexts and communicators: free every cp2_multi_dataset (and proof input) made through it first */
 void cp2_multi_free(cp2_multi* m);
