@@ -97,6 +97,17 @@ void dev_free(void* p, size_t) {
   (void)hipFree(p);
 }
 
+int device_free_bytes(size_t* out) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return CP2_ERR_HIP; }
+  if (const size_t limit = mem_limit_bytes()) {
+    const size_t held = dev_bytes_held();
+    free_b = std::min(free_b, limit > held ? limit - held : 0);
+  }
+  *out = free_b;
+  return CP2_OK;
+}
+
 size_t dev_bytes_held() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
@@ -143,6 +154,7 @@ extern "C" int cp2_check_environment(char* msg, size_t msg_len) try {
   if (!env_decimal("CODEX_P2_SPLIT", &v, &set) || (set && v > 1 && (v & (v - 1)))) return fail("CODEX_P2_SPLIT", "0 (choose), 1 (whole slots) or a power of two (units per slot)");
   if (!env_decimal("CODEX_P2_MEM_LIMIT_MB", &v, &set)) return fail("CODEX_P2_MEM_LIMIT_MB", "a decimal number of MiB (0 = no cap)");
   if (!env_decimal("CODEX_P2_EXCHANGE_TIMEOUT_S", &v, &set)) return fail("CODEX_P2_EXCHANGE_TIMEOUT_S", "a decimal number of seconds (0 = wait for ever)");
+  if (!env_decimal("CODEX_P2_STAGE_MB", &v, &set) || (set && (v < 1 || v > 65536))) return fail("CODEX_P2_STAGE_MB", "a decimal number of MiB between 1 and 65536");
   if (const char* e = std::getenv("CODEX_P2_GATHER"))
     if (*e && std::strcmp(e, "auto") && std::strcmp(e, "rccl") && std::strcmp(e, "host") && std::strcmp(e, "copy"))
       return fail("CODEX_P2_GATHER", "\"auto\", \"rccl\", \"copy\" or \"host\"");
@@ -180,6 +192,11 @@ extern "C" int cp2_init(int device, cp2_ctx** out) try {
     return CP2_ERR_HIP;
   }
   c->stream = c->own_stream;
+  {   // CODEX_P2_STAGE_MB: the device staging chunk of the fake-data builder (default 2048); a transient batch holds half of it in nodes
+    uint64_t mb = 0;
+    bool set = false;
+    if (env_decimal("CODEX_P2_STAGE_MB", &mb, &set) && set) c->stage_bytes = (size_t)mb << 20;
+  }
   trace.lap("context: stream");
   if (trace.on) {   // tracing only: the code object is otherwise loaded by the first launch, inside that launch's time
     (void)cp2k::load_code_object();

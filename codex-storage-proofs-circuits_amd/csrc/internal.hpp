@@ -32,6 +32,8 @@ size_t mem_limit_bytes();
 hipError_t dev_malloc(void** p, size_t n);
 void dev_free(void* p, size_t n);
 size_t dev_bytes_held();            // on the current device
+// what the CURRENT device has free for this process right now: hipMemGetInfo, and no more than the cap leaves
+int device_free_bytes(size_t* out);
 
 // Per-context cache of device and pinned-host scratch blocks.  The host-pointer entry points (one hipMalloc +
 // hipFree pair per call before) and the staging buffers of the builders draw from it, so a context that is
@@ -123,7 +125,7 @@ struct cp2_ctx {
   size_t ingest_chunk = 0;
   int ingest_direct = -1;                    // SlotFile reads with O_DIRECT: 1 on, 0 off, -1 = environment CP2_INGEST_DIRECT (cp2_set_ingest_direct)
   size_t body_budget = 0;                    // streamed proof-input bodies kept in host memory; 0: CP2_BODY_BUDGET_MB or 4 GiB (cp2_set_body_budget)
-  int mem_share = 1;                         // how many contexts of this process build on this context's DEVICE at the same time (cp2_multi sets it): the automatic residency choice takes 1 / mem_share of what the device has free
+  size_t mem_allowance = 0;                  // device bytes this context may plan with in its automatic residency choice; 0: ask the device.  cp2_multi sets it for the duration of a build: what the device had free BEFORE its shards started, divided by the number of contexts placed on that device
   int keep_trees = -1;                       // what cp2_dataset_build keeps of the slot trees in device memory: 1 every node, 2 block roots and up, 0 roots only, -1 = CODEX_P2_KEEP_TREES or the most that fits (cp2_set_keep_trees)
   std::string spill_dir;                     // where bodies beyond the budget go; empty: $TMPDIR or /tmp
   std::string err;

@@ -487,13 +487,14 @@ int exchange_roots(cp2_multi* m, const std::vector<RootsPart>& parts, uint64_t n
       ex.dev[i] = ex.all[i].p;
     }
     if (const char* fault = std::getenv("CODEX_P2_TEST_EXCHANGE_FAULT")) {
-      // test-only: flip one byte of the LAST context's gathered copy -- what a wrong rank-to-device mapping or a misplaced block
-      // would look like to the verification that follows the exchange (tests/test_gpu_multi.py)
-      if (std::strcmp(fault, "corrupt") == 0) {
-        cp2_ctx* ctx = parts[world - 1].ctx;
-        CP2_HIP(ctx, hipSetDevice(ctx->device));
-        CP2_HIP(ctx, hipMemsetAsync(const_cast<uint8_t*>(static_cast<const uint8_t*>(ex.dev[world - 1])) + 5, 0x5a, 1, ctx->stream));
-      }
+      // test-only: overwrite one byte of the first row in every context's gathered copy -- what a wrong rank-to-device mapping or a
+      // misplaced block would look like to the verification that follows the exchange (tests/test_gpu_round5.py)
+      if (std::strcmp(fault, "corrupt") == 0)
+        for (size_t i = 0; i < world; ++i) {
+          cp2_ctx* ctx = parts[i].ctx;
+          CP2_HIP(ctx, hipSetDevice(ctx->device));
+          CP2_HIP(ctx, hipMemsetAsync(const_cast<uint8_t*>(static_cast<const uint8_t*>(ex.dev[i])) + 5, 0x5a, 1, ctx->stream));
+        }
     }
     // the exchange is COMPLETE when this returns: a context's buffers are read by its peers (RCCL kernels, peer copies), so none
     // of them may go back to its pool on the strength of its own stream alone
@@ -557,8 +558,8 @@ int gather_roots_and_build_trees(cp2_multi_dataset* mds) {
         return ex.on_device ? cp2_dataset_set_roots_dev(mds->shards[i].ds, ex.dev[i]) : cp2_dataset_set_roots(mds->shards[i].ds, ex.host.data());
       }));
     }
-    if (world == 1) return CP2_OK;
-    // ---- verification
+    if (m->gather_note.rfind("none", 0) == 0) return CP2_OK;   // nothing moved
+    // ---- verification (also of a one-rank communicator asked for by name: the RCCL path's self-test)
     std::vector<char> in_place(world, 1);
     std::vector<std::array<uint8_t, 32>> roots(world);
     CP2_TRY(for_each_shard(world, [&](size_t i) -> int {
@@ -707,9 +708,8 @@ int multi_build(cp2_multi* m, const cp2_config* cfg, BuildKind kind, const uint8
     for (uint64_t r = 0; r < world && fits; ++r) {
       uint64_t first = 0, count = 0;
       cp2_shard_range(cfg->n_slots * S, (int)r, (int)world, &first, &count);
-      size_t free_b = 0, total_b = 0;
-      if (hipSetDevice(m->devices[r]) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); continue; }
-      if (const size_t limit = mem_limit_bytes()) { const size_t held = dev_bytes_held(); free_b = std::min(free_b, limit > held ? limit - held : 0); }
+      size_t free_b = 0;
+      if (hipSetDevice(m->devices[r]) != hipSuccess || device_free_bytes(&free_b) != CP2_OK) { (void)hipGetLastError(); continue; }
       const unsigned __int128 need = (unsigned __int128)trees_node_bytes(1, cfg->cell_size, cfg->block_size, cfg->n_cells / S) * count +
                                      3 * std::min<unsigned __int128>((unsigned __int128)count * (cfg->n_cells / S) * cfg->cell_size, (unsigned __int128)2 << 30) + ((unsigned __int128)1 << 30);
       fits = need <= (unsigned __int128)(free_b / (size_t)share_of(r, world)) * 9 / 10;
@@ -731,14 +731,25 @@ int multi_build(cp2_multi* m, const cp2_config* cfg, BuildKind kind, const uint8
   }
   const int per = std::max(1, threads / (int)world);
   std::vector<std::string> errs(world);
+  // what every device has free NOW, before any shard allocates, shared out among the contexts placed on it: each context's
+  // automatic residency choice plans with its share (0: the device did not answer, the context asks for itself)
+  std::vector<size_t> allowance(world, 0);
+  {
+    DeviceRestore restore;
+    for (uint64_t r = 0; r < world; ++r) {
+      size_t free_b = 0;
+      if (hipSetDevice(m->devices[r]) == hipSuccess && device_free_bytes(&free_b) == CP2_OK) allowance[r] = std::max<size_t>(1, free_b / (size_t)share_of(r, world));
+      else (void)hipGetLastError();
+    }
+  }
   StageTimer trace;
   int st = for_each_shard(world, [&](size_t i) -> int {
     auto& s = mds->shards[i];
     int cst = CP2_OK;
     cp2_ctx* ctx = m->ctx_of(s.dev, &cst);
     if (!ctx) { errs[i] = "device " + std::to_string(m->devices[s.dev]) + ": " + cp2_strerror(cst); return cst; }
-    ctx->mem_share = share_of(i, world);
-    struct ShareReset { cp2_ctx* c; ~ShareReset() { c->mem_share = 1; } } share_reset{ctx};
+    ctx->mem_allowance = allowance[i];
+    struct AllowanceReset { cp2_ctx* c; ~AllowanceReset() { c->mem_allowance = 0; } } allowance_reset{ctx};
     int r = CP2_OK;
     if (S > 1) {
       // cached: this shard's unit trees from "<cache>.units<S>.shard<i>of<world>" when that file is intact and describes exactly

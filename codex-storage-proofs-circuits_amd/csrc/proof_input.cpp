@@ -141,9 +141,18 @@ static size_t compact_bytes(const cp2_config& c, size_t n_slots) {
 
 // What of its trees does this dataset keep?  1 every node, 2 the compact part, 0 the roots.  The caller's word (cp2_set_keep_trees /
 // CODEX_P2_KEEP_TREES), else the most that fits: a buffer must leave room for the builders' staging (two 2 GiB chunks), the batch in
-// flight and some slack in what the device has free right now -- a SNAPSHOT (hipMemGetInfo), shared out among the contexts a
-// cp2_multi has placed on this device (ctx->mem_share) and capped by CODEX_P2_MEM_LIMIT_MB.  *automatic says whether the mode was
+// flight and some slack in what the device has free right now -- a SNAPSHOT (device_free_bytes: hipMemGetInfo, capped by
+// CODEX_P2_MEM_LIMIT_MB), or the allowance a cp2_multi handed this context (its share of what the device had free before the shards started).  *automatic says whether the mode was
 // chosen here (then dataset_build may step down when the allocation fails after all) or named by the caller (never changed).
+#define CP2_TRY_MODE(call) do { if ((call) != CP2_OK) return 1; } while (0)   /* the device does not answer: plan as if everything fits */
+
+// Slots per batch of a transient (compact / roots-only) build: half a staging chunk of nodes (1 GiB by default: 4 slots of 8 GiB), at
+// least one slot.  The pipelined build holds two such node buffers, together one staging chunk's worth.
+static size_t transient_batch_slots(const cp2_ctx* ctx, const cp2_config& c, uint64_t n_local) {
+  const size_t per_slot = std::max<size_t>(1, trees_node_bytes(1, c.cell_size, c.block_size, c.n_cells));
+  return std::max<size_t>(1, std::min<size_t>(n_local, (ctx->stage_bytes / 2) / per_slot));
+}
+
 static int dataset_tree_mode(cp2_ctx* ctx, const cp2_config& c, uint64_t n_local, bool* automatic = nullptr) {
   if (automatic) *automatic = false;
   int mode = ctx->keep_trees;
@@ -155,20 +164,18 @@ static int dataset_tree_mode(cp2_ctx* ctx, const cp2_config& c, uint64_t n_local
   if (automatic) *automatic = true;
   if (const char* t = std::getenv("CODEX_P2_TEST_OPTIMISTIC"))   // test-only: start at "every node" without looking, so that the step-down chain is what finds the mode that fits
     if (*t == '1') return 1;
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 1; }
-  if (const size_t limit = mem_limit_bytes()) {
-    const size_t held = dev_bytes_held();
-    free_b = std::min(free_b, limit > held ? limit - held : 0);
-  }
-  free_b /= (size_t)std::max(1, ctx->mem_share);
-  // slack: the builders' staging (two chunks of at most 2 GiB, never more than the data itself), the node batch in flight (about
-  // 2 GiB for the transient modes) and 1 GiB of headroom
-  const unsigned __int128 data = (unsigned __int128)n_local * c.n_cells * c.cell_size;
-  const unsigned __int128 chunk = std::min<unsigned __int128>(data, (unsigned __int128)2 << 30);
-  const unsigned __int128 room = (unsigned __int128)free_b * 9 / 10, slack = 3 * chunk + std::min<unsigned __int128>(data, (unsigned __int128)1 << 30);
-  if ((unsigned __int128)trees_node_bytes(1, c.cell_size, c.block_size, c.n_cells) * n_local + slack <= room) return 1;
-  if ((unsigned __int128)compact_bytes(c, 1) * n_local + slack <= room) return 2;
+  size_t free_b = ctx->mem_allowance;
+  if (!free_b) CP2_TRY_MODE(device_free_bytes(&free_b));
+  // What a build holds at its peak: what it keeps + the builders' staging (two chunks of at most `stage_bytes`, never more than the
+  // data itself) + for the transient modes the node buffers of two batches in flight + headroom (sampling scratch, the dataset tree)
+  typedef unsigned __int128 u128;
+  const u128 data = (u128)n_local * c.n_cells * c.cell_size;
+  const u128 staging = 2 * std::min<u128>(data, ctx->stage_bytes), headroom = std::min<u128>(data, (u128)1 << 30);
+  const u128 nodes_all = (u128)trees_node_bytes(1, c.cell_size, c.block_size, c.n_cells) * n_local;
+  const u128 in_flight = 2 * (u128)trees_node_bytes(transient_batch_slots(ctx, c, n_local), c.cell_size, c.block_size, c.n_cells);
+  const u128 room = (u128)free_b * 9 / 10;
+  if (nodes_all + staging + headroom <= room) return 1;
+  if ((u128)compact_bytes(c, 1) * n_local + in_flight + staging + headroom <= room) return 2;
   return 0;
 }
 
@@ -185,40 +192,80 @@ static int dataset_alloc_kept(cp2_dataset* ds, int mode) {
 }
 
 // ... and what stays of a finished batch `t` (local slots [base, base + t->n_slots)): its roots, or its layers from the block roots up.
-// Enqueued on the context's stream; the caller synchronises before the batch's nodes go back to the pool.
-static int dataset_keep_from_batch(cp2_dataset* ds, const cp2_slot_trees* t, size_t base) {
+// Enqueued on `st` (default: the context's stream); the caller waits before the batch's nodes are used for anything else.
+static int dataset_keep_from_batch(cp2_dataset* ds, const cp2_slot_trees* t, size_t base, hipStream_t st = nullptr) {
   cp2_ctx* ctx = ds->ctx;
+  if (!st) st = ctx->stream;
   if (ds->tree_mode == 0) {
-    CP2_HIP(ctx, hipMemcpyAsync(ds->local_roots.u8() + base * 32, cp2_slot_trees_roots_dev(t), t->n_slots * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    CP2_HIP(ctx, hipMemcpyAsync(ds->local_roots.u8() + base * 32, cp2_slot_trees_roots_dev(t), t->n_slots * 32, hipMemcpyDeviceToDevice, st));
     return CP2_OK;
   }
   for (size_t k = 0; k < t->tsizes.size(); ++k)   // layer k of the batch's slots is contiguous, and so is its place in the dataset's layout
     CP2_HIP(ctx, hipMemcpyAsync(ds->compact.u8() + (ds->coff[k] + base * ds->csizes[k]) * 32, t->nodes.u8() + t->toff[k] * 32,
-                                t->n_slots * t->tsizes[k] * 32, hipMemcpyDeviceToDevice, ctx->stream));
+                                t->n_slots * t->tsizes[k] * 32, hipMemcpyDeviceToDevice, st));
   return CP2_OK;
 }
 
-// compact / roots-only build: batches of at most ~2 GiB of nodes (8 slots of 8 GiB; at least one slot), every batch a normal builder
-// call into pooled scratch; what the mode keeps is copied out, the rest goes back to the pool
+// compact / roots-only build: batches of at most ~1 GiB of nodes (transient_batch_slots: 4 slots of 8 GiB; at least one slot), every
+// batch a normal builder call; what the mode keeps is copied out, the rest is overwritten by the batch after next.
+//
+// Fake data: the batches PIPELINE (BuildScratch: two node buffers used alternately, staging that outlives a builder call, nothing
+// synchronised per batch).  A batch ends with its tree-layer passes -- 22 launches for 2^22-cell slots, the top 16 of them one lone
+// permutation latency each -- and the copy-out of what is kept, all on the context's first stream; the NEXT batch's generation and
+// hashing start on the second stream meanwhile (its chunks alternate between the two), so the device no longer drains between
+// batches (round 4 synchronised and freed here: 1.3-2 % of config 5's nominal share).  Node buffer b is handed
+// to batch k + 2 once batch k's copy-out has completed (an event; long past by then).
+// Slot files: batch by batch as before -- the ingestion pipe owns its ring and drains it, and that path is bound by the storage.
 static int dataset_build_transient(cp2_dataset* ds, int mode, bool allocated = false) {
   cp2_ctx* ctx = ds->ctx;
   const cp2_config& c = ds->cfg;
-  const size_t per_slot = trees_node_bytes(1, c.cell_size, c.block_size, c.n_cells);
-  const size_t batch = std::max<size_t>(1, std::min<size_t>(ds->n_local, ((size_t)2 << 30) / std::max<size_t>(per_slot, 1)));
+  const size_t batch = transient_batch_slots(ctx, c, ds->n_local);
   if (!allocated) CP2_TRY(dataset_alloc_kept(ds, mode));
   const char* what = mode == 2 ? "compact" : "roots-only";
   StageTimer trace;
-  for (size_t s0 = 0; s0 < ds->n_local; s0 += batch) {
-    const size_t n = std::min(batch, (size_t)ds->n_local - s0);
-    cp2_slot_trees* t = nullptr;
-    CP2_TRY(dataset_transient_trees(ds, s0, n, &t));
-    int st = dataset_keep_from_batch(ds, t, s0);
-    if (st == CP2_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = std::string(what) + " build: copy out of a batch failed"; st = CP2_ERR_HIP; }
-    cp2_slot_trees_free(t);
-    if (st != CP2_OK) return st;
-    if (trace.on && ((s0 / batch) % 32 == 31 || s0 + n == ds->n_local))   // a long build says where it is (CP2_TRACE)
-      std::fprintf(stderr, "[cp2 trace] %s build: %zu of %llu slots\n", what, s0 + n, (unsigned long long)ds->n_local);
+  if (ds->from_file) {
+    for (size_t s0 = 0; s0 < ds->n_local; s0 += batch) {
+      const size_t n = std::min(batch, (size_t)ds->n_local - s0);
+      cp2_slot_trees* t = nullptr;
+      CP2_TRY(dataset_transient_trees(ds, s0, n, &t));
+      int st = dataset_keep_from_batch(ds, t, s0);
+      if (st == CP2_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = std::string(what) + " build: copy out of a batch failed"; st = CP2_ERR_HIP; }
+      cp2_slot_trees_free(t);
+      if (st != CP2_OK) return st;
+      if (trace.on && ((s0 / batch) % 32 == 31 || s0 + n == ds->n_local))   // a long build says where it is (CP2_TRACE)
+        std::fprintf(stderr, "[cp2 trace] %s build: %zu of %llu slots\n", what, s0 + n, (unsigned long long)ds->n_local);
+    }
+    trace.lap(mode == 2 ? "compact build (block layers dropped)" : "roots-only build (trees dropped)");
+    return CP2_OK;
   }
+  int st = CP2_OK;
+  {
+    BuildScratch scratch;                       // drains the context's streams before its buffers go, whatever path leaves this scope
+    hipEvent_t kept[2] = {nullptr, nullptr};
+    struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int i = 0; i < 2; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } ev_guard{kept};
+    for (int i = 0; i < 2; ++i) CP2_HIP(ctx, hipEventCreateWithFlags(&kept[i], hipEventDisableTiming));
+    size_t k = 0;
+    for (size_t s0 = 0; st == CP2_OK && s0 < ds->n_local; s0 += batch, ++k) {
+      const size_t n = std::min(batch, (size_t)ds->n_local - s0);
+      const int b = (int)(k & 1);
+      if (k >= 2 && hipEventSynchronize(kept[b]) != hipSuccess) { ctx->err = std::string(what) + " build: a batch failed on the device"; st = CP2_ERR_HIP; break; }
+      cp2_slot_trees* t = nullptr;
+      st = trees_build_fake(ctx, c.seed, ds->first_slot + s0, n, c.cell_size, c.block_size, c.n_cells, 0, nullptr, &t, 1, true, &scratch, b);
+      if (st == CP2_OK) st = dataset_keep_from_batch(ds, t, s0);          // on the context's stream: follows the batch's layer passes
+      if (st == CP2_OK && hipEventRecord(kept[b], ctx->stream) != hipSuccess) { ctx->err = "hipEventRecord failed"; st = CP2_ERR_HIP; }
+      cp2_slot_trees_free(t);                                             // (the batch's nodes are the scratch's: nothing is waited for here)
+      if (trace.on && ((k % 32) == 31 || s0 + n == ds->n_local))
+        std::fprintf(stderr, "[cp2 trace] %s build: %zu of %llu slots enqueued\n", what, s0 + n, (unsigned long long)ds->n_local);
+    }
+    if (st == CP2_OK) {                         // everything landed (a failed launch or copy shows up here)
+      if (hipStreamSynchronize(ctx->stream) != hipSuccess || (ctx->aux_stream && hipStreamSynchronize(ctx->aux_stream) != hipSuccess)) {
+        (void)hipGetLastError();
+        ctx->err = std::string(what) + " build: a batch failed on the device";
+        st = CP2_ERR_HIP;
+      }
+    }
+  }
+  if (st != CP2_OK) return st;
   trace.lap(mode == 2 ? "compact build (block layers dropped)" : "roots-only build (trees dropped)");
   return CP2_OK;
 }
@@ -1319,31 +1366,73 @@ static int build_streamed_in_mode(cp2_ctx* ctx, const cp2_config* cfg, uint64_t 
       (void)hipStreamSynchronize(aux);
       trace.lap("last bodies");
     } else {
-      // Roots only (the nodes of all local slots do not fit the device, or the caller said so): the same pipeline over batches of
-      // slots whose nodes live in pooled scratch -- about 2 GiB of them: 8 slots of 8 GiB, a whole number of groups -- and go
-      // back to the pool once the batch's bodies are made; roots and bodies stay.  The tail of a batch (its last group's
-      // sampling and formatting) is not overlapped with the next batch's hashing: a few tens of ms per batch.
-      const size_t per_slot = trees_node_bytes(1, cfgv.cell_size, cfgv.block_size, cfgv.n_cells);
-      size_t batch = std::max<size_t>(1, ((size_t)2 << 30) / std::max<size_t>(per_slot, 1));
+      // Compact / roots only (the nodes of all local slots do not fit the device, or the caller said so): the same pipeline over
+      // batches of slots -- about 1 GiB of nodes: 4 slots of 8 GiB, a whole number of groups -- whose nodes are dropped once the
+      // batch's bodies are made and what the mode keeps is copied out; roots (or compact layers) and bodies stay.
+      size_t batch = transient_batch_slots(ctx, cfgv, n_local);
       batch = std::max(group_slots, batch / group_slots * group_slots);
       st = dataset_alloc_kept(dsp, tree_mode);
-      for (size_t base = 0; st == CP2_OK && base < n_local; base += batch) {
-        const size_t nb = std::min(batch, (size_t)n_local - base);
-        slot_base = base;
-        have_geom = false;                                     // node offsets are those of THIS batch's layout
-        cp2_slot_trees* t = nullptr;
-        st = from_file ? trees_build_files(ctx, file_base, first_slot + base, nb, cfgv.cell_size, cfgv.block_size, cfgv.n_cells, group_slots, on_done, &t, 1, true)
-                       : trees_build_fake(ctx, cfgv.seed, first_slot + base, nb, cfgv.cell_size, cfgv.block_size, cfgv.n_cells, group_slots, on_done, &t, 1, true);
-        while (st == CP2_OK && consumed < n_groups) { st = consume(consumed); ++consumed; }
-        pool.wait_idle();                                      // nothing reads this batch's landing buffers or nodes any more
-        (void)hipStreamSynchronize(aux);
-        if (st == CP2_OK && t) {
-          st = dataset_keep_from_batch(dsp, t, base);
-          if (st == CP2_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "streamed build: copy out of a batch failed"; st = CP2_ERR_HIP; }
+      if (from_file) {
+        // slot files: batch by batch (the ingestion pipe owns and drains its ring; the storage is what bounds this path)
+        for (size_t base = 0; st == CP2_OK && base < n_local; base += batch) {
+          const size_t nb = std::min(batch, (size_t)n_local - base);
+          slot_base = base;
+          have_geom = false;                                     // node offsets are those of THIS batch's layout
+          cp2_slot_trees* t = nullptr;
+          st = trees_build_files(ctx, file_base, first_slot + base, nb, cfgv.cell_size, cfgv.block_size, cfgv.n_cells, group_slots, on_done, &t, 1, true);
+          while (st == CP2_OK && consumed < n_groups) { st = consume(consumed); ++consumed; }
+          pool.wait_idle();                                      // nothing reads this batch's landing buffers or nodes any more
+          (void)hipStreamSynchronize(aux);
+          if (st == CP2_OK && t) {
+            st = dataset_keep_from_batch(dsp, t, base);
+            if (st == CP2_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "streamed build: copy out of a batch failed"; st = CP2_ERR_HIP; }
+          }
+          cp2_slot_trees_free(t);
+          if (trace.on && ((base / batch) % 32 == 31 || base + nb == n_local))
+            std::fprintf(stderr, "[cp2 trace] streamed %s build: %zu of %llu slots\n", tree_mode == 2 ? "compact" : "roots-only", base + nb, (unsigned long long)n_local);
         }
-        cp2_slot_trees_free(t);
-        if (trace.on && ((base / batch) % 32 == 31 || base + nb == n_local))
-          std::fprintf(stderr, "[cp2 trace] streamed %s build: %zu of %llu slots\n", tree_mode == 2 ? "compact" : "roots-only", base + nb, (unsigned long long)n_local);
+      } else {
+        // Fake data: the batches PIPELINE (BuildScratch: two node buffers used alternately, nothing synchronised per batch).  A
+        // batch's tail -- the layer passes of its last group on the second stream, that group's sampling, gathers and downloads
+        // on the third, the copy-out of what is kept -- runs while the next batch's generation and hashing already occupy the
+        // first stream (round 4 drained the device here: 816 s against 806 s for the roots alone over 32 TiB).  Node buffer b
+        // goes to batch k + 2 once batch k's copy-out (second stream) and last sampling (third stream) have completed.
+        BuildScratch scratch;                                    // drains the context's streams before its buffers go
+        hipStream_t layer_stream = nullptr;
+        if (st == CP2_OK) st = aux_stream(ctx, &layer_stream, 1);
+        hipEvent_t done_ev[2] = {nullptr, nullptr}, sampled[2] = {nullptr, nullptr};
+        struct EvGuard { hipEvent_t* a; hipEvent_t* b; ~EvGuard() { for (int i = 0; i < 2; ++i) { if (a[i]) (void)hipEventDestroy(a[i]); if (b[i]) (void)hipEventDestroy(b[i]); } } } ev_guard2{done_ev, sampled};
+        for (int i = 0; i < 2 && st == CP2_OK; ++i)
+          if (hipEventCreateWithFlags(&done_ev[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&sampled[i], hipEventDisableTiming) != hipSuccess) {
+            ctx->err = "hipEventCreate failed";
+            st = CP2_ERR_HIP;
+          }
+        size_t k = 0;
+        for (size_t base = 0; st == CP2_OK && base < n_local; base += batch, ++k) {
+          const size_t nb = std::min(batch, (size_t)n_local - base);
+          const int b = (int)(k & 1);
+          if (k >= 2 && hipEventSynchronize(done_ev[b]) != hipSuccess) { ctx->err = "streamed build: a batch failed on the device"; st = CP2_ERR_HIP; break; }
+          slot_base = base;
+          have_geom = false;                                     // node offsets are those of THIS batch's layout
+          cp2_slot_trees* t = nullptr;
+          st = trees_build_fake(ctx, cfgv.seed, first_slot + base, nb, cfgv.cell_size, cfgv.block_size, cfgv.n_cells, group_slots, on_done, &t, 1, true, &scratch, b);
+          if (st == CP2_OK) st = dataset_keep_from_batch(dsp, t, base, layer_stream);     // follows the batch's last layer pass on that stream
+          if (st == CP2_OK && (hipEventRecord(sampled[b], aux) != hipSuccess || hipStreamWaitEvent(layer_stream, sampled[b], 0) != hipSuccess ||
+                               hipEventRecord(done_ev[b], layer_stream) != hipSuccess)) {
+            ctx->err = "streamed build: event bookkeeping failed";
+            st = CP2_ERR_HIP;
+          }
+          cp2_slot_trees_free(t);                                // (the batch's nodes are the scratch's: nothing is waited for here)
+          if (trace.on && ((k % 32) == 31 || base + nb == n_local))
+            std::fprintf(stderr, "[cp2 trace] streamed %s build: %zu of %llu slots enqueued\n", tree_mode == 2 ? "compact" : "roots-only", base + nb, (unsigned long long)n_local);
+        }
+        while (st == CP2_OK && consumed < n_groups) { st = consume(consumed); ++consumed; }
+        pool.wait_idle();
+        if (st == CP2_OK && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipStreamSynchronize(layer_stream) != hipSuccess || hipStreamSynchronize(aux) != hipSuccess)) {
+          (void)hipGetLastError();
+          ctx->err = "streamed build: a batch failed on the device";
+          st = CP2_ERR_HIP;
+        }
       }
       trace.lap("trees + bodies, batch by batch (trees dropped)");
     }

@@ -163,7 +163,7 @@ int main(int argc, char** argv) {
                      "the Goldilocks variants are out of scope\n";
         return 2;
       }
-      Engine engine;   // every visible GPU; CODEX_P2_GPUS=<count | index list> restricts it (no new flag: the reference's flag set stays exact)
+      Engine engine;   // one GPU; CODEX_P2_GPUS=all | <count> | <index list> opts in to several (no new flag: the reference's flag set stays exact)
       Entropy entropy = intToBN254(fullCfg.entropy);
       SlotProofInput prfInput = generateProofInputBN254(engine, fullCfg.hashCfg, fullCfg.globCfg, fullCfg.dsetCfg, fullCfg.slotIndex, entropy);
       exportProofInputBN254(fullCfg.hashCfg, fullCfg.outFile, prfInput);

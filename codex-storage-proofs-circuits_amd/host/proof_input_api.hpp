@@ -90,8 +90,9 @@ inline int64_t pow2(int k) { return int64_t(1) << k; }
 // ---- the engine -----------------------------------------------------------------------------------
 // Every GPU of the node behind one object (cp2_multi, include/codex_p2.h section e): the seam calls (hashCell, compress,
 // merkleTree, cellIndices ...) run on the first device's context, generateProofInputBN254 cuts the dataset's slots over all
-// devices.  Engine() takes every visible gfx950 device (the environment variable CODEX_P2_GPUS restricts it: "<count>" or an
-// index list); Engine(d) exactly device d.
+// devices.  Engine() takes ONE device -- the first visible gfx950 -- unless the environment variable CODEX_P2_GPUS names more ("all",
+// "<count>" or an index list): several devices are opt-in until the exchange between two real devices has a committed record
+// (include/codex_p2.h, cp2_multi_init); Engine(d) exactly device d.
 class Engine {
  public:
   Engine() { init(nullptr, 0); }
@@ -118,7 +119,11 @@ class Engine {
  private:
   void init(const int* devices, int n) {
     int st = cp2_multi_init(devices, n, &multi_);
-    if (st != CP2_OK) throw std::runtime_error(std::string("cp2_multi_init: ") + cp2_strerror(st) + (st == CP2_ERR_INVALID ? " (CODEX_P2_GPUS must be a device count or a comma-separated index list, CODEX_P2_MIN_CELLS a number, CODEX_P2_SPLIT 0, 1 or a power of two)" : ""));
+    if (st != CP2_OK) {
+      char why[512] = "";
+      if (st == CP2_ERR_INVALID) (void)cp2_check_environment(why, sizeof why);   // names the CODEX_P2_* variable that does not hold what it takes
+      throw std::runtime_error(std::string("cp2_multi_init: ") + cp2_strerror(st) + (why[0] ? std::string(" (") + why + ")" : std::string()));
+    }
   }
   cp2_multi* multi_ = nullptr;
 };

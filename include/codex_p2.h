@@ -65,6 +65,8 @@ int cp2_device_is_native(const cp2_ctx* ctx);
  *   CODEX_P2_SPLIT       0, 1 or a power of two                                                  (cp2_multi_set_split)
  *   CODEX_P2_KEEP_TREES  "auto" | "1" | "2" | "0"                                                (cp2_set_keep_trees)
  *   CODEX_P2_EXCHANGE_TIMEOUT_S  seconds the exchange of slot roots may take (default 120; 0 = no limit)
+ *   CODEX_P2_STAGE_MB    MiB of device staging per chunk of generated cells (default 2048; cp2_init); a compact / roots-only build
+ *                        holds half of it in tree nodes per batch
  *   CODEX_P2_MEM_LIMIT_MB        (tests) a cap, in MiB per device, on the device memory this process may hold through the library:
  *                        the automatic residency choice sees min(free, cap left) and an allocation beyond the cap fails like a real
  *                        out-of-memory, so all residency modes and the fallback between them can be reached on an empty 288 GB device */

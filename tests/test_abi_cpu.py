@@ -255,3 +255,41 @@ def test_multi_plan_and_shard_range_properties(pkg):
         assert covered == items and max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
 
     check()
+
+
+def test_environment_is_parsed_strictly_and_the_offender_is_named(pkg, tmp_path):
+    """Every CODEX_P2_* variable holds exactly what it takes or the library refuses to start -- BEFORE any device is touched, so this
+    runs on the CPU: through cp2_check_environment, and through the cli twin's error message (what a user of workflow/prove.sh sees).
+    VERDICT r04 item 5: CODEX_P2_GATHER=rcl silently meant "automatic", CODEX_P2_KEEP_TREES=3 too."""
+    bad = [("CODEX_P2_GATHER", "rcl"), ("CODEX_P2_GATHER", "RCCL"), ("CODEX_P2_GATHER", "rccl "), ("CODEX_P2_KEEP_TREES", "3"), ("CODEX_P2_KEEP_TREES", "-1"),
+           ("CODEX_P2_KEEP_TREES", "compact"), ("CODEX_P2_GPUS", "two"), ("CODEX_P2_GPUS", "0,x"), ("CODEX_P2_GPUS", "ALL"), ("CODEX_P2_GPUS", "0"),
+           ("CODEX_P2_SPLIT", "3"), ("CODEX_P2_MIN_CELLS", "1e6"), ("CODEX_P2_MEM_LIMIT_MB", "1g"), ("CODEX_P2_MEM_LIMIT_MB", "-5"),
+           ("CODEX_P2_EXCHANGE_TIMEOUT_S", "soon"), ("CODEX_P2_STAGE_MB", "0"), ("CODEX_P2_STAGE_MB", "big")]
+    good = [("CODEX_P2_GATHER", "auto"), ("CODEX_P2_GATHER", "rccl"), ("CODEX_P2_GATHER", "copy"), ("CODEX_P2_GATHER", "host"), ("CODEX_P2_KEEP_TREES", "auto"),
+            ("CODEX_P2_KEEP_TREES", "0"), ("CODEX_P2_KEEP_TREES", "2"), ("CODEX_P2_GPUS", "all"), ("CODEX_P2_GPUS", "8"), ("CODEX_P2_GPUS", "0,0"), ("CODEX_P2_GPUS", "2,"),
+            ("CODEX_P2_SPLIT", "4"), ("CODEX_P2_MEM_LIMIT_MB", "4096"), ("CODEX_P2_EXCHANGE_TIMEOUT_S", "0"), ("CODEX_P2_STAGE_MB", "64")]
+    clean = {k: v for k, v in os.environ.items() if not k.startswith("CODEX_P2_")}
+    saved = {k: os.environ.pop(k) for k in list(os.environ) if k.startswith("CODEX_P2_")}
+    try:
+        assert pkg.check_environment() is None
+        for var, val in bad + good:
+            os.environ[var] = val                                   # (putenv: the library's getenv sees it)
+            said = pkg.check_environment()
+            del os.environ[var]
+            if (var, val) in bad:
+                assert said and var in said and ('"%s"' % val) in said and "takes" in said, (var, val, said)
+            else:
+                assert said is None, (var, val, said)
+    finally:
+        os.environ.update(saved)
+    # the drop-in: the same words on stderr, a non-zero exit code, no output file -- with or without a GPU in the box
+    args = ["--nslots=2", "--ncells=64", "--nsamples=2", "--field=bn254", "--hash=poseidon2"]
+    for var, val in (("CODEX_P2_GATHER", "rcl"), ("CODEX_P2_KEEP_TREES", "3"), ("CODEX_P2_MEM_LIMIT_MB", "lots")):
+        out = str(tmp_path / "x.json")
+        r = subprocess.run([pkg.CLI_PATH] + args + ["--output=" + out], env=dict(clean, **{var: val}), capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "invalid argument" in r.stderr and var in r.stderr and val in r.stderr and not os.path.exists(out), (var, r.stderr)
+    # a context refuses a malformed environment too (cp2_init), whatever the device situation
+    r = subprocess.run([os.sys.executable, "-c", "import sys; sys.path.insert(0, %r); import __graft_entry__ as g; p = g.load_package()\n"
+                        "try:\n    p.Context(0)\nexcept p.CodexP2Error as e:\n    print('status', e.status)" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))],
+                       env=dict(clean, CODEX_P2_KEEP_TREES="7"), capture_output=True, text=True, timeout=120)
+    assert "status -1" in r.stdout, (r.stdout, r.stderr[-500:])

@@ -1,0 +1,275 @@
+"""GPU suite, round 5: residency that survives a shared device, the verified + bounded exchange, the cache that accepts what it
+finds, pipelined transient builds, the opt-in multi-GPU default.  Everything against the oracle-only fixtures."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def hexroot(r):
+    return r.tobytes()[::-1].hex()
+
+
+def child(job, **env):
+    """tests/residency_child.py in a fresh process: its own environment, an empty allocation ledger."""
+    clean = {k: v for k, v in os.environ.items() if not k.startswith("CODEX_P2_")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "residency_child.py"), json.dumps(job)], capture_output=True, text=True, timeout=900,
+                       env=dict(clean, CP2_TRACE="1", **{k: str(v) for k, v in env.items()}))
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]), r.stderr
+
+
+# ---- what dataset_tree_mode plans with (csrc/proof_input.cpp), restated so that the caps below sit inside its windows -----------------
+def layer_sum(n):
+    s, m, bottom = 0, n, True
+    while True:
+        s += m
+        if m == 1 and not bottom:
+            return s
+        m, bottom = (m + 1) // 2, False
+
+
+def plan_bytes(c, n_local, stage_mb=2048):
+    cpb = c["blockSize"] // c["cellSize"]
+    nblocks = c["nCells"] // cpb
+    per_slot = (nblocks * (layer_sum(cpb) - 1) + layer_sum(nblocks)) * 32
+    compact = layer_sum(nblocks) * 32
+    data = n_local * c["nCells"] * c["cellSize"]
+    staging, headroom = 2 * min(data, stage_mb << 20), min(data, 1 << 30)
+    batch = max(1, min(n_local, ((stage_mb << 20) // 2) // per_slot))
+    need1 = per_slot * n_local + staging + headroom
+    need2 = compact * n_local + 2 * batch * per_slot + staging + headroom
+    return need1 / 0.9, need2 / 0.9           # free bytes from which "every node" / "compact" is chosen
+
+
+def test_memory_cap_reaches_all_three_residency_modes(golden):
+    """CODEX_P2_MEM_LIMIT_MB (a cap on what the process may hold on the device, honoured by the allocations themselves) walks the automatic
+    choice through its three outcomes on config 5's scale-down (32 768 slots x 2^12 cells: 8 GiB of nodes, 0.25 GiB compact) without
+    288 GB of anything: every node under 16 GiB, compact under 11 GiB, roots only under 7 GiB -- same roots, same input.json each time."""
+    g5 = golden("config5.json")["scaled"]
+    free1, free2 = plan_bytes(g5["config"], 32768)
+    assert free2 < 11 * 2**30 < free1 < 16 * 2**30 and 7 * 2**30 < free2
+    slots = [0, 16384]
+    for cap_mb, want_mode in ((16384, 1), (11264, 2), (7168, 0)):
+        res, err = child({"what": "single", "config": g5["config"], "entropy": g5["entropy"], "slots": slots}, CODEX_P2_MEM_LIMIT_MB=cap_mb)
+        assert res["modes"] == [want_mode], (cap_mb, res["modes"], err[-1500:])
+        assert res["slot_roots_sha256"] == g5["slot_roots_sha256"] and res["dataset_root_hex"] == g5["dataset_root_hex"]
+        for s in slots:
+            assert res["inputs"][str(s)] == {k: g5["inputs"][str(s)][k] for k in ("json_sha256", "json_bytes")}, (cap_mb, s)
+        assert "did not fit after all" not in err                     # the estimate held: no step-down was needed
+
+
+def test_an_automatic_choice_that_does_not_fit_after_all_steps_down(golden):
+    """The figure the choice is made from is a snapshot -- another tenant can take the memory before the allocation.  Simulated with the
+    test-only CODEX_P2_TEST_OPTIMISTIC=1 (the choice starts at "every node" without looking) under a cap that holds the compact build
+    only: the first attempt fails with an allocation error, everything is freed, the scratch pool trimmed, and the build is retried
+    one mode down -- said so in the trace, same roots.  A mode the caller NAMED is never changed: the same cap with
+    CODEX_P2_KEEP_TREES=1 is an allocation error."""
+    g5 = golden("config5.json")["scaled"]
+    job = {"what": "single", "config": g5["config"], "entropy": g5["entropy"], "slots": [32767]}
+    res, err = child(job, CODEX_P2_MEM_LIMIT_MB=10240, CODEX_P2_TEST_OPTIMISTIC=1)
+    assert res["modes"] == [2], (res, err[-1500:])
+    assert "keeping every node did not fit after all" in err and "retrying with the compact layers" in err
+    assert res["slot_roots_sha256"] == g5["slot_roots_sha256"] and res["dataset_root_hex"] == g5["dataset_root_hex"]
+    assert res["inputs"]["32767"]["json_sha256"] == g5["inputs"]["32767"]["json_sha256"]
+    res, err = child(dict(job, what="streamed"), CODEX_P2_MEM_LIMIT_MB=10240, CODEX_P2_TEST_OPTIMISTIC=1)      # the streamed build has the same chain
+    assert res["modes"] == [2] and "streamed build: keeping every node did not fit after all" in err, err[-1500:]
+    assert res["dataset_root_hex"] == g5["dataset_root_hex"] and res["inputs"]["32767"]["json_sha256"] == g5["inputs"]["32767"]["json_sha256"]
+    clean = {k: v for k, v in os.environ.items() if not k.startswith("CODEX_P2_")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "residency_child.py"), json.dumps(job)], capture_output=True, text=True, timeout=600,
+                       env=dict(clean, CODEX_P2_MEM_LIMIT_MB="10240", CODEX_P2_KEEP_TREES="1"))
+    assert r.returncode != 0 and "status -4" in r.stderr, r.stderr[-1500:]                  # CP2_ERR_ALLOC, no silent change of a named mode
+
+
+def test_four_contexts_on_one_device_share_what_it_has_free(golden):
+    """cp2_multi over [0, 0, 0, 0]: every shard's automatic choice plans with a QUARTER of what the device had free before the shards
+    started (round 4: each saw all of it, all chose "every node", the build ended in CP2_ERR_ALLOC).  Config 4's shape (4096 slots x
+    2^12 cells) with 64 MiB staging chunks so that the window between compact and resident is reachable with 32 GiB of data: under a
+    6 GiB cap a quarter (1536 MiB) holds the compact build (1360) but not the resident one (1564) -> compact on every shard; under
+    8 GiB every shard keeps every node.  Roots, dataset root and input.json = the oracle-only fixture either way."""
+    g4 = golden("fullsize.json")["config4"]
+    free1, free2 = plan_bytes(g4["config"], 1024, stage_mb=64)
+    assert free2 < (6144 << 20) / 4 < free1 < (8192 << 20) / 4
+    slots = [1234, 4095]
+    for cap_mb, want in ((6144, [2, 2, 2, 2]), (8192, [1, 1, 1, 1])):
+        res, err = child({"what": "multi", "devices": [0, 0, 0, 0], "config": g4["config"], "entropy": g4["entropy"], "slots": slots},
+                         CODEX_P2_MEM_LIMIT_MB=cap_mb, CODEX_P2_STAGE_MB=64)
+        assert res["modes"] == want and res["units_per_slot"] == 1 and len(res["shards"]) == 4, (cap_mb, res, err[-1500:])
+        assert res["slot_roots_sha256"] == g4["slot_roots_sha256"] and res["dataset_root_hex"] == g4["dataset_root_hex"]
+        for s in slots:
+            assert res["inputs"][str(s)] == {k: g4["inputs"][str(s)][k] for k in ("json_sha256", "json_bytes")}
+        assert "did not fit after all" not in err
+
+
+@pytest.mark.parametrize("mode", [2, 0])
+def test_pipelined_transient_builds_over_many_batches(golden, mode):
+    """The compact / roots-only builds pipeline their batches (two node buffers used alternately, the copy-out of batch k under the
+    hashing of batch k + 1, nothing synchronised in between).  16 MiB staging chunks cut config 4's 4096 slots into 128 batches of 32:
+    plain and streamed, every slot root, the dataset root and two complete input.json texts against the oracle-only fixture."""
+    g4 = golden("fullsize.json")["config4"]
+    for what in ("single", "streamed"):
+        res, err = child({"what": what, "config": g4["config"], "entropy": g4["entropy"], "slots": [1234, 4095]}, CODEX_P2_KEEP_TREES=mode, CODEX_P2_STAGE_MB=16)
+        assert res["modes"] == [mode], (what, res)
+        assert res["slot_roots_sha256"] == g4["slot_roots_sha256"] and res["dataset_root_hex"] == g4["dataset_root_hex"], what
+        for s in ("1234", "4095"):
+            assert res["inputs"][s] == {k: g4["inputs"][s][k] for k in ("json_sha256", "json_bytes")}, (what, s)
+        assert "4096 of 4096 slots enqueued" in err
+
+
+# ---- the exchange: verified, bounded, and still usable after a failure ------------------------------------------------------------------
+def test_exchange_is_verified_whatever_carried_it(pkg, golden):
+    """After the exchange every device must find its own slot roots at its own rows of the list it received, and all devices must
+    compute the same dataset root.  The test-only CODEX_P2_TEST_EXCHANGE_FAULT=corrupt flips one byte of the last context's gathered
+    copy on the device paths -- what a wrong rank-to-device mapping or a misplaced block looks like: the build fails with
+    "exchange verification failed", by slots and by units, for peer copies and for the RCCL path (a one-rank communicator asked for
+    by name); it never returns a dataset with a wrong root.  And the handle, its contexts and its cached communicator still work."""
+    c = golden("proof_inputs.json")["inputs"]["params_default"]["config"]
+    want = golden("proof_inputs.json")["inputs"]["params_default"]
+    cfg = pkg.make_config(**c)
+    for devices, policy, split in (([0, 0, 0], pkg.GATHER_COPY, 1), ([0, 0], pkg.GATHER_COPY, 2), ([0], pkg.GATHER_RCCL, 1)):
+        m = pkg.Multi(devices)
+        m.set_policy(policy, 1)
+        m.set_split(split)
+        ok = m.dataset(cfg)
+        root = ok.root().copy()
+        assert ok.proof_input(want["slotIndex"], want["entropy"]).json() == golden("input_params_default.json")
+        ok.free()
+        os.environ["CODEX_P2_TEST_EXCHANGE_FAULT"] = "corrupt"
+        try:
+            with pytest.raises(pkg.CodexP2Error) as e:
+                m.dataset(cfg)
+            assert "exchange verification failed" in str(e.value) and ("copy" in str(e.value) or "rccl" in str(e.value)), str(e.value)
+        finally:
+            del os.environ["CODEX_P2_TEST_EXCHANGE_FAULT"]
+        again = m.dataset(cfg)                                        # the handle (and, for RCCL, its cached communicator) after the failure
+        assert (again.root() == root).all() and ("rccl" in m.gather_mode() if policy == pkg.GATHER_RCCL else "copy" in m.gather_mode())
+        assert again.proof_input(want["slotIndex"], want["entropy"]).json() == golden("input_params_default.json")
+        again.free()
+        m.close()
+
+
+def test_rccl_by_name_on_one_device_after_a_failed_build(pkg, golden, tmp_path):
+    """CP2_GATHER_RCCL on [0] (a one-rank communicator: the RCCL code path itself) before and after a build that FAILS (a missing slot
+    file): the error names the file, and the next build on the same handle uses the cached communicator and gives the fixture's text."""
+    m0 = golden("proof_inputs.json")["inputs"]["params_default"]
+    cfg = pkg.make_config(**m0["config"])
+    m = pkg.Multi([0])
+    m.set_policy(pkg.GATHER_RCCL, 0)
+    a = m.dataset(cfg)
+    assert "rccl" in m.gather_mode()
+    a.free()
+    with pytest.raises(pkg.CodexP2Error) as e:
+        m.dataset(pkg.make_config(**dict(m0["config"], file=str(tmp_path / "nothing_here"))))
+    assert "nothing_here0.dat" in str(e.value)
+    b = m.dataset(cfg)
+    assert "rccl" in m.gather_mode() and b.proof_input(m0["slotIndex"], m0["entropy"]).json() == golden("input_params_default.json")
+    b.free()
+    m.close()
+
+
+def test_several_devices_are_opt_in(pkg):
+    """cp2_multi_init with no device named takes ONE device (the first visible gfx950) until the exchange between two real devices has a
+    committed record; CODEX_P2_GPUS=all / a count / a list opts in."""
+    import torch
+    saved = os.environ.pop("CODEX_P2_GPUS", None)
+    try:
+        m = pkg.Multi()
+        assert m.count == 1 and m.devices() == [0]
+        m.close()
+        os.environ["CODEX_P2_GPUS"] = "all"
+        m = pkg.Multi()
+        assert m.count == torch.cuda.device_count()
+        m.close()
+        os.environ["CODEX_P2_GPUS"] = "0,0"
+        m = pkg.Multi()
+        assert m.devices() == [0, 0]
+        m.close()
+    finally:
+        os.environ.pop("CODEX_P2_GPUS", None)
+        if saved is not None:
+            os.environ["CODEX_P2_GPUS"] = saved
+
+
+# ---- the cache accepts what it finds; roots-only datasets notice changed data -----------------------------------------------------------
+def test_cached_build_accepts_any_valid_representation_and_never_evicts_a_richer_one(pkg, golden, tmp_path, capfd):
+    """Which representation a cached build WANTS depends on what the device has free that day.  (1) A run that would keep every node
+    finds the compact layers in the cache: it takes them (the dataset is compact, nothing is hashed), instead of rebuilding every
+    slot and overwriting the file.  (2) A run that keeps its trees compact finds a full tree cache at the path: the tree cache stays,
+    the compact layers go to "<path>.kept" beside it, and the next compact run loads from there.  (3) A named mode is literal: a
+    roots-only run does not take a compact cache."""
+    m0 = golden("proof_inputs.json")["inputs"]["testmain_small"]
+    cfg, want = pkg.make_config(**m0["config"]), golden("input_testmain_small.json")
+    os.environ["CP2_TRACE"] = "1"
+    try:
+        ctx = pkg.Context(0)
+        cache = str(tmp_path / "a.cp2")
+        ctx.set_keep_trees(2)
+        ctx.dataset(cfg, cache=cache).free()                         # the compact layers are what is cached
+        assert open(cache, "rb").read(8) == b"CP2KEPT1"
+        ctx.set_keep_trees(-1)                                        # automatic: an empty 288 GB device -> "every node" is what it wants
+        capfd.readouterr()
+        ds = ctx.dataset(cfg, cache=cache)
+        err = capfd.readouterr().err
+        assert ds.tree_mode == 2 and "taken as it is" in err and "generate + hash" not in err, err
+        assert ds.proof_input(m0["slotIndex"], m0["entropy"]).json() == want and open(cache, "rb").read(8) == b"CP2KEPT1"
+        ds.free()
+        # (2)
+        cache2 = str(tmp_path / "b.cp2")
+        ctx.set_keep_trees(1)
+        ctx.dataset(cfg, cache=cache2).free()
+        tree_bytes = open(cache2, "rb").read()
+        assert tree_bytes[:8] == b"CP2TREE3"
+        ctx.set_keep_trees(2)
+        ctx.dataset(cfg, cache=cache2).free()                        # built compact; the tree cache is not overwritten
+        assert open(cache2, "rb").read() == tree_bytes and open(cache2 + ".kept", "rb").read(8) == b"CP2KEPT1"
+        capfd.readouterr()
+        ds = ctx.dataset(cfg, cache=cache2)
+        err = capfd.readouterr().err
+        assert ds.tree_mode == 2 and "compact layers loaded from the cache" in err and "generate + hash" not in err, err
+        assert ds.proof_input(m0["slotIndex"], m0["entropy"]).json() == want
+        ds.free()
+        ctx.set_keep_trees(1)
+        ds = ctx.dataset(cfg, cache=cache2)                          # and the tree cache still loads
+        assert ds.tree_mode == 1 and ds.proof_input(m0["slotIndex"], m0["entropy"]).json() == want
+        ds.free()
+        # (3)
+        ctx.set_keep_trees(0)
+        capfd.readouterr()
+        ds = ctx.dataset(cfg, cache=cache)                           # holds compact layers; roots only was NAMED: built, and written in place of them
+        err = capfd.readouterr().err
+        assert ds.tree_mode == 0 and "built and written to the cache" in err, err
+        ds.free()
+        ctx.close()
+    finally:
+        del os.environ["CP2_TRACE"]
+
+
+def test_roots_only_dataset_notices_changed_slot_data(pkg, oracle, golden, tmp_path):
+    """Roots only: slotRoot, slotProof and dataSetRoot come from the stored roots, indices / paths / cells from the slot's tree rebuilt
+    on demand.  When the slot file changed in between, the rebuilt root no longer equals the stored one: CP2_ERR_IO ("... does not hash
+    to its stored root"), never an input.json over mixed data (compact mode has had the same check per block)."""
+    C, _ = oracle
+    c = golden("proof_inputs.json")["inputs"]["testmain_small"]["config"]
+    base = str(tmp_path / "slotdata")
+    for k in range(c["nSlots"]):
+        C.gen_fake_cells(C.slot_seed(c["seed"], k), 0, c["nCells"], c["cellSize"]).tofile("%s%d.dat" % (base, k))
+    ctx = pkg.Context(0)
+    ctx.set_keep_trees(0)
+    ds = ctx.dataset(pkg.make_config(**dict(c, file=base)))
+    assert ds.tree_mode == 0 and ds.proof_input(3, 1234567).json() == golden("input_testmain_small.json")
+    raw = bytearray(open(base + "3.dat", "rb").read())
+    raw[777] ^= 0x40
+    open(base + "3.dat", "wb").write(bytes(raw))
+    with pytest.raises(pkg.CodexP2Error) as e:
+        ds.proof_input(3, 1234567)
+    assert e.value.status == -5 and "slot 3 does not hash to its stored root" in str(e.value)
+    assert ds.proof_input(2, 1234567).json()                          # the other slots still prove
+    ds.free()
+    ctx.close()
