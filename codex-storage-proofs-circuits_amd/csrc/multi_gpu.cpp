@@ -255,6 +255,9 @@ struct cp2_multi_dataset {
   std::vector<size_t> upper_off;
   std::vector<uint8_t> dlayers;
   std::vector<size_t> dsizes;
+  // by units, streamed kind: the finished input.json of every slot for the entropy of the build (few, large slots: a few MB)
+  bool prepared = false;
+  std::vector<std::string> texts;
   ~cp2_multi_dataset() {
     for (auto& s : shards) { cp2_dataset_free(s.ds); cp2_slot_trees_free(s.units); }
   }
@@ -686,6 +689,8 @@ void plan_shards(const cp2_config& c, size_t n_dev, uint64_t min_cells_per_devic
 }
 
 enum class BuildKind { Plain, Streamed, Cached };
+int units_export(cp2_multi_dataset* mds, const uint64_t* slot_idx, size_t n, const uint8_t entropy[32], const char* dir, int threads, size_t batch,
+                 uint64_t* total_bytes, std::vector<std::string>* keep);
 
 int multi_build(cp2_multi* m, const cp2_config* cfg, BuildKind kind, const uint8_t* entropy, int threads, size_t group_slots,
                 const char* cache_path, cp2_multi_dataset** out) {
@@ -693,9 +698,13 @@ int multi_build(cp2_multi* m, const cp2_config* cfg, BuildKind kind, const uint8
   *out = nullptr;
   m->err.clear();
   if (cfg->n_slots == 0 || cfg->max_depth < 0 || cfg->max_log2_nslots < 0) return CP2_ERR_INVALID;
-  // whole slots or units: streamed builds keep whole slots (their per-slot bodies live in a cp2_dataset)
+  // whole slots or units -- the same plan for every kind of build.  A STREAMED build cut by units is two-phase: nothing of a proof
+  // input can be made while later units hash (sampling needs the slot root, which exists only after the exchange of unit roots), so
+  // it is the balanced unit build, the exchange, then every slot's input.json from the devices that hold its units -- batched per
+  // device, the devices in parallel (units_export) -- kept as text for cp2_multi_dataset_export_streamed / _streamed_json.  (Round 4
+  // fell back to whole slots here: 11 slots of 8 GiB on 8 GPUs left the busiest device with 2 slots against a share of 1.375.)
   uint64_t world = 1, S = 1;
-  plan_shards(*cfg, m->devices.size(), m->min_cells, kind == BuildKind::Streamed ? 1 : m->split, &world, &S);
+  plan_shards(*cfg, m->devices.size(), m->min_cells, m->split, &world, &S);
   // how many shards build on each PHYSICAL device at the same time (an index may repeat): each context's automatic residency choice
   // takes its share of what that device has free, not all of it (proof_input.cpp dataset_tree_mode)
   auto share_of = [&](uint64_t r, uint64_t w) { int k = 0; for (uint64_t q = 0; q < w; ++q) k += m->devices[q] == m->devices[r]; return k; };
@@ -794,84 +803,198 @@ int multi_build(cp2_multi* m, const cp2_config* cfg, BuildKind kind, const uint8
       }
     return st;
   }
+  if (S > 1 && kind == BuildKind::Streamed) {
+    mds->texts.assign(cfg->n_slots, std::string());
+    std::vector<uint64_t> all(cfg->n_slots);
+    for (uint64_t i = 0; i < cfg->n_slots; ++i) all[i] = i;
+    uint64_t tot = 0;
+    CP2_TRY(units_export(mds.get(), all.data(), all.size(), entropy, nullptr, threads, 0, &tot, &mds->texts));
+    mds->prepared = true;
+    trace.lap("every input.json from the devices holding the units");
+  }
   *out = mds.release();
   return CP2_OK;
 }
 
-// generateProofInput (gen_input/bn254.nim:35-79) for a dataset cut by units: the cell indices from the slot root, the bottom
-// part of every path from the unit that holds the sampled cell (on whichever device that is), the top part from the upper
-// layers, the cells regenerated / read, all of it handed to the byte-exact writer's object (cp2_proof_input_create).
-int units_proof_input(cp2_multi_dataset* mds, uint64_t slot, const uint8_t entropy[32], cp2_proof_input** out) {
+// generateProofInput (gen_input/bn254.nim:35-79) for `n` slots of a dataset cut by units, shaped like the by-slots path: ONE
+// sampling launch for all (slot, counter) pairs (sample/bn254.nim:16-27), the touched units grouped by the device that holds
+// them -- one batched gather per device, the devices in parallel (the bottom of every path: merkleProof inside the unit) -- the
+// top of every path from the upper layers, the sampled cells regenerated in one launch (or read from the slot files on `threads`
+// host threads), all of it handed to the byte-exact writer's objects (cp2_proof_input_create).  Round 4 did one
+// cp2_slot_trees_paths + synchronisation per touched unit, one slot after the other.
+int units_proof_inputs(cp2_multi_dataset* mds, const uint64_t* slots, size_t n, const uint8_t entropy_in[32], int threads, cp2_proof_input** out) {
   const cp2_config& c = mds->cfg;
   cp2_multi* m = mds->m;
-  if (slot >= c.n_slots) return CP2_ERR_INVALID;
+  for (size_t i = 0; i < n; ++i) { out[i] = nullptr; if (slots[i] >= c.n_slots) return CP2_ERR_INVALID; }
+  if (n == 0) return CP2_OK;
   if (c.n_samples && c.n_cells < 2) return CP2_ERR_INVALID;                        // extractLowBits asserts k > 0, types/bn254.nim:48
+  if (!is_pow2(c.n_cells)) return CP2_ERR_INVALID;                                 // sample/bn254.nim:19-20
   const uint64_t S = mds->units_per_slot, P = c.n_cells / S, cpb = c.block_size / c.cell_size;
-  const size_t ns = c.n_samples, md = (size_t)c.max_depth, cs = c.cell_size;
+  const size_t ns = c.n_samples, md = (size_t)c.max_depth, cs = c.cell_size, total = n * ns;
   size_t levels = 0;
   while (((uint64_t)1 << levels) < S) ++levels;
   const size_t depth_unit = (layer_sizes_of(cpb).size() - 1) + (layer_sizes_of(P / cpb).size() - 1);
   if (depth_unit + levels > md) return CP2_ERR_INVALID;                            // padMerkleProof assert, types.nim:29
   if (mds->dsizes.size() - 1 > (size_t)c.max_log2_nslots) return CP2_ERR_INVALID;  // the same for slotProof
   cp2_ctx* ctx0 = mds->shards[0].units->ctx;
-  std::vector<uint64_t> idx(ns);
-  if (ns) CP2_TRY(cp2_cell_indices(ctx0, entropy, mds->slot_root(slot), c.n_cells, ns, idx.data()));   // sample/bn254.nim:16-27
-  std::vector<uint8_t> paths(ns * md * 32, 0), leaves(ns * 32), cells(ns * cs);
-  // samples grouped by the unit that holds them
-  std::vector<std::vector<size_t>> by_unit(S);
-  for (size_t i = 0; i < ns; ++i) by_unit[idx[i] / P].push_back(i);
-  for (uint64_t q = 0; q < S; ++q) {
-    if (by_unit[q].empty()) continue;
-    auto* sh = mds->owner(slot * S + q);
-    if (!sh) return CP2_ERR_INVALID;
-    const size_t k = by_unit[q].size();
-    std::vector<uint64_t> local(k);
-    for (size_t j = 0; j < k; ++j) local[j] = idx[by_unit[q][j]] % P;
-    std::vector<uint8_t> up(k * depth_unit * 32), lf(k * 32);
-    int st = cp2_slot_trees_paths(sh->units, (size_t)(slot * S + q - sh->first), local.data(), k, depth_unit, up.data(), lf.data());
-    if (st != CP2_OK) { m->err = cp2_last_error(sh->units->ctx); return st; }
-    for (size_t j = 0; j < k; ++j) {
-      const size_t i = by_unit[q][j];
-      std::memcpy(&paths[i * md * 32], &up[j * depth_unit * 32], depth_unit * 32);                        // merkleProof inside the unit
-      for (size_t lv = 0; lv < levels; ++lv) {                                                            // ... and above it
-        const uint64_t sib = (q >> lv) ^ 1;
-        std::memcpy(&paths[(i * md + depth_unit + lv) * 32], &mds->upper[(mds->upper_off[lv] + slot * (S >> lv) + sib) * 32], 32);
+  // (the entropy is a field element, types/bn254.nim:21: the sponge takes any 32 bytes mod r, and cp2_proof_input_create stores and
+  // prints the canonical residue -- so what is hashed and what is printed agree without reducing it here)
+  const uint8_t* entropy = entropy_in;
+  // ---- cellIndices for all pairs at once
+  std::vector<uint64_t> idx(total);
+  if (total) {
+    DeviceRestore restore;
+    std::vector<uint8_t> felts(total * 96, 0), dig(total * 32);
+    for (size_t i = 0; i < n; ++i)
+      for (size_t k = 0; k < ns; ++k) {
+        uint8_t* f = &felts[(i * ns + k) * 96];
+        std::memcpy(f, entropy, 32);
+        std::memcpy(f + 32, mds->slot_root(slots[i]), 32);
+        const uint64_t counter = k + 1;
+        std::memcpy(f + 64, &counter, 8);
       }
-      std::memcpy(&leaves[i * 32], &lf[j * 32], 32);
+    int st = cp2_sponge2_felts_batch(ctx0, felts.data(), 3, total, dig.data());
+    if (st != CP2_OK) { m->err = cp2_last_error(ctx0); return st; }
+    for (size_t p = 0; p < total; ++p) {
+      uint64_t lo;
+      std::memcpy(&lo, &dig[32 * p], 8);                                            // extractLowBits, types/bn254.nim:47-59
+      idx[p] = lo & (c.n_cells - 1);
     }
   }
-  // the sampled cells (slot.nim:57-73)
-  if (c.file_base) {
-    const std::string fname = slot_file_name(mds->file_base, slot);
-    const int fd = open(fname.c_str(), O_RDONLY);
-    if (fd < 0) { m->err = "cannot open " + fname; return CP2_ERR_IO; }
-    for (size_t i = 0; i < ns; ++i) read_file_cell(fd, cs, idx[i], &cells[i * cs]);
-    close(fd);
-  } else if (ns) {   // genFakeCell for the sampled indices in one launch (the list form of the generator), one download
+  std::vector<uint8_t> paths(total * md * 32, 0), leaves(total * 32), cells(total * cs);
+  // ---- the bottom of every path from the device that holds the unit: one gather per device, devices in parallel
+  const size_t world = mds->shards.size();
+  std::vector<std::vector<size_t>> by_shard(world);                                 // pair indices per owning shard
+  for (size_t p = 0; p < total; ++p) {
+    const uint64_t unit = slots[p / ns] * S + idx[p] / P;
+    auto* sh = mds->owner(unit);
+    if (!sh) return CP2_ERR_INVALID;
+    by_shard[(size_t)(sh - mds->shards.data())].push_back(p);
+  }
+  std::vector<std::string> errs(world);
+  int st = for_each_shard(world, [&](size_t w) -> int {
+    const auto& mine = by_shard[w];
+    if (mine.empty()) return CP2_OK;
+    auto& sh = mds->shards[w];
+    const size_t k = mine.size();
+    std::vector<uint64_t> unit_local(k), cell_local(k);
+    for (size_t j = 0; j < k; ++j) {
+      const size_t p = mine[j];
+      unit_local[j] = slots[p / ns] * S + idx[p] / P - sh.first;
+      cell_local[j] = idx[p] % P;
+    }
+    std::vector<uint8_t> up(k * depth_unit * 32), lf(k * 32);
+    int r = trees_paths_multi(sh.units, unit_local.data(), cell_local.data(), k, depth_unit, up.data(), lf.data());
+    if (r != CP2_OK) { errs[w] = cp2_last_error(sh.units->ctx); return r; }
+    for (size_t j = 0; j < k; ++j) {
+      const size_t p = mine[j];
+      std::memcpy(&paths[p * md * 32], &up[j * depth_unit * 32], depth_unit * 32);                          // merkleProof inside the unit
+      std::memcpy(&leaves[p * 32], &lf[j * 32], 32);
+    }
+    return CP2_OK;
+  });
+  if (st != CP2_OK) {
+    for (auto& e : errs) if (!e.empty()) { m->err = e; break; }
+    return st;
+  }
+  for (size_t p = 0; p < total; ++p) {                                              // ... and above the unit, from the upper layers
+    const uint64_t slot = slots[p / ns], q = idx[p] / P;
+    for (size_t lv = 0; lv < levels; ++lv) {
+      const uint64_t sib = (q >> lv) ^ 1;
+      std::memcpy(&paths[(p * md + depth_unit + lv) * 32], &mds->upper[(mds->upper_off[lv] + slot * (S >> lv) + sib) * 32], 32);
+    }
+  }
+  // ---- the sampled cells (slot.nim:57-73)
+  if (c.file_base && total) {
+    const int nt = (int)std::min<size_t>((size_t)std::max(1, threads), n);
+    std::vector<std::string> failed(nt);
+    auto work = [&](int t) {
+      for (size_t i = (size_t)t; i < n; i += (size_t)nt) {
+        const std::string fname = slot_file_name(mds->file_base, slots[i]);
+        const int fd = open(fname.c_str(), O_RDONLY);
+        if (fd < 0) { failed[t] = fname; return; }
+        for (size_t k = 0; k < ns; ++k) read_file_cell(fd, cs, idx[i * ns + k], &cells[(i * ns + k) * cs]);
+        close(fd);
+      }
+    };
+    {
+      Workers pool(nt > 1 ? nt - 1 : 1);
+      for (int t = 1; t < nt; ++t) pool.submit([&work, t] { work(t); });
+      work(0);
+      pool.wait_idle();
+    }
+    for (auto& f : failed) if (!f.empty()) { m->err = "cannot open " + f; return CP2_ERR_IO; }
+  } else if (total) {   // genFakeCell for every sampled index in one launch: the list form over "global cells" slot * nCells + cell, seed of slot 0
     DeviceRestore restore;
     CP2_HIP(ctx0, hipSetDevice(ctx0->device));
+    std::vector<uint64_t> list(total);
+    for (size_t p = 0; p < total; ++p) list[p] = slots[p / ns] * c.n_cells + idx[p];
     DevBuf d_idx, d_cells;
-    CP2_TRY(d_idx.scratch(ctx0, ns * 8));
-    CP2_TRY(d_cells.scratch(ctx0, ns * cs));
-    CP2_HIP(ctx0, hipMemcpyAsync(d_idx.p, idx.data(), ns * 8, hipMemcpyHostToDevice, ctx0->stream));
-    CP2_HIP(ctx0, cp2k::launch_gen_fake_cells(cp2_slot_seed(c.seed, slot), 0, 0, static_cast<const uint64_t*>(d_idx.p), ns, cs, d_cells.p, ctx0->stream));
-    CP2_HIP(ctx0, hipMemcpyAsync(cells.data(), d_cells.p, ns * cs, hipMemcpyDeviceToHost, ctx0->stream));
+    CP2_TRY(d_idx.scratch(ctx0, total * 8));
+    CP2_TRY(d_cells.scratch(ctx0, total * cs));
+    CP2_HIP(ctx0, hipMemcpyAsync(d_idx.p, list.data(), total * 8, hipMemcpyHostToDevice, ctx0->stream));
+    CP2_HIP(ctx0, cp2k::launch_gen_fake_cells(cp2_slot_seed(c.seed, 0), c.n_cells, 0, static_cast<const uint64_t*>(d_idx.p), total, cs, d_cells.p, ctx0->stream));
+    CP2_HIP(ctx0, hipMemcpyAsync(cells.data(), d_cells.p, total * cs, hipMemcpyDeviceToHost, ctx0->stream));
     CP2_HIP(ctx0, hipStreamSynchronize(ctx0->stream));
   }
-  // slotProof = padMerkleProof(merkleProof(dsetTree, slotIdx), maxLog2NSlots), gen_input/bn254.nim:51,72
-  std::vector<uint8_t> proof((size_t)c.max_log2_nslots * 32, 0);
-  {
-    size_t k = slot, mm = c.n_slots, off = 0;
-    for (size_t i = 0; i + 1 < mds->dsizes.size(); ++i) {
+  // ---- slotProof = padMerkleProof(merkleProof(dsetTree, slotIdx), maxLog2NSlots), gen_input/bn254.nim:51,72; the objects
+  std::vector<uint8_t> proof((size_t)c.max_log2_nslots * 32);
+  for (size_t i = 0; i < n; ++i) {
+    std::fill(proof.begin(), proof.end(), 0);
+    size_t k = slots[i], mm = c.n_slots, off = 0;
+    for (size_t l = 0; l + 1 < mds->dsizes.size(); ++l) {
       const size_t j = k ^ 1;
-      if (j < mm) std::memcpy(&proof[i * 32], &mds->dlayers[(off + j) * 32], 32);
-      off += mds->dsizes[i];
+      if (j < mm) std::memcpy(&proof[l * 32], &mds->dlayers[(off + j) * 32], 32);
+      off += mds->dsizes[l];
       k >>= 1;
       mm = (mm + 1) >> 1;
     }
+    int r = cp2_proof_input_create(&c, slots[i], &mds->dlayers[mds->dlayers.size() - 32], entropy, mds->slot_root(slots[i]), proof.data(), ns, &idx[i * ns],
+                                   &cells[i * ns * cs], &paths[i * ns * md * 32], &leaves[i * ns * 32], out + i);
+    if (r != CP2_OK) {
+      for (size_t j = 0; j < i; ++j) { cp2_proof_input_free(out[j]); out[j] = nullptr; }
+      return r;
+    }
   }
-  return cp2_proof_input_create(&c, slot, &mds->dlayers[mds->dlayers.size() - 32], entropy, mds->slot_root(slot), proof.data(), ns, idx.data(),
-                                cells.data(), paths.data(), leaves.data(), out);
+  return CP2_OK;
+}
+
+// the texts (and, with a directory, the files) of many slots of a dataset cut by units: batches of `batch` slots through
+// units_proof_inputs, formatted on `threads` host threads (cp2_proof_inputs_write_json_batch); keep != nullptr: the texts are kept
+int units_export(cp2_multi_dataset* mds, const uint64_t* slot_idx, size_t n, const uint8_t entropy[32], const char* dir, int threads, size_t batch,
+                 uint64_t* total_bytes, std::vector<std::string>* keep) {
+  if (batch == 0) batch = 256;
+  if (threads < 1) threads = 1;
+  uint64_t tot = 0;
+  for (size_t b0 = 0; b0 < n; b0 += batch) {
+    const size_t k = std::min(batch, n - b0);
+    std::vector<cp2_proof_input*> ps(k, nullptr);
+    struct Release { std::vector<cp2_proof_input*>& v; ~Release() { for (auto* p : v) cp2_proof_input_free(p); } } rel{ps};
+    CP2_TRY(units_proof_inputs(mds, slot_idx + b0, k, entropy, threads, ps.data()));
+    if (keep) {
+      for (size_t i = 0; i < k; ++i) {
+        char* text = nullptr;
+        size_t len = 0;
+        CP2_TRY(cp2_proof_input_json(ps[i], &text, &len));
+        (*keep)[slot_idx[b0 + i]].assign(text, len);
+        cp2_free_buffer(text);
+        tot += len;
+      }
+      continue;
+    }
+    std::vector<std::string> names;
+    std::vector<const char*> paths;
+    if (dir) {
+      for (size_t i = 0; i < k; ++i) names.push_back(std::string(dir) + "/input_" + std::to_string(slot_idx[b0 + i]) + ".json");
+      for (auto& s2 : names) paths.push_back(s2.c_str());
+    }
+    uint64_t got = 0;
+    int st = cp2_proof_inputs_write_json_batch(ps.data(), k, dir ? paths.data() : nullptr, threads, &got);
+    if (st != CP2_OK) { if (st == CP2_ERR_IO) mds->m->err = std::string("cannot write into ") + (dir ? dir : "?"); return st; }
+    tot += got;
+  }
+  if (total_bytes) *total_bytes = tot;
+  return CP2_OK;
 }
 
 }  // namespace
@@ -953,7 +1076,7 @@ extern "C" int cp2_multi_dataset_slot_roots(cp2_multi_dataset* mds, uint8_t* out
 extern "C" int cp2_multi_proof_input_generate(cp2_multi_dataset* mds, uint64_t slot_idx, const uint8_t entropy[32], cp2_proof_input** out) try {
   if (!mds || !out || !entropy) return CP2_ERR_INVALID;
   *out = nullptr;
-  if (mds->by_units()) return units_proof_input(mds, slot_idx, entropy, out);
+  if (mds->by_units()) return units_proof_inputs(mds, &slot_idx, 1, entropy, 1, out);
   auto* s = mds->owner(slot_idx);
   if (!s) return CP2_ERR_INVALID;                                  // slot index out of range
   int st = cp2_proof_input_generate(s->ds, slot_idx, entropy, out);
@@ -969,27 +1092,7 @@ extern "C" int cp2_multi_proof_input_generate(cp2_multi_dataset* mds, uint64_t s
 extern "C" int cp2_multi_dataset_export_proof_inputs(cp2_multi_dataset* mds, const uint64_t* slot_idx, size_t n, const uint8_t entropy[32],
                                                      const char* dir, int threads, size_t batch, uint64_t* total_bytes) try {
   if (!mds || !entropy || (n && !slot_idx)) return CP2_ERR_INVALID;
-  if (mds->by_units()) {                                           // few, large slots: one proof input after the other
-    uint64_t tot = 0;
-    for (size_t i = 0; i < n; ++i) {
-      cp2_proof_input* p = nullptr;
-      CP2_TRY(units_proof_input(mds, slot_idx[i], entropy, &p));
-      std::unique_ptr<cp2_proof_input, void (*)(cp2_proof_input*)> guard(p, cp2_proof_input_free);
-      char* text = nullptr;
-      size_t len = 0;
-      CP2_TRY(cp2_proof_input_json(p, &text, &len));                 // formatted once: counted, and written when a directory is given
-      std::unique_ptr<char, void (*)(void*)> text_guard(text, cp2_free_buffer);
-      if (dir) {
-        const std::string name = std::string(dir) + "/input_" + std::to_string(slot_idx[i]) + ".json";
-        FILE* f = std::fopen(name.c_str(), "wb");
-        const bool ok = f && std::fwrite(text, 1, len, f) == len;
-        if ((f && std::fclose(f) != 0) || !ok) { mds->m->err = "cannot write " + name; return CP2_ERR_IO; }
-      }
-      tot += len;
-    }
-    if (total_bytes) *total_bytes = tot;
-    return CP2_OK;
-  }
+  if (mds->by_units()) return units_export(mds, slot_idx, n, entropy, dir, threads, batch, total_bytes, nullptr);   // batched per device, devices in parallel
   const size_t world = mds->shards.size();
   std::vector<std::vector<uint64_t>> part(world);
   for (size_t i = 0; i < n; ++i) {
@@ -1014,7 +1117,21 @@ extern "C" int cp2_multi_dataset_export_proof_inputs(cp2_multi_dataset* mds, con
 }
 
 extern "C" int cp2_multi_dataset_export_streamed(cp2_multi_dataset* mds, const char* dir, int threads, uint64_t* total_bytes) try {
-  if (!mds || mds->by_units()) return CP2_ERR_INVALID;
+  if (!mds) return CP2_ERR_INVALID;
+  if (mds->by_units()) {                                             // two-phase streamed build: the texts are there
+    if (!mds->prepared) return CP2_ERR_INVALID;
+    uint64_t tot = 0;
+    for (size_t s = 0; s < mds->texts.size(); ++s) {
+      tot += mds->texts[s].size();
+      if (!dir) continue;
+      const std::string name = std::string(dir) + "/input_" + std::to_string(s) + ".json";
+      FILE* f = std::fopen(name.c_str(), "wb");
+      const bool ok = f && std::fwrite(mds->texts[s].data(), 1, mds->texts[s].size(), f) == mds->texts[s].size();
+      if ((f && std::fclose(f) != 0) || !ok) { mds->m->err = "cannot write " + name; return CP2_ERR_IO; }
+    }
+    if (total_bytes) *total_bytes = tot;
+    return CP2_OK;
+  }
   const size_t world = mds->shards.size();
   const int per = std::max(1, threads / (int)world);
   std::vector<uint64_t> bytes(world, 0);
@@ -1030,7 +1147,18 @@ extern "C" int cp2_multi_dataset_export_streamed(cp2_multi_dataset* mds, const c
 }
 
 extern "C" int cp2_multi_dataset_streamed_json(cp2_multi_dataset* mds, uint64_t slot_idx, char** text, size_t* len) try {
-  if (!mds || !text || mds->by_units()) return CP2_ERR_INVALID;
+  if (!mds || !text) return CP2_ERR_INVALID;
+  if (mds->by_units()) {
+    if (!mds->prepared || slot_idx >= mds->texts.size()) return CP2_ERR_INVALID;
+    const std::string& t = mds->texts[slot_idx];
+    char* buf = (char*)std::malloc(t.size() + 1);
+    if (!buf) return CP2_ERR_ALLOC;
+    std::memcpy(buf, t.data(), t.size());
+    buf[t.size()] = 0;
+    *text = buf;
+    if (len) *len = t.size();
+    return CP2_OK;
+  }
   auto* s = mds->owner(slot_idx);
   if (!s) return CP2_ERR_INVALID;
   return cp2_dataset_streamed_json(s->ds, slot_idx, text, len);

@@ -405,8 +405,9 @@ extern "C" int cp2_dataset_build_cached(cp2_ctx* ctx, const cp2_config* cfg, uin
       (void)step_down(ctx, &mode, "cached build (loading the tree cache)");   // the nodes do not fit after all: what is smaller may
     }
   }
+  auto size_rank = [](int md) { return md == 1 ? 2 : (md == 2 ? 1 : 0); };   // every node > compact > roots only
   for (int m2 : {2, 0}) {
-    if (m2 > mode || (m2 != mode && !automatic)) continue;       // never a representation larger than what fits; a named mode is taken literally
+    if (size_rank(m2) > size_rank(mode) || (m2 != mode && !automatic)) continue;   // never a representation larger than what fits; a named mode is taken literally
     for (const char* path : {cache_path, beside.c_str()}) {
       cp2_dataset* ds = nullptr;
       const int lst = load_kept_dataset(ctx, cfg, first_slot, n_local, m2, path, &ds);

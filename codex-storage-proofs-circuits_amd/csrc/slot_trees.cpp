@@ -1064,9 +1064,11 @@ void cp2i::path_rows(const cp2_slot_trees* t, size_t slot, uint64_t cell, size_t
   for (; d < max_depth; ++d) rows[d] = NO_ROW;                                                  // padMerkleProof
 }
 
-extern "C" int cp2_slot_trees_paths(cp2_slot_trees* t, size_t slot, const uint64_t* cell_idx, size_t n, size_t max_depth,
-                                    uint8_t* out, uint8_t* leaf_hashes) try {
-  if (!t || (n && (!cell_idx || !out)) || slot >= t->n_slots) return CP2_ERR_INVALID;
+// merged paths of n (slot-in-batch, cell) pairs in ONE gather: what a device contributes to the proof inputs of many slots of a
+// dataset cut by units (multi_gpu.cpp), and, with a constant slot, cp2_slot_trees_paths
+int cp2i::trees_paths_multi(cp2_slot_trees* t, const uint64_t* slot_idx, const uint64_t* cell_idx, size_t n, size_t max_depth, uint8_t* out,
+                            uint8_t* leaf_hashes) {
+  if (!t || (n && (!slot_idx || !cell_idx || !out))) return CP2_ERR_INVALID;
   if (cp2_slot_trees_depth(t) > max_depth) return CP2_ERR_INVALID;     // types.nim:29 assert(pad >= 0)
   if (n == 0) return CP2_OK;
   cp2_ctx* ctx = t->ctx;
@@ -1074,9 +1076,9 @@ extern "C" int cp2_slot_trees_paths(cp2_slot_trees* t, size_t slot, const uint64
   const size_t per = max_depth + 1;                                     // + the leaf itself
   std::vector<uint64_t> rows(n * per);
   for (size_t i = 0; i < n; ++i) {
-    if (cell_idx[i] >= t->n_cells) return CP2_ERR_INVALID;              // merkle.nim:27 assert
-    path_rows(t, slot, cell_idx[i], max_depth, &rows[i * per]);
-    rows[i * per + max_depth] = slot * t->n_cells + cell_idx[i];
+    if (slot_idx[i] >= t->n_slots || cell_idx[i] >= t->n_cells) return CP2_ERR_INVALID;   // merkle.nim:27 assert
+    path_rows(t, slot_idx[i], cell_idx[i], max_depth, &rows[i * per]);
+    rows[i * per + max_depth] = slot_idx[i] * t->n_cells + cell_idx[i];
   }
   DevBuf d_rows, d_out;
   CP2_TRY(d_rows.scratch(ctx, rows.size() * 8));
@@ -1091,6 +1093,13 @@ extern "C" int cp2_slot_trees_paths(cp2_slot_trees* t, size_t slot, const uint64
     if (leaf_hashes) std::memcpy(leaf_hashes + i * 32, &tmp[(i * per + max_depth) * 32], 32);
   }
   return CP2_OK;
+}
+
+extern "C" int cp2_slot_trees_paths(cp2_slot_trees* t, size_t slot, const uint64_t* cell_idx, size_t n, size_t max_depth,
+                                    uint8_t* out, uint8_t* leaf_hashes) try {
+  if (!t || (n && (!cell_idx || !out)) || slot >= t->n_slots) return CP2_ERR_INVALID;
+  const std::vector<uint64_t> slots(n, (uint64_t)slot);
+  return trees_paths_multi(t, slots.data(), cell_idx, n, max_depth, out, leaf_hashes);
 } catch (const std::bad_alloc&) {
   return CP2_ERR_ALLOC;   // nothing may unwind across the C ABI
 } catch (...) {

@@ -65,6 +65,8 @@ size_t trees_node_bytes(size_t n_slots, size_t cell_size, size_t block_size, siz
 void trees_geom(const cp2_slot_trees* t, cp2k::TreeGeom* g);
 // node-row indices of the merged path of `cell` in slot `slot` (host twin of k_sample_paths' row arithmetic)
 void path_rows(const cp2_slot_trees* t, size_t slot, uint64_t cell, size_t max_depth, uint64_t* rows);
+// merged paths (padded to max_depth, + leaf hashes) of n (slot-in-batch, cell) pairs of a batch in one gather
+int trees_paths_multi(cp2_slot_trees* t, const uint64_t* slot_idx, const uint64_t* cell_idx, size_t n, size_t max_depth, uint8_t* out, uint8_t* leaf_hashes);
 // one cell of a slot file, zero-filled past EOF (slot.nim:57-68); fd < 0: all zeros
 void read_file_cell(int fd, size_t cell_size, uint64_t cell, uint8_t* out);
 std::string slot_file_name(const std::string& base, uint64_t slot);

@@ -82,6 +82,7 @@ proc cp2_multi_dataset_build(m: Cp2Multi, cfg: ptr Cp2Config, ds: ptr Cp2MultiDa
 proc cp2_multi_dataset_build_cached(m: Cp2Multi, cfg: ptr Cp2Config, cachePath: cstring, ds: ptr Cp2MultiDataset): cint {.importc.}
 proc cp2_multi_dataset_build_streamed(m: Cp2Multi, cfg: ptr Cp2Config, entropy: ptr byte, threads: cint, groupSlots: csize_t,
                                       ds: ptr Cp2MultiDataset): cint {.importc.}
+proc cp2_check_environment(msg: cstring, msgLen: csize_t): cint {.importc.}
 proc cp2_multi_dataset_free(ds: Cp2MultiDataset) {.importc.}
 proc cp2_multi_dataset_shards(ds: Cp2MultiDataset): cint {.importc.}
 proc cp2_multi_proof_input_generate(ds: Cp2MultiDataset, slotIdx: uint64, entropy: ptr byte, p: ptr Cp2ProofInput): cint {.importc.}
@@ -91,12 +92,16 @@ proc cp2_multi_dataset_export_streamed(ds: Cp2MultiDataset, dir: cstring, thread
 var gMulti: Cp2Multi
 
 proc multi(): Cp2Multi =
-  ## one engine per process over EVERY visible GPU (the reference is single threaded, cli.nim:208-237): the seam calls run on
-  ## the first device's context, generateProofInput cuts the dataset's slots over all of them.  The environment variable
-  ## CODEX_P2_GPUS ("<count>" or an index list) restricts the devices; nothing in cli.nim changes.
+  ## one engine per process (the reference is single threaded, cli.nim:208-237): the seam calls run on the first device's
+  ## context, generateProofInput cuts the dataset's slots over all the engine's devices.  The environment variable
+  ## CODEX_P2_GPUS ("all", "<count>" or an index list) names the devices -- unset: ONE device, several are opt-in (INTEGRATION.md
+  ## section 1); nothing in cli.nim changes.
   if pointer(gMulti) == nil:
     let st = cp2_multi_init(nil, 0, addr gMulti)
-    if st != 0: raiseAssert("cp2_multi_init: " & $cp2_strerror(st))
+    if st != 0:
+      var why: array[512, char]            # a CODEX_P2_* variable that does not hold what it takes is named, not guessed at
+      discard cp2_check_environment(cast[cstring](addr why[0]), csize_t(len(why)))
+      raiseAssert("cp2_multi_init: " & $cp2_strerror(st) & " " & $cast[cstring](addr why[0]))
   gMulti
 
 proc ctx(): Cp2Ctx =

@@ -364,8 +364,12 @@ int cp2_write_circom_main(const cp2_config* cfg, const char* path);
  *     more than 6 % above its share (11 slots on 8 GPUs: 2 against 1.375; ONE 128 GiB slot on 8 GPUs), every slot is cut into
  *     S = 2^s units of nCells / S cells (cp2_slot_trees_build_*_units), the nSlots x S units are dealt out contiguously, the
  *     unit roots exchanged, and the log2 S upper layers of every slot tree plus the dataset tree built once; a proof input then
- *     takes the bottom of each path from whichever device holds the sampled cell.  cp2_multi_dataset_build and _build_cached
- *     (streamed builds keep whole slots); cp2_multi_set_split / CODEX_P2_SPLIT override (1 = whole slots only). */
+ *     takes the bottom of each path from whichever device holds the sampled cell; many proof inputs at once
+ *     (cp2_multi_dataset_export_proof_inputs) take ONE batched gather per device, the devices in parallel.  Every kind of build
+ *     follows this plan.  A STREAMED build cut by units is two-phase -- sampling needs the slot root, which exists only after the
+ *     exchange of unit roots, so nothing of a proof input can be made while later units hash: the balanced unit build, the
+ *     exchange, then every slot's input.json from the devices that hold its units, kept as text for _export_streamed /
+ *     _streamed_json.  cp2_multi_set_split / CODEX_P2_SPLIT override (1 = whole slots only: the overlapped per-slot pipeline). */
 typedef struct cp2_multi cp2_multi;
 typedef struct cp2_multi_dataset cp2_multi_dataset;
 enum { CP2_GATHER_AUTO = 0, CP2_GATHER_RCCL = 1, CP2_GATHER_HOST = 2, CP2_GATHER_COPY = 3 };
@@ -400,7 +404,7 @@ void cp2_shard_range(uint64_t n_items, int rank, int world, uint64_t* first, uin
 int cp2_multi_plan(const cp2_config* cfg, int n_devices, uint64_t min_cells_per_device, int64_t units_per_slot, int* n_shards,
                    uint64_t* units_per_slot_out);
 /* cp2_dataset_build / _build_cached / _build_streamed for ALL cfg->n_slots slots over the devices of `m`, including the
- * exchange and the dataset tree on every device.  Cached: shard i of n uses "<cache_path>.shard<i>of<n>" (one shard: the path
+ * exchange (verified and bounded, above) and the dataset tree on every device.  Cached: shard i of n uses "<cache_path>.shard<i>of<n>" (one shard: the path
  * itself; cut by S units per slot: "<cache_path>.units<S>.shard<i>of<n>", the unit trees of that shard).  Streamed: `threads` formatting threads in total, divided over the shards. */
 int cp2_multi_dataset_build(cp2_multi* m, const cp2_config* cfg, cp2_multi_dataset** out);
 int cp2_multi_dataset_build_cached(cp2_multi* m, const cp2_config* cfg, const char* cache_path, cp2_multi_dataset** out);

@@ -208,8 +208,21 @@ def test_multi_streamed_and_batched_exports_equal_the_object_path(pkg, oracle, t
         assert want[s] == P.export_json(expected_proof_input_fast(C, P, c, s, entropy, threads=4))
     m = pkg.Multi([0, 0, 0])
     m.set_policy(pkg.GATHER_AUTO, 1)
+    # round 5: a streamed build follows the same plan as a plain one -- 7 slots over 3 contexts are cut by units (8 per slot), built
+    # balanced, exchanged, and every input.json made from the devices that hold the units (two-phase); the texts are the object path's
+    su = m.dataset_streamed(cfg, entropy, threads=4, group_slots=1)
+    assert su.units_per_slot == 8 and [(f, k) for _, f, k in su.shards()] == [(0, 19), (19, 19), (38, 18)]
+    out0 = tmp_path / "streamed_units"
+    out0.mkdir()
+    assert su.export_streamed(str(out0), threads=3) == sum(len(t) for t in want.values())
+    for s in range(7):
+        assert su.streamed_json(s) == want[s] and open(out0 / ("input_%d.json" % s)).read() == want[s]
+    assert su.proof_input(5, 99).json() == ref.proof_input(5, 99).json()          # still a normal dataset for other entropies
+    su.free()
+    m.set_split(1)                                                                 # whole slots by request: the overlapped per-slot pipeline on every shard
     sd = m.dataset_streamed(cfg, entropy, threads=4, group_slots=1)
     assert [(f, k) for _, f, k in sd.shards()] == [(0, 3), (3, 2), (5, 2)]
+    m.set_split(0)
     out1, out2 = tmp_path / "streamed", tmp_path / "batched"
     out1.mkdir()
     out2.mkdir()
@@ -763,7 +776,7 @@ def _big(golden):
         pytest.skip("tests/golden/bigslots.json not generated (tests/golden/make_bigslots_golden.py)")
 
 
-def test_bigslots_by_units_over_three_contexts_and_one_8gib_slot_over_two(pkg, golden):
+def test_bigslots_by_units_over_three_contexts_and_one_8gib_slot_over_two(pkg, golden, tmp_path):
     """8 slots of 8 GiB over three contexts: whole slots would be 3 / 3 / 2, so every slot is cut into 4 units of 2^20 cells
     (32 units: 11 / 11 / 10) and slots 2 and 5 are shared by two contexts each; then ONE 8 GiB slot over two contexts (config 3's
     slot, two units of 4 GiB).  Slot roots, dataset root and input.json against the oracle-only fixtures."""
@@ -776,7 +789,26 @@ def test_bigslots_by_units_over_three_contexts_and_one_8gib_slot_over_two(pkg, g
     for slot in (0, 2, 5, 7):
         text = ds.proof_input(slot, g["entropy"]).json()
         assert tsha(text) == g["inputs"][str(slot)]["json_sha256"] and len(text) == g["inputs"][str(slot)]["json_bytes"], slot
+    # round 5: ALL eight at once -- the touched units grouped per device, one batched gather per device, the devices in parallel,
+    # the texts formatted on host threads: every file byte-identical to the oracle-only fixture (and so to the per-slot path above)
+    out = tmp_path / "batched"
+    out.mkdir()
+    total = ds.export_proof_inputs(list(range(8)), g["entropy"], str(out), threads=_threads(), batch=3)
+    assert total == sum(g["inputs"][str(s_)]["json_bytes"] for s_ in range(8))
+    for s_ in range(8):
+        assert tsha(open(out / ("input_%d.json" % s_)).read()) == g["inputs"][str(s_)]["json_sha256"], s_
     ds.free()
+    # ... and the STREAMED kind follows the same plan (cp2_multi_plan is the plan of every kind): cut by units, built balanced
+    # (11 / 11 / 10 units instead of 3 / 3 / 2 slots), exchanged, then every input.json from the devices that hold the units
+    assert pkg.multi_plan(pkg.make_config(**c), 3) == (3, 4)
+    su = m.dataset_streamed(pkg.make_config(**c), g["entropy"], threads=_threads())
+    assert su.units_per_slot == 4 and [k for _, _, k in su.shards()] == [11, 11, 10] and hexroot(su.root()) == g["dataset_root_hex"]
+    out2 = tmp_path / "streamed"
+    out2.mkdir()
+    assert su.export_streamed(str(out2), threads=_threads()) == total
+    for s_ in range(8):
+        assert tsha(open(out2 / ("input_%d.json" % s_)).read()) == g["inputs"][str(s_)]["json_sha256"] == tsha(su.streamed_json(s_)), s_
+    su.free()
     m.close()
     m = pkg.Multi([0, 0])
     ds = m.dataset(pkg.make_config(**dict(c, nSlots=1, maxLog2NSlots=1)))

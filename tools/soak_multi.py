@@ -14,7 +14,7 @@ from oracle_helpers import expected_proof_input_fast
 pkg = g.load_package()
 C, P = g.load_oracle()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
-UNITS = len(sys.argv) > 3 and sys.argv[3] == "units"          # third argument "units": plain and cached builds, every slot cut into 2 / 4 / 8 units
+UNITS = len(sys.argv) > 3 and sys.argv[3] == "units"          # third argument "units": every slot cut into 2 / 4 / 8 units (plain, streamed and cached builds)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20261004)
 single = pkg.Context(0)
 handles = {n: pkg.Multi([0] * n) for n in (2, 3, 4)}          # long-lived handles: contexts and their scratch pools are reused
@@ -57,7 +57,7 @@ while time.time() - t0 < budget:
         del cc["seed"]
         cc["file"] = base
     cfg = pkg.make_config(**cc)
-    kind = int(rng.choice([0, 2])) if UNITS else int(rng.integers(0, 3))   # plain / streamed / cached (units: plain or cached -- streamed builds keep whole slots)
+    kind = int(rng.integers(0, 3))                             # plain / streamed / cached (round 5: a streamed build cut by units is two-phase, same plan as the others)
     threads = int(rng.choice([1, 3, 8]))
     if kind == 0:
         ds = m.dataset(cfg)
@@ -72,7 +72,7 @@ while time.time() - t0 < budget:
     S = ds.units_per_slot
     by_units += S > 1
     want_world = min(n_ctx, n_slots * S, max(1, -(-n_slots * nc // max(1, min_cells))))
-    if (kind == 1 and S != 1) or len(shards) != want_world or [(f, k) for _, f, k in shards] != [pkg.shard_range(n_slots * S, r, len(shards)) for r in range(len(shards))]:
+    if len(shards) != want_world or [(f, k) for _, f, k in shards] != [pkg.shard_range(n_slots * S, r, len(shards)) for r in range(len(shards))]:
         bad += 1
         print("WRONG SPLIT", c, n_ctx, min_cells, split, S, shards, flush=True)
     # every slot root and the dataset root against the C oracle (as EVERY shard's device computed the latter)
@@ -103,6 +103,15 @@ while time.time() - t0 < budget:
         if t_edge != P.export_json(expected_proof_input_fast(C, P, c, edge, entropy, threads=8, slot_roots=want_roots)):
             bad += 1
             print("MISMATCH input.json vs oracle", c, "slot", edge, flush=True)
+    if it % 4 == 0:                                            # the batched export (by units: one gather per device, devices in parallel) against the per-slot path
+        exp = os.path.join(tmp, "exp%d" % it)
+        os.mkdir(exp)
+        pick = sorted(set(int(x) for x in rng.integers(0, n_slots, size=min(n_slots, 5))))
+        nbytes = ds.export_proof_inputs(pick, entropy, exp, threads=threads, batch=int(rng.choice([0, 1, 2])))
+        texts = [open(os.path.join(exp, "input_%d.json" % s_)).read() for s_ in pick]
+        if nbytes != sum(len(t) for t in texts) or any(t != ds.proof_input(s_, entropy).json() for s_, t in zip(pick, texts)):
+            bad += 1
+            print("MISMATCH batched export vs per-slot proof inputs", c, pick, flush=True)
     ref = single.dataset(cfg)
     if t_rand != ref.proof_input(s_rand, entropy).json():
         bad += 1
