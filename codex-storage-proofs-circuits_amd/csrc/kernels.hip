@@ -146,11 +146,23 @@ __global__ void __launch_bounds__(TPB) k_sponge2_felts(const uint4* __restrict__
 // line of each of its 64 cells into a per-cell LDS ring: lane-linear dword loads, 32 consecutive lanes read
 // one full line (perfectly coalesced), and the ring row stride of 49 dwords is odd, so the per-lane reads
 // are bank-conflict free.  The sponge consumes 62 bytes per permutation, the producer adds 128 per stage,
-// so at most 60 bytes wait in the ring when the next line lands: 188 <= 192 ring bytes.  (The first
+// so at most 60 bytes wait in the ring when the next line lands (what is left is even and below 62): 188 bytes, the ring's size.
+// A lane's 17-dword read window (68 bytes for 62) may run a few bytes past the valid data; chunk_pair uses 512 bits of it.  (The first
 // version staged 124-byte tiles, which touches most lines twice: FETCH_SIZE showed 2x the algorithmic
 // bytes, calibrated with tools/fetch_calib.hip.)
-constexpr int RING_WORDS = 48;             // 192 bytes per cell
-constexpr int RING_STRIDE = 49;            // odd row stride
+#ifndef CP2_RING_WORDS
+#define CP2_RING_WORDS 47
+#define CP2_RING_STRIDE 47
+#endif
+#ifndef CP2_HASH_BT
+#define CP2_HASH_BT 256
+#endif
+// 47 words = 188 bytes per cell: exactly the 60 bytes that can still wait plus the 128 of a new line.  Round 5: with 48 words and a
+// row stride of 49 (round 1) a 256-thread workgroup held 54 016 B of LDS and only TWO of them fitted a CU -- SQ_WAVE_CYCLES showed
+// 1.94 waves per SIMD where the registers allow 3; at 47 / 47 it holds 51 968 B, three fit, and the kernel is 1.1 % faster
+// (tools/ab_hash_kernel.py, profiles/r05_ab_hash_ring.txt).  The stride stays odd: the per-lane reads are bank-conflict free.
+constexpr int RING_WORDS = CP2_RING_WORDS;
+constexpr int RING_STRIDE = CP2_RING_STRIDE;
 constexpr int LINE_WORDS = 32;             // 128 bytes
 
 // two 31-byte chunks from a 17-dword window whose first chunk starts SH bits into w[0] (SH = 0 or 16)
@@ -486,13 +498,14 @@ static int hash_block_override() {
 
 hipError_t launch_hash_cells_block(int block, const void* cells, size_t cell_size, size_t n_cells, void* out, hipStream_t st) {
   if (block != 64 && block != 256) return hipErrorInvalidValue;
+  if (block == 256) block = CP2_HASH_BT;
   const size_t max_items = MAX_BLOCKS * (size_t)block;
   for (size_t i0 = 0; i0 < n_cells; i0 += max_items) {
     const size_t m = n_cells - i0 < max_items ? n_cells - i0 : max_items;
     const unsigned grid = (unsigned)((m + block - 1) / block);
     const uint8_t* src = (const uint8_t*)cells + i0 * cell_size;
     if (block == 64) CP2K_LAUNCH(k_hash_cells<64>, dim3(grid), dim3(64), 0, st, src, cell_size, m, (uint4*)out + 2 * i0);
-    else CP2K_LAUNCH(k_hash_cells<256>, dim3(grid), dim3(256), 0, st, src, cell_size, m, (uint4*)out + 2 * i0);
+    else CP2K_LAUNCH(k_hash_cells<CP2_HASH_BT>, dim3(grid), dim3(CP2_HASH_BT), 0, st, src, cell_size, m, (uint4*)out + 2 * i0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }

@@ -184,7 +184,7 @@ if f_med and w_med:
               "shader_cycles_per_launch": cyc_h, "valu_wave_insts_per_launch": insts_h,
               "kernel_ms_in_this_pass": h_pass_ms.get("hsq"),
               "shader_clock_GHz_in_this_pass": (cyc_h / (h_pass_ms["hsq"] * 1e-3) / 1e9) if h_pass_ms.get("hsq") else None,
-              "waves_per_simd": {"by_lds": 3, "measured_SQ_WAVE_CYCLES_x4_over_cycles_x_1024_simds":
+              "waves_per_simd": {"by_registers": 3, "measured_SQ_WAVE_CYCLES_x4_over_cycles_x_1024_simds":
                                  round(hc["SQ_WAVE_CYCLES"]["per_launch_avg"] * 4 / (cyc_h * 1024), 2) if "SQ_WAVE_CYCLES" in hc else None},
               "other_counters_per_launch": {k: v["per_launch_avg"] for k, v in hc.items() if k not in ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE")}}
         hcls_path = os.path.join(P, "%s_valu_classes_hash_cells.json" % R)
@@ -201,6 +201,11 @@ if f_med and w_med:
                                           "isa_over_counter": round(cl["valu_insts_per_cell_from_isa"] / (insts_h / waves_h), 4),
                                           "note": "the ISA count walks the kernel's loop nest at cellSize 2048 (17 lines, 34 absorb steps); the staging blocks outside the absorb loop "
                                                   "(0.5 % of the stream) are priced approximately"}
+            if "SQ_INSTS_VALU_INT64" in hc:      # an independent check of the class mix: the hardware's own count of 64-bit integer instructions
+                isa64 = sum(r["per_permutation"] for r in cl["opcodes"] if r["opcode"] in ("v_mad_u64_u32", "v_lshl_add_u64", "v_lshlrev_b64", "v_mad_i64_i32"))
+                hv["int64_share_check"] = {"SQ_INSTS_VALU_INT64_over_SQ_INSTS_VALU": round(hc["SQ_INSTS_VALU_INT64"]["per_launch_avg"] / insts_h, 4),
+                                           "isa_share_of_v_mad_u64_u32_plus_64bit_adds": round(isa64 / n_isa, 4),
+                                           "note": "SQ_INSTS_VALU_INT64 (pass hsq2) counts the 64-bit multiply-accumulates and adds; the ISA-derived share of the same opcodes agrees"}
             hv["class_floor_cycles"] = {k: (round(x, 1) if x else None) for k, x in floors.items()}
             hv["frac_of_class_floor"] = {k: (round(x / per_perm, 4) if x else None) for k, x in floors.items()}
             hv["classes_source"] = "profiles/%s_valu_classes_hash_cells.json (tools/valu_roof.py)" % R
