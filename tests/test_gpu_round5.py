@@ -273,3 +273,19 @@ def test_roots_only_dataset_notices_changed_slot_data(pkg, oracle, golden, tmp_p
     assert ds.proof_input(2, 1234567).json()                          # the other slots still prove
     ds.free()
     ctx.close()
+
+
+def test_a_rank_without_slots_issues_the_same_collective(pkg, oracle, tmp_path):
+    """World 3, two slots: rank 2 holds nothing.  Round 4 sent it down the host path while its peers used the device gather (two
+    different collectives for one step); now every rank takes the device path, the empty one contributes an empty block
+    and computes the root from the gathered roots.  Fresh rank processes sharing GPU 0, gloo."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from rank_helpers import run_ranks
+    C, _ = oracle
+    c = dict(maxDepth=16, maxLog2NSlots=2, cellSize=2048, blockSize=65536, nSlots=2, nCells=256, nSamples=7, seed=31337)
+    res = run_ranks(3, c, 55555, tmp_path)
+    roots = np.stack([C.fake_slot_root(C.slot_seed(c["seed"], s_), c["cellSize"], c["blockSize"], c["nCells"], 4) for s_ in range(2)])
+    want = hexroot(C.merkle_root(roots))
+    assert sorted((r["rank"], r["count"]) for r in res) == [(0, 1), (1, 1), (2, 0)]
+    for r in res:
+        assert r["dataset_root_hex"] == want and r["all_roots_sha256"] == hashlib.sha256(roots.tobytes()).hexdigest(), r["rank"]
