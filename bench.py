@@ -1393,14 +1393,18 @@ def inprocess_leg(torch, coord, budget, ctx, rank, world):
         me = [sys.executable, os.path.abspath(__file__), "--inprocess-leg", str(world)]
         cap = float(os.environ.get("BENCH_CHILD_CAP_S", "120"))
         worst = LEG_WORST_S["dataset_inprocess"](world)
+        # the library bounds its exchange itself (communicator creation and the collective: CODEX_P2_EXCHANGE_TIMEOUT_S); half the child's
+        # cap, so that an exchange that never completes is reported by the LIBRARY, in its own words, before the child is terminated
+        cenv = dict(os.environ, CODEX_P2_EXCHANGE_TIMEOUT_S=os.environ.get("CODEX_P2_EXCHANGE_TIMEOUT_S", str(int(cap // 2))))
+        child = lambda what: run_child(me + ["--inprocess-what", what], budget.child_timeout(cap), env=cenv) if budget.fits(worst) else {"skipped": "budget"}   # noqa: E731
         try:
             ways = {}
             if world > 1:
                 for name in ("rccl", "copy", "host"):
-                    ways[name] = run_child(me + ["--inprocess-what", name], budget.child_timeout(cap)) if budget.fits(worst) else {"skipped": "budget"}
-            res = run_child(me + ["--inprocess-what", "main"], budget.child_timeout(cap)) if budget.fits(worst) else {"skipped": "budget"}
+                    ways[name] = child(name)
+            res = child("main")
             if world > 1:
-                ways["few_large_slots"] = run_child(me + ["--inprocess-what", "few"], budget.child_timeout(cap)) if budget.fits(worst) else {"skipped": "budget"}
+                ways["few_large_slots"] = child("few")
                 res["exchange_every_way"] = ways
         finally:
             coord.post("inprocess/done", "ok", rank_key=False)

@@ -368,6 +368,9 @@ bool comm_init_all(Rccl& r, const std::vector<int>& devices, size_t world, doubl
   st->comms.assign(world, nullptr);
   st->devices.assign(devices.begin(), devices.begin() + (long)world);
   std::thread th([st, &r] {
+    if (const char* fault = std::getenv("CODEX_P2_TEST_EXCHANGE_FAULT"))      // test-only: a communicator creation that never returns
+      if (std::strcmp(fault, "hang_init") == 0)
+        for (;;) std::this_thread::sleep_for(std::chrono::seconds(3600));
     ncclResult_t e = r.CommInitAll(st->comms.data(), (int)st->comms.size(), st->devices.data());
     std::lock_guard<std::mutex> lk(st->mu);
     st->result = e;

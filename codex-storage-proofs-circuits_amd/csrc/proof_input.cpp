@@ -211,9 +211,9 @@ static int dataset_keep_from_batch(cp2_dataset* ds, const cp2_slot_trees* t, siz
 //
 // Fake data: the batches PIPELINE (BuildScratch: two node buffers used alternately, staging that outlives a builder call, nothing
 // synchronised per batch).  A batch ends with its tree-layer passes -- 22 launches for 2^22-cell slots, the top 16 of them one lone
-// permutation latency each -- and the copy-out of what is kept, all on the context's first stream; the NEXT batch's generation and
-// hashing start on the second stream meanwhile (its chunks alternate between the two), so the device no longer drains between
-// batches (round 4 synchronised and freed here: 1.3-2 % of config 5's nominal share).  Node buffer b is handed
+// permutation latency each -- and the copy-out of what is kept, all on the context's THIRD stream; the next batch's generation and
+// hashing go on alternating between the first two meanwhile, so the device does not drain between batches and the tail of a
+// batch's last hash launch has the next batch's first one beside it (round 4 synchronised and freed here).  Node buffer b is handed
 // to batch k + 2 once batch k's copy-out has completed (an event; long past by then).
 // Slot files: batch by batch as before -- the ingestion pipe owns its ring and drains it, and that path is bound by the storage.
 static int dataset_build_transient(cp2_dataset* ds, int mode, bool allocated = false) {
@@ -251,14 +251,16 @@ static int dataset_build_transient(cp2_dataset* ds, int mode, bool allocated = f
       if (k >= 2 && hipEventSynchronize(kept[b]) != hipSuccess) { ctx->err = std::string(what) + " build: a batch failed on the device"; st = CP2_ERR_HIP; break; }
       cp2_slot_trees* t = nullptr;
       st = trees_build_fake(ctx, c.seed, ds->first_slot + s0, n, c.cell_size, c.block_size, c.n_cells, 0, nullptr, &t, 1, true, &scratch, b);
-      if (st == CP2_OK) st = dataset_keep_from_batch(ds, t, s0);          // on the context's stream: follows the batch's layer passes
-      if (st == CP2_OK && hipEventRecord(kept[b], ctx->stream) != hipSuccess) { ctx->err = "hipEventRecord failed"; st = CP2_ERR_HIP; }
+      hipStream_t tail = scratch.tail_stream ? scratch.tail_stream : ctx->stream;
+      if (st == CP2_OK) st = dataset_keep_from_batch(ds, t, s0, tail);    // follows the batch's layer passes on their stream (the context's third)
+      if (st == CP2_OK && hipEventRecord(kept[b], tail) != hipSuccess) { ctx->err = "hipEventRecord failed"; st = CP2_ERR_HIP; }
       cp2_slot_trees_free(t);                                             // (the batch's nodes are the scratch's: nothing is waited for here)
       if (trace.on && ((k % 32) == 31 || s0 + n == ds->n_local))
         std::fprintf(stderr, "[cp2 trace] %s build: %zu of %llu slots enqueued\n", what, s0 + n, (unsigned long long)ds->n_local);
     }
     if (st == CP2_OK) {                         // everything landed (a failed launch or copy shows up here)
-      if (hipStreamSynchronize(ctx->stream) != hipSuccess || (ctx->aux_stream && hipStreamSynchronize(ctx->aux_stream) != hipSuccess)) {
+      if (hipStreamSynchronize(ctx->stream) != hipSuccess || (ctx->aux_stream && hipStreamSynchronize(ctx->aux_stream) != hipSuccess) ||
+          (ctx->aux2_stream && hipStreamSynchronize(ctx->aux2_stream) != hipSuccess)) {
         (void)hipGetLastError();
         ctx->err = std::string(what) + " build: a batch failed on the device";
         st = CP2_ERR_HIP;

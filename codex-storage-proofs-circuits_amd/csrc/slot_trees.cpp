@@ -172,6 +172,9 @@ struct LayerScheduler {
   hipStream_t hs[2] = {nullptr, nullptr};
   hipEvent_t ev[2] = {nullptr, nullptr};     // the latest hashing enqueued on each stream
   bool detached = false;                     // pipelined batches (BuildScratch): nothing is waited for here, the pipeline's owner does
+  hipStream_t tail = nullptr;                // detached, no groups: the layer passes go to the context's THIRD stream -- the first stream must not
+                                             // wait for the last chunk of this batch (hashed on the second), or nothing could overlap that chunk's
+                                             // tail: the next batch's first chunk is queued on the first stream and runs beside it instead
   ~LayerScheduler() {
     for (int i = 0; i < 2; ++i) {
       if (hs[i] && !detached) (void)hipStreamSynchronize(hs[i]);
@@ -186,8 +189,11 @@ struct LayerScheduler {
       CP2_HIP(ctx, hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
       CP2_HIP(ctx, hipEventRecord(ev[i], hs[i]));
     }
+    if (detached && !group) CP2_TRY(aux_stream(ctx, &tail, 2));
     return CP2_OK;
   }
+  // the stream this batch's layer passes (and whatever follows them: the hook, the caller's copy-out) are enqueued on
+  hipStream_t layer_stream() const { return tail ? tail : hs[group ? 1 : 0]; }
   // a chunk's hashing has just been enqueued on hs[s]
   int hashed_on(int s) {
     CP2_HIP(t->ctx, hipEventRecord(ev[s], hs[s]));
@@ -206,9 +212,11 @@ struct LayerScheduler {
       if (!take) return CP2_OK;
       (void)s;
       const int ts = group ? 1 : 0;             // groups: layer passes on the second stream; otherwise everything ends on the context's
-      CP2_HIP(ctx, hipStreamWaitEvent(hs[ts], ev[1 - ts], 0));   // cells of these slots were (also) hashed on the other stream
-      CP2_TRY(trees_build_layers(t, built, built + take, hs[ts]));
-      if (done) CP2_TRY(done(t, built, built + take, hs[ts]));
+      hipStream_t ls = layer_stream();
+      if (tail) CP2_HIP(ctx, hipStreamWaitEvent(ls, ev[ts], 0));
+      CP2_HIP(ctx, hipStreamWaitEvent(ls, ev[1 - ts], 0));        // cells of these slots were (also) hashed on the other stream
+      CP2_TRY(trees_build_layers(t, built, built + take, ls));
+      if (done) CP2_TRY(done(t, built, built + take, ls));
       built += take;
     }
   }
@@ -254,7 +262,7 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
   // dataset, the generator places unit first_slot + i inside slot (first_slot + i) / units_per_slot
   const uint64_t seed0 = cp2_slot_seed(dataset_seed, units_per_slot > 1 ? 0 : first_slot);
   LayerScheduler sched{t.get(), group, done};
-  sched.detached = scratch != nullptr;
+  sched.detached = scratch != nullptr;        // (before init(): the choice of the layer stream depends on it)
   // Groups (the streamed proof-input path): what follows a group on the host -- the JSON bodies of its slots -- overlaps the
   // hashing of the NEXT group, so the last group's formatting overlaps nothing.  When a chunk is a whole number of slots the
   // last groups are therefore halved down to one residency of the hash kernel (768 x 256 cells): 256, 256, ..., 128, 64, 48
@@ -278,6 +286,7 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
     st = sched.hashed_on(s);
     if (st == CP2_OK) st = sched.advance(c0 + n, c0 + n == total_cells, s);
   }
+  if (scratch) scratch->tail_stream = sched.layer_stream();   // where the batch ends: the caller's copy-out follows the layer passes there
   int fin = sched.finish();
   trace.lap("fake slots: generate + hash + layers");
   if (st == CP2_OK) st = fin;

@@ -46,6 +46,7 @@ using SlotsDone = std::function<int(cp2_slot_trees* t, size_t s0, size_t s1, hip
 struct BuildScratch {
   cp2_ctx* ctx = nullptr;
   DevBuf stage[2], nodes[2];
+  hipStream_t tail_stream = nullptr;   // set by the builder: the stream the last batch's layer passes were enqueued on
   ~BuildScratch();
 };
 

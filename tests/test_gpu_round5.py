@@ -289,3 +289,47 @@ def test_a_rank_without_slots_issues_the_same_collective(pkg, oracle, tmp_path):
     assert sorted((r["rank"], r["count"]) for r in res) == [(0, 1), (1, 1), (2, 0)]
     for r in res:
         assert r["dataset_root_hex"] == want and r["all_roots_sha256"] == hashlib.sha256(roots.tobytes()).hexdigest(), r["rank"]
+
+
+def test_a_communicator_creation_that_never_returns_costs_a_timeout_not_the_process(pkg, golden):
+    """ncclCommInitAll runs on a helper thread under CODEX_P2_EXCHANGE_TIMEOUT_S.  With the test-only fault "hang_init" (the thread never
+    returns) a build that asked for RCCL by name fails after the timeout with an error that says so; RCCL is then not used again in
+    the process (its thread is still somewhere inside the library), the automatic mode goes on working, and RCCL by name says why not.
+    A fresh process: the abandonment is process-wide."""
+    code = r"""
+import json, os, sys, time
+sys.path.insert(0, %r)
+import __graft_entry__ as g
+pkg = g.load_package()
+cfg = pkg.make_config(maxDepth=8, maxLog2NSlots=2, cellSize=128, blockSize=512, nSlots=3, nCells=16, nSamples=3, seed=7)
+m = pkg.Multi([0])
+m.set_policy(pkg.GATHER_RCCL, 0)
+out = {}
+t0 = time.time()
+try:
+    m.dataset(cfg)
+    out["first"] = "built"
+except pkg.CodexP2Error as e:
+    out["first"] = str(e)
+out["seconds"] = time.time() - t0
+del os.environ["CODEX_P2_TEST_EXCHANGE_FAULT"]
+try:
+    m.dataset(cfg)
+    out["second"] = "built"
+except pkg.CodexP2Error as e:
+    out["second"] = str(e)
+m.set_policy(pkg.GATHER_AUTO, 0)
+d = m.dataset(cfg)
+out["auto"] = m.gather_mode()
+out["root"] = d.root().tobytes().hex()
+print(json.dumps(out))
+os._exit(0)          # the abandoned thread sleeps for ever: leave without joining it
+""" % ROOT
+    clean = {k: v for k, v in os.environ.items() if not k.startswith("CODEX_P2_")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(clean, CODEX_P2_TEST_EXCHANGE_FAULT="hang_init", CODEX_P2_EXCHANGE_TIMEOUT_S="2"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "ncclCommInitAll did not return within 2 s" in out["first"] and 1.5 < out["seconds"] < 30, out
+    assert "RCCL gather requested but unavailable" in out["second"] and "abandoned" in out["second"], out
+    assert out["auto"].startswith("none") and len(out["root"]) == 64
