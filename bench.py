@@ -41,8 +41,9 @@ The JSON line also carries
                 stated scale-down (32 768 slots x 2^12 cells sharded over the ranks, one gather of slot roots, dataset tree
                 of 15 levels, one proof input per rank) at every N including 1; the same shape through the C ABI's own
                 multi-GPU entry points in ONE process (cp2_multi_*: what the cli twin / a Nim caller gets, `dataset_inprocess`;
-                at N > 1 it also exchanges the roots every way the library has, each by name -- RCCL all-gather, peer copies,
-                host memory -- and builds a dataset of few, large slots by units: `exchange_every_way`);
+                at N > 1 one fresh child process per question, each under its own timeout: the roots exchanged every way the library
+                has, each BY NAME and RCCL first -- RCCL all-gather, peer copies, host memory --, the automatic choice, and a dataset
+                of few, large slots cut by units: `exchange_every_way`);
                 config 5's other stated scale-down, 8 slots at the nominal 8 GiB slot size (`dataset_big_slots`); and the
                 drop-in's own workload, the cli twin on workflow/params.sh's defaults as a fresh process, split into HIP init /
                 code-object load / hashing / JSON, beside the C oracle on the same configuration (`cli_default`).
