@@ -92,9 +92,9 @@ def test_multi_over_every_real_device_rccl_vs_oracle_fixture(pkg, golden, name):
     oracle-only fixture -- the device-to-device ncclAllGather itself, uneven shards included -- then the same dataset cut by units."""
     g = golden("config5.json")[name]
     c, n = g["config"], g["config"]["nSlots"]
-    m = pkg.Multi(None)
+    m = pkg.Multi(list(range(_n_devices())))                      # explicitly: with no device named a cp2_multi takes ONE (several are opt-in)
     world = m.count
-    assert world == _n_devices() or os.environ.get("CODEX_P2_GPUS")
+    assert world == _n_devices()
     m.set_policy(pkg.GATHER_RCCL, 1)
     m.set_split(1)
     ds = m.dataset(pkg.make_config(**c))
