@@ -249,9 +249,10 @@ bench.spawn_ranks(2, argv=[], script=%r)
 """ % (ROOT, os.path.join(ROOT, "tests", "bench_fake_rank.py"))
 
 
-def _spawn(fault, **env):
+def _spawn(fault, world=2, **env):
     t0 = time.monotonic()
-    p = subprocess.run([sys.executable, "-c", SPAWN], env=dict(os.environ, FAKE_INJECT=fault, **{k: str(v) for k, v in env.items()}),
+    p = subprocess.run([sys.executable, "-c", SPAWN.replace("spawn_ranks(2,", "spawn_ranks(%d," % world)],
+                       env=dict(os.environ, FAKE_INJECT=fault, OMP_NUM_THREADS="1", **{k: str(v) for k, v in env.items()}),
                        capture_output=True, text=True, timeout=120)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, (p.stdout, p.stderr[-2000:])
@@ -263,6 +264,18 @@ def test_two_ranks_no_fault():
     e = d["extra"]
     assert rc == 0 and d["value"] == 1.0 and e["legs"] == {"a": "go", "b": "go", "c": "go", "d": "go"}
     assert e["b"]["gathered"] == [0.0, 1.0] and "rank_failures" not in e and "bench_aborted" not in e
+
+
+def test_eight_ranks_the_drivers_largest_world():
+    """The store coordination at the world size of the driver's last run: eight ranks, clean, and with rank 1 dying inside a leg."""
+    rc, d, dt = _spawn("", world=8)
+    e = d["extra"]
+    assert rc == 0 and d["n_gpus"] == 8 and e["legs"] == {"a": "go", "b": "go", "c": "go", "d": "go"}
+    assert e["b"]["gathered"] == [float(r) for r in range(8)] and "rank_failures" not in e
+    rc, d, dt = _spawn("rank_exit", world=8, FAKE_SYNC_S=30)
+    e = d["extra"]
+    assert rc == 0 and dt < 30 and "exited with code 3" in e["rank_failures"]["1"] and sorted(e["b_rank_errors"]) == ["0", "2", "3", "4", "5", "6", "7"]
+    assert e["c"] == {"ok": True} and e["legs"]["d"].startswith("skipped: rank(s) [1]")
 
 
 def test_a_rank_that_dies_is_named_and_costs_seconds():
