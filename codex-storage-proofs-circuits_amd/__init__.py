@@ -99,6 +99,7 @@ def load_library():
         "cp2_check_environment": (i32, [cp, sz]),
         "cp2_set_ingest": (i32, [vp, i32, i32, sz]),
         "cp2_set_ingest_direct": (i32, [vp, i32]),
+        "cp2_set_ingest_mapped": (i32, [vp, i32]),
         "cp2_trim": (i32, [vp]),
         "cp2_set_body_budget": (i32, [vp, sz, cp]),
         "cp2_set_keep_trees": (i32, [vp, i32]),
@@ -287,6 +288,10 @@ class Context:
     def set_ingest_direct(self, on):
         """O_DIRECT reads of slot files (1 / 0; -1 = environment CP2_INGEST_DIRECT)."""
         self._ck(self.L.cp2_set_ingest_direct(self.h, on), "cp2_set_ingest_direct")
+
+    def set_ingest_mapped(self, on):
+        """page-cache-resident chunks of slot files uploaded straight from a mapping, no CPU copy (1 / 0; -1 = environment CP2_INGEST_MAPPED, default on)"""
+        self._ck(self.L.cp2_set_ingest_mapped(self.h, on), "cp2_set_ingest_mapped")
 
     def trim(self):
         """Give the context's cached device / pinned scratch back to the system (cp2_trim)."""

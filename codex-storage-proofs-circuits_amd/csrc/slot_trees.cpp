@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -407,6 +408,7 @@ struct IngestPipe {
     (void)finish();
     (void)hipStreamSynchronize(ctx->stream);
     if (copy) (void)hipStreamSynchronize(copy);
+    release_windows(-1);
     for (int b = 0; b < depth; ++b) {
       if (copied[b]) (void)hipEventDestroy(copied[b]);
       if (hashed[b]) (void)hipEventDestroy(hashed[b]);
@@ -461,6 +463,7 @@ struct IngestPipe {
   int acquire(uint8_t** buf) {
     int b = (int)(turn % depth);
     CP2_HIP(ctx, hipEventSynchronize(hashed[b]));
+    release_windows(b);                              // (the chunk that last used this ring slot was uploaded from a mapping)
     *buf = pinned[b].u8();
     return CP2_OK;
   }
@@ -475,9 +478,68 @@ struct IngestPipe {
     CP2_HIP(ctx, hipEventRecord(hashed[b], hs));
     last_on_aux = (turn & 1) ? b : last_on_aux;
     ++turn;
+    ++ring_chunks;
     return CP2_OK;
   }
   int last_on_aux = -1;
+
+  // ---- mapped mode (round 5): chunks of a slot file that sit in the PAGE CACHE go to the device without a CPU copy.  The file is
+  // mmap'ed read-only; a chunk whose pages are all resident (mincore) is registered with the runtime (hipHostRegister pins the
+  // page-cache pages themselves) and uploaded straight from the mapping by the copy engine -- 57 GB/s, the pinned H2D peak
+  // (tools/mmap_register_probe.cpp, profiles/r05_mmap_register_probe.txt) -- where pread into the pinned ring tops out at 37-38 GB/s
+  // on 4-8 threads and keeps them busy.  A chunk that is not (all) in the cache, reaches past the end of the file, or cannot be
+  // registered goes through the ring as before; the two mix freely, chunk by chunk: either way ring slot b's device buffer holds
+  // the chunk when `copied[b]` fires.
+  bool mapped_allowed = false, mapped_broken = false;
+  size_t mapped_chunks = 0, ring_chunks = 0;
+  struct Window { void* p; size_t n; int slot; };
+  std::vector<Window> windows;                       // registered windows whose uploads may still be in flight
+  std::vector<unsigned char> residency;              // mincore scratch
+  void release_windows(int slot) {                   // slot b's upload has completed (its hash has): its windows can be unregistered
+    for (size_t i = 0; i < windows.size();) {
+      if (slot < 0 || windows[i].slot == slot) { (void)hipHostUnregister(windows[i].p); windows[i] = windows.back(); windows.pop_back(); }
+      else ++i;
+    }
+  }
+  // all uploads from mappings are complete and unregistered: the caller may munmap
+  int drain_mapped() {
+    if (windows.empty()) return CP2_OK;
+    CP2_HIP(ctx, hipStreamSynchronize(copy));
+    release_windows(-1);
+    return CP2_OK;
+  }
+  // bytes [off, off + len) of the mapping `base` (of `map_len` bytes): resident and registrable?  On success the window is registered.
+  bool try_window(uint8_t* base, size_t map_len, size_t off, size_t len, int slot) {
+    if (!mapped_allowed || mapped_broken || !base || off + len > map_len) return false;
+    const size_t page = 4096;
+    if (off % page || ((off + len) % page && off + len != map_len)) return false;   // windows are whole pages of their own (two registrations never share a page); other chunk shapes use the ring
+    const size_t a = off, e = std::min(map_len, (off + len + page - 1) / page * page);
+    residency.resize((e - a + page - 1) / page);
+    if (mincore(base + a, e - a, residency.data()) != 0) return false;
+    for (unsigned char r : residency)
+      if (!(r & 1)) return false;                    // not (all) in the page cache: the ring path reads it (buffered or O_DIRECT)
+    if (hipHostRegister(base + a, e - a, hipHostRegisterDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      mapped_broken = true;                          // this stack does not register file-backed pages: the ring from here on
+      return false;
+    }
+    windows.push_back({base + a, e - a, slot});
+    return true;
+  }
+  // ship m cells that sit at `src` inside a REGISTERED window: upload on the copy stream, hash, like submit()
+  int submit_mapped(const uint8_t* src, size_t m, size_t cell_size, uint8_t* leaves_out) {
+    int b = (int)(turn % depth);
+    CP2_HIP(ctx, hipMemcpyAsync(dev[b].p, src, m * cell_size, hipMemcpyHostToDevice, copy));
+    CP2_HIP(ctx, hipEventRecord(copied[b], copy));
+    hipStream_t hs = hash_stream[turn & 1];
+    CP2_HIP(ctx, hipStreamWaitEvent(hs, copied[b], 0));
+    CP2_HIP(ctx, cp2k::launch_hash_cells(dev[b].p, cell_size, m, leaves_out, hs));
+    CP2_HIP(ctx, hipEventRecord(hashed[b], hs));
+    last_on_aux = (turn & 1) ? b : last_on_aux;
+    ++turn;
+    ++mapped_chunks;
+    return CP2_OK;
+  }
   // everything hashed on the second stream is ordered before whatever the caller enqueues next on the context's stream
   int finish() {
     if (last_on_aux >= 0) {
@@ -557,6 +619,10 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
       while (h) { size_t r = g % h; g = h; h = r; }               // gcd(cell_size, 4096)
       pipe.cell_multiple = IngestPipe::DIRECT_ALIGN / g;
     }
+    // mapped mode (cp2_set_ingest_mapped / CP2_INGEST_MAPPED, default on): chunks that sit in the page cache are uploaded straight
+    // from a mapping of the file, no CPU copy; not with O_DIRECT, whose point is to leave the page cache alone
+    pipe.mapped_allowed = !want_direct && (ctx->ingest_mapped > 0 || (ctx->ingest_mapped < 0 && env_size("CP2_INGEST_MAPPED", 1) != 0));
+    StageTimer ingest_trace;
     for (size_t s = 0; st == CP2_OK && s < n_slots; ++s) {
       // unit s of the batch = cells [unit_off, unit_off + n_cells) of the file of slot (first_slot + s) / units_per_slot
       const uint64_t unit = first_slot + s;
@@ -565,12 +631,26 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
       int fd = open(fname.c_str(), O_RDONLY);
       if (fd < 0) { ctx->err = "cannot open " + fname; st = CP2_ERR_IO; break; }
       const int dfd = want_direct ? open(fname.c_str(), O_RDONLY | O_DIRECT) : -1;
+      // the whole file mapped read-only (nothing is read by this: pages that are not in the cache stay where they are)
+      uint8_t* map = nullptr;
+      size_t map_len = 0;
+      if (pipe.mapped_allowed && !pipe.mapped_broken) {
+        struct stat sb;
+        if (fstat(fd, &sb) == 0 && sb.st_size > 0) {
+          void* p = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_SHARED, fd, 0);
+          if (p != MAP_FAILED) { map = static_cast<uint8_t*>(p); map_len = (size_t)sb.st_size; }
+        }
+      }
       for (size_t c0 = 0, m = 0; st == CP2_OK && c0 < n_cells; c0 += m) {
         m = pipe.next_cells(n_cells - c0);
         uint8_t* buf = nullptr;
         st = pipe.acquire(&buf);
         if (st != CP2_OK) break;
         const size_t off = unit_off + c0 * cell_size;
+        if (pipe.try_window(map, map_len, off, m * cell_size, (int)(pipe.turn % pipe.depth))) {
+          st = pipe.submit_mapped(map + off, m, cell_size, t->nodes.u8() + (s * n_cells + c0) * 32);
+          continue;
+        }
         const bool direct = dfd >= 0 && off % IngestPipe::DIRECT_ALIGN == 0;
         // bytes [off, off+n) of the file into the pinned buffer, zero-filled past EOF (slot.nim:61-66)
         pipe.parallel_ranges(m * cell_size, (size_t)2 << 20, [=](size_t a, size_t b) {
@@ -593,6 +673,11 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
         }, direct ? IngestPipe::DIRECT_ALIGN : 1);
         st = pipe.submit(m, cell_size, t->nodes.u8() + (s * n_cells + c0) * 32);
       }
+      if (map) {                                  // its uploads are done (a few ms at most: the hashing queued behind them goes on) before the mapping goes
+        int dst = pipe.drain_mapped();
+        if (st == CP2_OK) st = dst;
+        munmap(map, map_len);
+      }
       if (dfd >= 0) close(dfd);
       close(fd);
       if (st == CP2_OK) st = pipe.finish();   // the context's stream now follows everything hashed on the second one
@@ -601,10 +686,24 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
     }
     int fin = sched.finish();
     if (st == CP2_OK) st = fin;
+    if (ingest_trace.on) {
+      char what[160];
+      std::snprintf(what, sizeof what, "slot files: %zu chunk(s) from the page cache by mapping, %zu through the pinned ring%s", pipe.mapped_chunks, pipe.ring_chunks,
+                    pipe.mapped_broken ? " (registration refused)" : "");
+      ingest_trace.lap(what);
+    }
   }
   if (st != CP2_OK) return st;
   *out = t.release();
   return CP2_OK;
+}
+
+extern "C" int cp2_set_ingest_mapped(cp2_ctx* ctx, int on) try {
+  if (!ctx) return CP2_ERR_INVALID;
+  ctx->ingest_mapped = on < 0 ? -1 : (on ? 1 : 0);
+  return CP2_OK;
+} catch (...) {
+  return CP2_ERR_INVALID;
 }
 
 extern "C" int cp2_set_ingest_direct(cp2_ctx* ctx, int on) try {

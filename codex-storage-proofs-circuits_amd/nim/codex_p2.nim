@@ -35,6 +35,7 @@ proc cp2_strerror(status: cint): cstring {.importc.}
 proc cp2_last_error(ctx: Cp2Ctx): cstring {.importc.}
 proc cp2_trim(ctx: Cp2Ctx): cint {.importc.}
 proc cp2_set_ingest_direct(ctx: Cp2Ctx, on: cint): cint {.importc.}
+proc cp2_set_ingest_mapped(ctx: Cp2Ctx, on: cint): cint {.importc.}
 proc cp2_set_body_budget(ctx: Cp2Ctx, maxResidentBytes: csize_t, spillDir: cstring): cint {.importc.}
 proc cp2_set_keep_trees(ctx: Cp2Ctx, mode: cint): cint {.importc.}
 proc cp2_permute_batch(ctx: Cp2Ctx, inp, outp: ptr byte, n: csize_t): cint {.importc.}

@@ -333,3 +333,63 @@ os._exit(0)          # the abandoned thread sleeps for ever: leave without joini
     assert "ncclCommInitAll did not return within 2 s" in out["first"] and 1.5 < out["seconds"] < 30, out
     assert "RCCL gather requested but unavailable" in out["second"] and "abandoned" in out["second"], out
     assert out["auto"].startswith("none") and len(out["root"]) == 64
+
+
+def test_slot_files_in_the_page_cache_are_uploaded_straight_from_a_mapping(pkg, oracle, golden, tmp_path, capfd):
+    """Mapped ingestion (cp2_set_ingest_mapped, default on): chunks of a slot file whose pages are all in the page cache are registered
+    with the runtime and uploaded from the mapping itself -- no pread into the pinned ring -- and everything else goes through the
+    ring; same trees either way.  Files just written are in the cache: with 2048-byte cells every chunk is page-aligned and takes the
+    mapped path (the trace says how many did); with 100-byte cells chunk boundaries fall inside pages and the ring carries them; a
+    file evicted from the cache (fsync + POSIX_FADV_DONTNEED) is read through the ring; a short file is zero-filled (slot.nim:61-66)
+    by the ring for the chunk that reaches past its end."""
+    C, _ = oracle
+    os.environ["CP2_TRACE"] = "1"
+    try:
+        ctx = pkg.Context(0)
+        for cs, nc, n_slots in ((2048, 1 << 16, 3), (100, 1 << 12, 2)):
+            base = str(tmp_path / ("f%d_" % cs))
+            for k in range(n_slots):
+                C.gen_fake_cells(C.slot_seed(777, k), 0, nc, cs).tofile("%s%d.dat" % (base, k))
+            bs = cs * 32
+            want = np.stack([C.fake_slot_root(C.slot_seed(777, k), cs, bs, nc, 8) for k in range(n_slots)])
+            cfg = pkg.make_config(maxDepth=24, maxLog2NSlots=2, cellSize=cs, blockSize=bs, nSlots=n_slots, nCells=nc, nSamples=4, file=base)
+            if cs == 100:
+                ctx.set_ingest(4, 3, 65536)               # 64 KiB chunks of 100-byte cells: no chunk boundary on a page boundary
+            for mapped in (1, 0):
+                ctx.set_ingest_mapped(mapped)
+                capfd.readouterr()
+                ds = ctx.dataset(cfg)
+                err = capfd.readouterr().err
+                assert np.array_equal(ds.local_roots(), want), (cs, mapped)
+                line = [l for l in err.splitlines() if "slot files:" in l][-1]
+                n_mapped = int(line.split("slot files:")[1].split("chunk")[0])
+                assert (n_mapped > 0) == (mapped == 1 and cs == 2048), (cs, mapped, line)
+                pi = ds.proof_input(1, 4242).json()
+                ds.free()
+            ctx.set_ingest_mapped(-1)
+            ctx.set_ingest(0, 0, 0)
+        # evicted from the page cache: nothing is resident, the ring reads it; same root
+        base = str(tmp_path / "f2048_")
+        for k in range(3):
+            fd = os.open("%s%d.dat" % (base, k), os.O_RDONLY)
+            os.fsync(fd)
+            os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+            os.close(fd)
+        cfg = pkg.make_config(maxDepth=24, maxLog2NSlots=2, cellSize=2048, blockSize=65536, nSlots=3, nCells=1 << 16, nSamples=4, file=base)
+        want = np.stack([C.fake_slot_root(C.slot_seed(777, k), 2048, 65536, 1 << 16, 8) for k in range(3)])
+        capfd.readouterr()
+        ds = ctx.dataset(cfg)
+        err = capfd.readouterr().err
+        assert np.array_equal(ds.local_roots(), want)
+        ds.free()
+        # a short file: cells past its end read as zeros, whichever path carried the chunks before
+        cells = C.gen_fake_cells(C.slot_seed(777, 0), 0, 1 << 16, 2048)
+        cells[50000:] = 0
+        cells[:50000].tofile(base + "0.dat")
+        ds = ctx.dataset(cfg)
+        assert np.array_equal(ds.local_roots()[0], ctx.slot_trees_host(cells, 1, 2048, 65536, 1 << 16).roots()[0])
+        assert np.array_equal(ds.local_roots()[1:], want[1:])
+        ds.free()
+        ctx.close()
+    finally:
+        del os.environ["CP2_TRACE"]
