@@ -408,7 +408,8 @@ struct IngestPipe {
     (void)finish();
     (void)hipStreamSynchronize(ctx->stream);
     if (copy) (void)hipStreamSynchronize(copy);
-    release_windows(-1);
+    for (auto& mp : mappings) mp.open = false;
+    (void)release_mapped();
     for (int b = 0; b < depth; ++b) {
       if (copied[b]) (void)hipEventDestroy(copied[b]);
       if (hashed[b]) (void)hipEventDestroy(hashed[b]);
@@ -463,7 +464,6 @@ struct IngestPipe {
   int acquire(uint8_t** buf) {
     int b = (int)(turn % depth);
     CP2_HIP(ctx, hipEventSynchronize(hashed[b]));
-    release_windows(b);                              // (the chunk that last used this ring slot was uploaded from a mapping)
     *buf = pinned[b].u8();
     return CP2_OK;
   }
@@ -484,46 +484,62 @@ struct IngestPipe {
   int last_on_aux = -1;
 
   // ---- mapped mode (round 5): chunks of a slot file that sit in the PAGE CACHE go to the device without a CPU copy.  The file is
-  // mmap'ed read-only; a chunk whose pages are all resident (mincore) is registered with the runtime (hipHostRegister pins the
-  // page-cache pages themselves) and uploaded straight from the mapping by the copy engine -- 57 GB/s, the pinned H2D peak
-  // (tools/mmap_register_probe.cpp, profiles/r05_mmap_register_probe.txt) -- where pread into the pinned ring tops out at 37-38 GB/s
-  // on 4-8 threads and keeps them busy.  A chunk that is not (all) in the cache, reaches past the end of the file, or cannot be
-  // registered goes through the ring as before; the two mix freely, chunk by chunk: either way ring slot b's device buffer holds
-  // the chunk when `copied[b]` fires.
+  // mmap'ed read-only; a chunk whose pages are resident (mincore, sampled) is REGISTERED with the runtime (hipHostRegister pins the
+  // page-cache pages themselves: 0.7-2.5 ms per 384 MiB, and it does not wait for the device) and uploaded straight from the
+  // mapping by the copy engine at the pinned H2D rate, 57 GB/s -- where pread into the pinned ring tops out at 37-38 GB/s on 4-8
+  // busy threads (tools/mmap_register_probe.cpp, profiles/r05_mmap_register_probe.txt).  Two things the probe found shape this:
+  //   * hipHostUnregister waits for the whole DEVICE (409 ms beside a 418 ms kernel): unregistering per chunk serialised the pipe to
+  //     18 GB/s.  So windows stay registered -- and their mappings mapped -- until the pipe ends (it synchronises there anyway), or
+  //     until `mapped_budget` bytes are registered, when everything uploaded so far is released in one go (one bubble per budget).
+  //   * uploading from the UNregistered mapping (the runtime pins in place by itself) reaches 55 GB/s beside an idle device but only
+  //     30 GB/s beside the hash kernel, and holds the host for the duration: slower than the ring.
+  // A chunk that is not in the cache, reaches past the end of the file or cannot be registered goes through the ring as before; the
+  // two mix freely, chunk by chunk: either way ring slot b's device buffer holds the chunk when `copied[b]` fires.
   bool mapped_allowed = false, mapped_broken = false;
-  size_t mapped_chunks = 0, ring_chunks = 0;
-  struct Window { void* p; size_t n; int slot; };
-  std::vector<Window> windows;                       // registered windows whose uploads may still be in flight
-  std::vector<unsigned char> residency;              // mincore scratch
-  void release_windows(int slot) {                   // slot b's upload has completed (its hash has): its windows can be unregistered
-    for (size_t i = 0; i < windows.size();) {
-      if (slot < 0 || windows[i].slot == slot) { (void)hipHostUnregister(windows[i].p); windows[i] = windows.back(); windows.pop_back(); }
+  size_t mapped_chunks = 0, ring_chunks = 0, registered_bytes = 0, mapped_budget = (size_t)32 << 30, releases = 0;
+  struct Window { void* p; size_t n; };
+  struct Mapping { uint8_t* base; size_t len; bool open; };
+  std::vector<Window> windows;                       // registered, uploads possibly in flight
+  std::vector<Mapping> mappings;                     // every file mapped so far that still has (or may get) windows
+  // all uploads from mappings are complete: unregister every window (this waits for the device) and unmap the files that are done
+  int release_mapped() {
+    if (!windows.empty()) {
+      CP2_HIP(ctx, hipStreamSynchronize(copy));
+      for (auto& w : windows) (void)hipHostUnregister(w.p);
+      windows.clear();
+      ++releases;
+    }
+    registered_bytes = 0;
+    for (size_t i = 0; i < mappings.size();) {
+      if (!mappings[i].open) { munmap(mappings[i].base, mappings[i].len); mappings[i] = mappings.back(); mappings.pop_back(); }
       else ++i;
     }
-  }
-  // all uploads from mappings are complete and unregistered: the caller may munmap
-  int drain_mapped() {
-    if (windows.empty()) return CP2_OK;
-    CP2_HIP(ctx, hipStreamSynchronize(copy));
-    release_windows(-1);
     return CP2_OK;
   }
-  // bytes [off, off + len) of the mapping `base` (of `map_len` bytes): resident and registrable?  On success the window is registered.
-  bool try_window(uint8_t* base, size_t map_len, size_t off, size_t len, int slot) {
-    if (!mapped_allowed || mapped_broken || !base || off + len > map_len) return false;
+  // bytes [off, off + len) of the mapping `base` (of `map_len` bytes): in the page cache and registrable?  mincore over every page of
+  // a 384 MiB chunk costs as much as the upload itself (98 304 page-cache lookups: 7 ms measured), so the chunk is SAMPLED: its
+  // first and last page and one page in every 256 KiB.  Caches fill and evict in far larger runs than that; a chunk that passes with
+  // a hole in it is still read correctly (the missing pages are faulted in while they are pinned), only more slowly.
+  bool try_window(uint8_t* base, size_t map_len, size_t off, size_t len) {
+    if (!mapped_allowed || mapped_broken || !base || len == 0 || off + len > map_len) return false;
     const size_t page = 4096;
-    if (off % page || ((off + len) % page && off + len != map_len)) return false;   // windows are whole pages of their own (two registrations never share a page); other chunk shapes use the ring
-    const size_t a = off, e = std::min(map_len, (off + len + page - 1) / page * page);
-    residency.resize((e - a + page - 1) / page);
-    if (mincore(base + a, e - a, residency.data()) != 0) return false;
-    for (unsigned char r : residency)
-      if (!(r & 1)) return false;                    // not (all) in the page cache: the ring path reads it (buffered or O_DIRECT)
-    if (hipHostRegister(base + a, e - a, hipHostRegisterDefault) != hipSuccess) {
+    if (off % page || ((off + len) % page && off + len != map_len)) return false;   // windows are whole pages of their own: two registrations never share a page
+    const size_t stride = (size_t)256 << 10, last = (off + len - 1) / page * page;
+    unsigned char r = 0;
+    for (size_t at = off;; at += stride) {
+      if (at > last) at = last;
+      if (mincore(base + at, page, &r) != 0 || !(r & 1)) return false;   // not in the page cache: the ring path reads the chunk (buffered or O_DIRECT)
+      if (at == last) break;
+    }
+    const size_t n = std::min(map_len, (off + len + page - 1) / page * page) - off;
+    if (registered_bytes + n > mapped_budget && release_mapped() != CP2_OK) return false;
+    if (hipHostRegister(base + off, n, hipHostRegisterDefault) != hipSuccess) {
       (void)hipGetLastError();
       mapped_broken = true;                          // this stack does not register file-backed pages: the ring from here on
       return false;
     }
-    windows.push_back({base + a, e - a, slot});
+    windows.push_back({base + off, n});
+    registered_bytes += n;
     return true;
   }
   // ship m cells that sit at `src` inside a REGISTERED window: upload on the copy stream, hash, like submit()
@@ -638,7 +654,11 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
         struct stat sb;
         if (fstat(fd, &sb) == 0 && sb.st_size > 0) {
           void* p = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_SHARED, fd, 0);
-          if (p != MAP_FAILED) { map = static_cast<uint8_t*>(p); map_len = (size_t)sb.st_size; }
+          if (p != MAP_FAILED) {
+            map = static_cast<uint8_t*>(p);
+            map_len = (size_t)sb.st_size;
+            pipe.mappings.push_back({map, map_len, true});
+          }
         }
       }
       for (size_t c0 = 0, m = 0; st == CP2_OK && c0 < n_cells; c0 += m) {
@@ -647,7 +667,7 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
         st = pipe.acquire(&buf);
         if (st != CP2_OK) break;
         const size_t off = unit_off + c0 * cell_size;
-        if (pipe.try_window(map, map_len, off, m * cell_size, (int)(pipe.turn % pipe.depth))) {
+        if (pipe.try_window(map, map_len, off, m * cell_size)) {
           st = pipe.submit_mapped(map + off, m, cell_size, t->nodes.u8() + (s * n_cells + c0) * 32);
           continue;
         }
@@ -673,11 +693,9 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
         }, direct ? IngestPipe::DIRECT_ALIGN : 1);
         st = pipe.submit(m, cell_size, t->nodes.u8() + (s * n_cells + c0) * 32);
       }
-      if (map) {                                  // its uploads are done (a few ms at most: the hashing queued behind them goes on) before the mapping goes
-        int dst = pipe.drain_mapped();
-        if (st == CP2_OK) st = dst;
-        munmap(map, map_len);
-      }
+      if (map)                                    // the mapping stays until its windows are released (the pipe's end, or the next release)
+        for (auto& mp : pipe.mappings)
+          if (mp.base == map) mp.open = false;
       if (dfd >= 0) close(dfd);
       close(fd);
       if (st == CP2_OK) st = pipe.finish();   // the context's stream now follows everything hashed on the second one

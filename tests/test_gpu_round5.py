@@ -338,10 +338,10 @@ os._exit(0)          # the abandoned thread sleeps for ever: leave without joini
 def test_slot_files_in_the_page_cache_are_uploaded_straight_from_a_mapping(pkg, oracle, golden, tmp_path, capfd):
     """Mapped ingestion (cp2_set_ingest_mapped, default on): chunks of a slot file whose pages are all in the page cache are registered
     with the runtime and uploaded from the mapping itself -- no pread into the pinned ring -- and everything else goes through the
-    ring; same trees either way.  Files just written are in the cache: with 2048-byte cells every chunk is page-aligned and takes the
-    mapped path (the trace says how many did); with 100-byte cells chunk boundaries fall inside pages and the ring carries them; a
-    file evicted from the cache (fsync + POSIX_FADV_DONTNEED) is read through the ring; a short file is zero-filled (slot.nim:61-66)
-    by the ring for the chunk that reaches past its end."""
+    ring; same trees either way.  Files just written are in the cache: every chunk takes the mapped path (the trace says how many did),
+    chunks of 100-byte cells whose boundaries fall inside pages do not (a window is whole pages of its own); switched off, the ring carries everything; a file evicted from
+    the cache (fsync + POSIX_FADV_DONTNEED) is read through the ring; a short file is zero-filled (slot.nim:61-66) by the ring for the
+    chunk that reaches past its end."""
     C, _ = oracle
     os.environ["CP2_TRACE"] = "1"
     try:
@@ -363,7 +363,10 @@ def test_slot_files_in_the_page_cache_are_uploaded_straight_from_a_mapping(pkg, 
                 assert np.array_equal(ds.local_roots(), want), (cs, mapped)
                 line = [l for l in err.splitlines() if "slot files:" in l][-1]
                 n_mapped = int(line.split("slot files:")[1].split("chunk")[0])
-                assert (n_mapped > 0) == (mapped == 1 and cs == 2048), (cs, mapped, line)
+                if cs == 100:
+                    assert n_mapped == 0, line            # windows are whole pages of their own: these chunks all go through the ring
+                else:
+                    assert (n_mapped > 0) == (mapped == 1) and ("%d chunk(s) from the page cache by mapping, 0 through" % n_mapped in line) == (mapped == 1), (cs, mapped, line)
                 pi = ds.proof_input(1, 4242).json()
                 ds.free()
             ctx.set_ingest_mapped(-1)
@@ -381,6 +384,7 @@ def test_slot_files_in_the_page_cache_are_uploaded_straight_from_a_mapping(pkg, 
         ds = ctx.dataset(cfg)
         err = capfd.readouterr().err
         assert np.array_equal(ds.local_roots(), want)
+        assert "slot files: 0 chunk(s) from the page cache by mapping" in err, err            # nothing was resident: the ring read it all
         ds.free()
         # a short file: cells past its end read as zeros, whichever path carried the chunks before
         cells = C.gen_fake_cells(C.slot_seed(777, 0), 0, 1 << 16, 2048)

@@ -36,7 +36,9 @@ try:
     ctx.set_keep_trees(2)
     hexroot = lambda a: np.asarray(a, dtype=np.uint8).tobytes()[::-1].hex()      # noqa: E731
     res = {}
-    for label, evict, direct in (("page_cache", False, 0), ("evicted_buffered", True, 0), ("evicted_o_direct", True, 1)):
+    os.environ["CP2_TRACE"] = "1"                                   # the library says how many chunks went by mapping / through the ring
+    for label, evict, direct in (("page_cache", False, 0), ("page_cache_ring_only", False, 0), ("page_cache_again", False, 0),
+                                 ("evicted_buffered", True, 0), ("evicted_o_direct", True, 1)):
         if evict:
             for k in range(n_slots):
                 fd = os.open("%s%d.dat" % (base, k), os.O_RDONLY)
@@ -44,6 +46,7 @@ try:
                 os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
                 os.close(fd)
         ctx.set_ingest_direct(direct)
+        ctx.set_ingest_mapped(0 if label == "page_cache_ring_only" else -1)
         t = time.time()
         ds = ctx.dataset(cfg)
         dt = time.time() - t
