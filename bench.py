@@ -1032,10 +1032,10 @@ def ingest_leg(torch, ctx, pkg, dev):
     bh = max(r["host_pointer_GBps"] for r in table)
     bf = max(r["page_cache_file_GBps"] for r in table)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    return {"ingest": {"workload": "one 4 GiB slot (cellSize 2048) from host memory through the pinned ring / from a page-cache-warm slot file (resident chunks uploaded from registered windows of its mapping; ring_only: the same file with that switched off)",
+    return {"ingest": {"workload": "one 4 GiB slot (cellSize 2048) from host memory / from a page-cache-warm slot file through the pinned ring (mapped: the same file with cp2_set_ingest_mapped(1), resident chunks uploaded from registered windows of its mapping, no host thread copying)",
                        "pinned_h2d_peak_GBps": round(best, 2), "hash_from_hbm_GBps": round(kernel_gbps, 2), "by_fill_threads": table,
                        "best_host_pointer_GBps": bh, "best_page_cache_file_GBps": bf,
-                       "best_page_cache_file_ring_only_GBps": max(r["page_cache_file_ring_only_GBps"] for r in table),
+                       "best_page_cache_file_mapped_GBps": max(r["page_cache_file_mapped_GBps"] for r in table),
                        "host_pointer_frac_of_h2d_peak": round(bh / best, 3), "file_frac_of_h2d_peak": round(bf / best, 3),
                        "host_pointer_frac_of_kernel_rate": round(bh / kernel_gbps, 3), "cold_file": cold}}
 
@@ -1078,8 +1078,8 @@ def ingest_table(ctx, pkg, np, cells, cfg, cs, bs, nc, nbytes, want, table):
         dt_f = time.perf_counter() - t
         ok_f = bool(np.array_equal(ds.local_roots()[0], want))
         ds.free()
-        # the same file with mapped ingestion switched off: every chunk pread into the pinned ring by the fill threads
-        ctx.set_ingest_mapped(0)
+        # the same file with mapped ingestion switched on: resident chunks uploaded from registered windows of the file's mapping
+        ctx.set_ingest_mapped(1)
         try:
             t = time.perf_counter()
             ds = ctx.dataset(cfg)
@@ -1089,7 +1089,7 @@ def ingest_table(ctx, pkg, np, cells, cfg, cs, bs, nc, nbytes, want, table):
         finally:
             ctx.set_ingest_mapped(-1)
         table.append({"fill_threads": threads, "chunk_MiB": chunk_mb, "host_pointer_GBps": round(nbytes / dt_h / 1e9, 2), "page_cache_file_GBps": round(nbytes / dt_f / 1e9, 2),
-                      "page_cache_file_ring_only_GBps": round(nbytes / dt_r / 1e9, 2), "roots_match_device_build": ok_h and ok_f})
+                      "page_cache_file_mapped_GBps": round(nbytes / dt_r / 1e9, 2), "roots_match_device_build": ok_h and ok_f})
 
 
 def dataset_leg(torch, bdist, coord, ctx, pkg, dev, rank, world):

@@ -290,7 +290,7 @@ class Context:
         self._ck(self.L.cp2_set_ingest_direct(self.h, on), "cp2_set_ingest_direct")
 
     def set_ingest_mapped(self, on):
-        """page-cache-resident chunks of slot files uploaded straight from a mapping, no CPU copy (1 / 0; -1 = environment CP2_INGEST_MAPPED, default on)"""
+        """page-cache-resident chunks of slot files uploaded straight from a mapping, no CPU copy (1 / 0; -1 = environment CP2_INGEST_MAPPED, default off)"""
         self._ck(self.L.cp2_set_ingest_mapped(self.h, on), "cp2_set_ingest_mapped")
 
     def trim(self):

@@ -123,7 +123,7 @@ struct cp2_ctx {
   size_t stage_bytes = (size_t)1 << 31;   // device staging chunk of the fake-data builder
   int ingest_threads = 0, ingest_ring = 0;   // 0: CP2_INGEST_* environment or the built-in default (cp2_set_ingest)
   size_t ingest_chunk = 0;
-  int ingest_mapped = -1;                    // SlotFile chunks that sit in the page cache uploaded straight from a mapping of the file (no CPU copy): 1 on, 0 off, -1 = environment CP2_INGEST_MAPPED, default on (cp2_set_ingest_mapped)
+  int ingest_mapped = -1;                    // SlotFile chunks that sit in the page cache uploaded straight from a mapping of the file (no CPU copy): 1 on, 0 off, -1 = environment CP2_INGEST_MAPPED, default off (cp2_set_ingest_mapped)
   int ingest_direct = -1;                    // SlotFile reads with O_DIRECT: 1 on, 0 off, -1 = environment CP2_INGEST_DIRECT (cp2_set_ingest_direct)
   size_t body_budget = 0;                    // streamed proof-input bodies kept in host memory; 0: CP2_BODY_BUDGET_MB or 4 GiB (cp2_set_body_budget)
   size_t mem_allowance = 0;                  // device bytes this context may plan with in its automatic residency choice; 0: ask the device.  cp2_multi sets it for the duration of a build: what the device had free BEFORE its shards started, divided by the number of contexts placed on that device

@@ -82,14 +82,15 @@ int cp2_set_ingest(cp2_ctx* ctx, int fill_threads, int ring_depth, size_t chunk_
  * on = 1 / 0; -1 = the environment variable CP2_INGEST_DIRECT (default off).  A file system that refuses O_DIRECT is read
  * buffered; results are identical either way. */
 int cp2_set_ingest_direct(cp2_ctx* ctx, int on);
-/* SlotFile source: chunks of a slot file that sit in the PAGE CACHE go to the device without a CPU copy -- the file is mmap'ed
- * read-only, a chunk that starts and ends on page boundaries and whose pages are resident (mincore, sampled) is registered with
- * the runtime (the page-cache pages themselves are pinned) and uploaded straight from the mapping by the copy engine, instead of
- * being pread into the pinned ring first.  Registrations are held until the build's ingestion ends (at most 32 GiB at a time).
+/* SlotFile source, opt-in: chunks of a slot file that sit in the PAGE CACHE go to the device without a CPU copy -- the file is
+ * mmap'ed read-only, a chunk that starts and ends on page boundaries and whose pages are resident (mincore, sampled) is registered
+ * with the runtime (the page-cache pages themselves are pinned) and uploaded straight from the mapping by the copy engine, instead
+ * of being pread into the pinned ring first.  Registrations are held until the build's ingestion ends (at most 32 GiB at a time).
  * Any other chunk -- not cached, not on page boundaries, past the end of the file, or the runtime refuses to register file pages
- * (RLIMIT_MEMLOCK and the like) -- goes through the ring as before; the two mix chunk by chunk, results are identical.  Same
- * throughput as the ring on one device (the hash kernel bounds both), with no host threads copying and a third of the host
- * memory traffic.  on = 1 / 0; -1 = the environment variable CP2_INGEST_MAPPED (default ON).  Not used together with O_DIRECT. */
+ * (RLIMIT_MEMLOCK and the like) -- goes through the ring as before; the two mix chunk by chunk, results are identical.  On one
+ * device the throughput equals the ring's (the hash kernel bounds both: DESIGN.md section 6); what it saves is host threads
+ * copying and two thirds of the host memory traffic.  on = 1 / 0; -1 = the environment variable CP2_INGEST_MAPPED (default OFF).
+ * Not used together with O_DIRECT. */
 int cp2_set_ingest_mapped(cp2_ctx* ctx, int on);
 /* Memory a long-lived context holds.  Scratch blocks (device staging, pinned landing zones) are cached per context so that
  * repeated calls stop allocating: up to 6 GiB of device memory and 3 GiB of PINNED host memory stay with the context after

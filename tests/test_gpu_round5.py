@@ -336,7 +336,7 @@ os._exit(0)          # the abandoned thread sleeps for ever: leave without joini
 
 
 def test_slot_files_in_the_page_cache_are_uploaded_straight_from_a_mapping(pkg, oracle, golden, tmp_path, capfd):
-    """Mapped ingestion (cp2_set_ingest_mapped, default on): chunks of a slot file whose pages are all in the page cache are registered
+    """Mapped ingestion (cp2_set_ingest_mapped, opt-in): chunks of a slot file whose pages are all in the page cache are registered
     with the runtime and uploaded from the mapping itself -- no pread into the pinned ring -- and everything else goes through the
     ring; same trees either way.  Files just written are in the cache: every chunk takes the mapped path (the trace says how many did),
     chunks of 100-byte cells whose boundaries fall inside pages do not (a window is whole pages of its own); switched off, the ring carries everything; a file evicted from
@@ -361,7 +361,7 @@ def test_slot_files_in_the_page_cache_are_uploaded_straight_from_a_mapping(pkg, 
                 ds = ctx.dataset(cfg)
                 err = capfd.readouterr().err
                 assert np.array_equal(ds.local_roots(), want), (cs, mapped)
-                line = [l for l in err.splitlines() if "slot files:" in l][-1]
+                line = [l for l in err.splitlines() if "from the page cache by mapping" in l][-1]
                 n_mapped = int(line.split("slot files:")[1].split("chunk")[0])
                 if cs == 100:
                     assert n_mapped == 0, line            # windows are whole pages of their own: these chunks all go through the ring
@@ -372,6 +372,7 @@ def test_slot_files_in_the_page_cache_are_uploaded_straight_from_a_mapping(pkg, 
             ctx.set_ingest_mapped(-1)
             ctx.set_ingest(0, 0, 0)
         # evicted from the page cache: nothing is resident, the ring reads it; same root
+        ctx.set_ingest_mapped(1)
         base = str(tmp_path / "f2048_")
         for k in range(3):
             fd = os.open("%s%d.dat" % (base, k), os.O_RDONLY)
@@ -393,6 +394,12 @@ def test_slot_files_in_the_page_cache_are_uploaded_straight_from_a_mapping(pkg, 
         ds = ctx.dataset(cfg)
         assert np.array_equal(ds.local_roots()[0], ctx.slot_trees_host(cells, 1, 2048, 65536, 1 << 16).roots()[0])
         assert np.array_equal(ds.local_roots()[1:], want[1:])
+        ds.free()
+        # left alone (-1, no CP2_INGEST_MAPPED in the environment) the ring carries everything: mapping is opt-in
+        ctx.set_ingest_mapped(-1)
+        capfd.readouterr()
+        ds = ctx.dataset(cfg)
+        assert "slot files: 0 chunk(s) from the page cache by mapping" in capfd.readouterr().err
         ds.free()
         ctx.close()
     finally:

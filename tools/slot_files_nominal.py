@@ -37,7 +37,7 @@ try:
     hexroot = lambda a: np.asarray(a, dtype=np.uint8).tobytes()[::-1].hex()      # noqa: E731
     res = {}
     os.environ["CP2_TRACE"] = "1"                                   # the library says how many chunks went by mapping / through the ring
-    for label, evict, direct in (("page_cache", False, 0), ("page_cache_ring_only", False, 0), ("page_cache_again", False, 0),
+    for label, evict, direct in (("page_cache", False, 0), ("page_cache_mapped", False, 0), ("page_cache_again", False, 0), ("page_cache_mapped_again", False, 0),
                                  ("evicted_buffered", True, 0), ("evicted_o_direct", True, 1)):
         if evict:
             for k in range(n_slots):
@@ -46,7 +46,7 @@ try:
                 os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
                 os.close(fd)
         ctx.set_ingest_direct(direct)
-        ctx.set_ingest_mapped(0 if label == "page_cache_ring_only" else -1)
+        ctx.set_ingest_mapped(1 if "mapped" in label else -1)
         t = time.time()
         ds = ctx.dataset(cfg)
         dt = time.time() - t
