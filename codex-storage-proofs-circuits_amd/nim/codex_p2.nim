@@ -327,6 +327,11 @@ proc engineSetIngestDirect*(on: bool) =
   ## SlotFile source: O_DIRECT reads of slot files that are not in the page cache
   for c in contexts(): check(cp2_set_ingest_direct(c, cint(ord(on))), "cp2_set_ingest_direct")
 
+proc engineSetIngestMapped*(on: bool) =
+  ## SlotFile source, opt-in: chunks of slot files that sit in the page cache are uploaded from registered windows of the file's
+  ## mapping instead of being copied into the pinned ring by host threads (same throughput on one device, fewer busy cores)
+  for c in contexts(): check(cp2_set_ingest_mapped(c, cint(ord(on))), "cp2_set_ingest_mapped")
+
 proc engineSetKeepTrees*(mode: int) =
   ## what a dataset keeps of its slot trees in device memory: 1 every node; 2 compact (block roots and up, the bottom of a path
   ## recomputed from the touched blocks); 0 roots only (the proved slot's tree is rebuilt on demand); -1 the most that fits
