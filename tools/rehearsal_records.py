@@ -12,6 +12,8 @@ what = {"clean": "no fault", "rank_exit": "BENCH_INJECT=rank_exit: rank 1 dies (
         "rank_hang": "BENCH_INJECT=rank_hang: rank 1 hangs at the start of the dataset leg",
         "gather_error": "BENCH_INJECT=gather_error: rank 1 raises right where the others enter the all-gather of slot roots",
         "child_hang": "BENCH_INJECT=child_hang: the first child process of the in-process leg (RCCL by name) never returns",
+        "clean4": "no fault, 4 ranks on the one GPU (python bench.py --gpus 4)",
+        "torchrun_clean4": "no fault, 4 ranks on the one GPU under `python -m torch.distributed.run --nproc-per-node 4` (the driver's launcher)",
         "torchrun_rank_exit": "BENCH_INJECT=rank_exit under `python -m torch.distributed.run --nproc-per-node 2` (the driver's launcher): torchrun ends rank 0 with SIGTERM"}
 times = {}
 for l in open(os.path.join(O, "times.txt")):
@@ -30,7 +32,10 @@ for case, (rc, wall) in times.items():
     rec = {"round": R, "case": case, "what": what.get(case, case), "bench_py_commit": commit,
            "setup": "ONE MI355X: BENCH_SHARE_GPU=1 BENCH_BACKEND=gloo (2 ranks on GPU 0, gloo carries the collectives: RCCL refuses two ranks per device); --steps 5 --warmup 2; tools/rehearse_bench.sh",
            "exit_code": rc, "wall_s": wall, "json_lines_on_stdout": len(lines), "line": line}
-    name = "%s_bench_2rank_%s.json" % (R, "clean" if case == "clean" else "inject_" + case)
+    four = case.endswith("clean4")
+    if four:
+        rec["setup"] = rec["setup"].replace("2 ranks on GPU 0", "4 ranks on GPU 0")
+    name = "%s_bench_%s_%s.json" % (R, "4rank" if four else "2rank", case.replace("clean4", "clean") if four else ("clean" if case == "clean" else "inject_" + case))
     json.dump(rec, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
     e = (line or {}).get("extra", {})
     print(name, "rc", rc, "wall", wall, "| failures:", e.get("rank_failures"), "| aborted:", (e.get("bench_aborted") or {}).get("reason"))
