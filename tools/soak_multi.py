@@ -56,6 +56,10 @@ while time.time() - t0 < budget:
             C.gen_fake_cells(C.slot_seed(c["seed"], k), 0, nc, cs).tofile("%s%d.dat" % (base, k))
         del cc["seed"]
         cc["file"] = base
+        mapped = int(rng.choice([-1, 0, 1, 1]))                # mapped ingestion of the (just written, so cached) files on the multi side, the ring on the other or the other way round
+        for i in range(m.count):
+            m.ctx(i).set_ingest_mapped(mapped)
+        single.set_ingest_mapped(int(rng.choice([0, 1])))
     cfg = pkg.make_config(**cc)
     kind = int(rng.integers(0, 3))                             # plain / streamed / cached (round 5: a streamed build cut by units is two-phase, same plan as the others)
     threads = int(rng.choice([1, 3, 8]))

@@ -41,6 +41,7 @@ while time.time() - t0 < budget:
         cc["file"] = base
     cfg = pkg.make_config(**cc)
     ctx.set_ingest(int(rng.choice([0, 1, 3])), int(rng.choice([0, 2, 4])), int(rng.choice([0, 1 << 16, 1 << 20])))
+    ctx.set_ingest_mapped(int(rng.choice([-1, 0, 1, 1])))      # slot files (just written: cached) by mapping or through the ring
     # bodies kept in memory up to a random budget (1 byte: every body spills; 50 KB: some do; 4 GiB: none does)
     ctx.set_body_budget(int(rng.choice([1, 50000, 4 << 30])), tmp)
     ref = ctx.dataset(cfg)
@@ -90,6 +91,7 @@ while time.time() - t0 < budget:
         print("iteration %d  bad=%d  maxrss %.0f MB  device free %.2f GiB (first reading %.2f)  %.0f s" %
               (it, bad, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024, free / 2**30, free0 / 2**30, time.time() - t0), flush=True)
 ctx.set_ingest(0, 0, 0)
+ctx.set_ingest_mapped(-1)
 ctx.set_body_budget(4 << 30, None)
 print("pipeline soak done: %d iterations, mismatches: %d, %.0f s" % (it, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
