@@ -405,16 +405,22 @@ struct IngestPipe {
 
   ~IngestPipe() {
     if (!ctx) return;
+    const bool trace = std::getenv("CP2_TRACE") != nullptr && (mapped_chunks + ring_chunks) > 0;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     (void)finish();
     (void)hipStreamSynchronize(ctx->stream);
     if (copy) (void)hipStreamSynchronize(copy);
+    const double t1 = now();
     for (auto& mp : mappings) mp.open = false;
     (void)release_mapped();
+    const double t2 = now();
     for (int b = 0; b < depth; ++b) {
       if (copied[b]) (void)hipEventDestroy(copied[b]);
       if (hashed[b]) (void)hipEventDestroy(hashed[b]);
     }
     if (copy) (void)hipStreamDestroy(copy);
+    if (trace) std::fprintf(stderr, "[cp2 trace] slot files: pipe torn down: drain %.1f ms, release %.1f ms, events + copy stream %.1f ms\n", t1 - t0, t2 - t1, now() - t2);
   }
   int init(cp2_ctx* c, size_t cell_size, size_t max_cells, bool direct_slack = false) {
     ctx = c;
@@ -523,10 +529,17 @@ struct IngestPipe {
       else ++i;
     }
     if (!done.empty()) {
+      // ... in pieces of 64 MiB: an unmap holds the process's address-space lock, which the runtime's own allocations, frees and
+      // registrations on the building thread need too; 0.07 ms at a time lets them in between
+      auto unmap_in_pieces = [](const std::vector<Mapping>& v) {
+        const size_t piece = (size_t)64 << 20;
+        for (auto& mp : v)
+          for (size_t at = 0; at < mp.len; at += piece) munmap(mp.base + at, std::min(piece, mp.len - at));
+      };
       try {
-        std::thread([done] { for (auto& mp : done) munmap(mp.base, mp.len); }).detach();
+        std::thread([done, unmap_in_pieces] { unmap_in_pieces(done); }).detach();
       } catch (...) {
-        for (auto& mp : done) munmap(mp.base, mp.len);
+        unmap_in_pieces(done);
       }
     }
     if (trace && n_windows)
@@ -642,7 +655,9 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
   {
     IngestPipe pipe;
     const bool want_direct = ctx->ingest_direct > 0 || (ctx->ingest_direct < 0 && env_size("CP2_INGEST_DIRECT", 0) != 0);
+    StageTimer init_trace;
     st = pipe.init(ctx, cell_size, n_cells, want_direct);
+    if (init_trace.on) init_trace.lap("slot files: pipe set up (ring, events, copy stream)");
     LayerScheduler sched{t.get(), group, done};
     if (st == CP2_OK) st = sched.init();
     // O_DIRECT (cp2_set_ingest_direct / CP2_INGEST_DIRECT=1): slot files that are not in the page cache are read straight into
