@@ -321,15 +321,26 @@ extern "C" int cp2_permute_batch_dev(cp2_ctx* ctx, const void* d_in, void* d_out
 }
 
 // Host arrays through the GPU in chunks: out[i] = kernel(in[i]) for n items.  Three stages on three streams over a
-// 3-deep ring of pinned + device buffers -- upload of chunk i+1, kernel of chunk i and download of chunk i-1 overlap
+// 4-deep ring of pinned + device buffers -- upload of chunk i+1, kernel of chunk i and download of chunk i-1 overlap
 // (PCIe is full duplex), and a few host threads copy between the caller's pageable arrays and the pinned ring.
-// Small inputs take one upload / launch / download on the context's stream with pooled scratch.
+// Arrays the caller has pinned (hipHostMalloc, hipHostRegister) skip the ring and the copies: the copy engines work on them
+// in place.  Small inputs take one upload / launch / download on the context's stream with pooled scratch.
 namespace {
+// is p..p+bytes host memory the runtime can DMA from / to directly (hipHostMalloc'ed or hipHostRegister'ed by the caller)?
+static bool host_pinned(const void* p) {
+  hipPointerAttribute_t a{};
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeHost;
+}
 template <typename Launch>
 int stream_map(cp2_ctx* ctx, const uint8_t* in, size_t in_item, uint8_t* out, size_t out_item, size_t n, Launch launch) {
-  constexpr size_t CHUNK = (size_t)1 << 20;   // items per chunk: 4096 workgroups, several residencies of any kernel here
-  constexpr int DEPTH = 3;
-  if (n <= CHUNK) {
+  constexpr int MAX_DEPTH = 4;
+  // items per chunk and ring depth: swept on 2^24 states (profiles/r05_host_array_sweep.txt): 2^18 x 4 is the fastest cell of the table at
+  // 8 and 16 copy threads (38 ms against 44-48 ms for round 4's 2^20 x 3); deeper rings are slower (more pinned memory in flight
+  // for the copy threads and both DMA directions to share)
+  constexpr size_t CHUNK = (size_t)1 << 18;
+  constexpr int DEPTH = 4;
+  if (n <= ((size_t)1 << 20)) {
     DevBuf d_in, d_out;
     CP2_TRY(d_in.scratch(ctx, n * in_item));
     CP2_TRY(d_out.scratch(ctx, n * out_item));
@@ -342,14 +353,14 @@ int stream_map(cp2_ctx* ctx, const uint8_t* in, size_t in_item, uint8_t* out, si
   struct Ring {
     cp2_ctx* ctx;
     hipStream_t up = nullptr, down = nullptr;
-    hipEvent_t e_up[DEPTH] = {}, e_k[DEPTH] = {}, e_down[DEPTH] = {};
-    PinBuf pin_in[DEPTH], pin_out[DEPTH];
-    DevBuf d_in[DEPTH], d_out[DEPTH];
+    hipEvent_t e_up[MAX_DEPTH] = {}, e_k[MAX_DEPTH] = {}, e_down[MAX_DEPTH] = {};
+    PinBuf pin_in[MAX_DEPTH], pin_out[MAX_DEPTH];
+    DevBuf d_in[MAX_DEPTH], d_out[MAX_DEPTH];
     ~Ring() {   // drain everything before the buffers go back to the pools
       if (up) (void)hipStreamSynchronize(up);
       (void)hipStreamSynchronize(ctx->stream);
       if (down) (void)hipStreamSynchronize(down);
-      for (int r = 0; r < DEPTH; ++r) {
+      for (int r = 0; r < MAX_DEPTH; ++r) {
         if (e_up[r]) (void)hipEventDestroy(e_up[r]);
         if (e_k[r]) (void)hipEventDestroy(e_k[r]);
         if (e_down[r]) (void)hipEventDestroy(e_down[r]);
@@ -360,14 +371,43 @@ int stream_map(cp2_ctx* ctx, const uint8_t* in, size_t in_item, uint8_t* out, si
   } ring{ctx};
   CP2_HIP(ctx, hipStreamCreateWithFlags(&ring.up, hipStreamNonBlocking));
   CP2_HIP(ctx, hipStreamCreateWithFlags(&ring.down, hipStreamNonBlocking));
+  const bool trace = std::getenv("CP2_TRACE") != nullptr;
+  // the caller's arrays are pinned (hipHostMalloc / hipHostRegister): the copy engines read and write them in place -- no pinned
+  // ring, no host thread copies; chunks of 2^20 items, every dependency a device-side event wait, one host wait at the end
+  const bool direct = host_pinned(in) && host_pinned(in + (n - 1) * in_item) && host_pinned(out) && host_pinned(out + (n - 1) * out_item);
+  const size_t chunk = direct ? (size_t)1 << 20 : CHUNK;
   for (int r = 0; r < DEPTH; ++r) {
     CP2_HIP(ctx, hipEventCreateWithFlags(&ring.e_up[r], hipEventDisableTiming));
     CP2_HIP(ctx, hipEventCreateWithFlags(&ring.e_k[r], hipEventDisableTiming));
     CP2_HIP(ctx, hipEventCreateWithFlags(&ring.e_down[r], hipEventDisableTiming));
-    CP2_TRY(ring.pin_in[r].alloc(ctx, CHUNK * in_item));
-    CP2_TRY(ring.pin_out[r].alloc(ctx, CHUNK * out_item));
-    CP2_TRY(ring.d_in[r].scratch(ctx, CHUNK * in_item));
-    CP2_TRY(ring.d_out[r].scratch(ctx, CHUNK * out_item));
+    if (!direct) {
+      CP2_TRY(ring.pin_in[r].alloc(ctx, chunk * in_item));
+      CP2_TRY(ring.pin_out[r].alloc(ctx, chunk * out_item));
+    }
+    CP2_TRY(ring.d_in[r].scratch(ctx, chunk * in_item));
+    CP2_TRY(ring.d_out[r].scratch(ctx, chunk * out_item));
+  }
+  if (direct) {
+    const size_t n_chunks = (n + chunk - 1) / chunk;
+    for (size_t c = 0; c < n_chunks; ++c) {
+      const int r = (int)(c % DEPTH);
+      const size_t m = std::min(chunk, n - c * chunk);
+      if (c >= (size_t)DEPTH) {
+        CP2_HIP(ctx, hipStreamWaitEvent(ring.up, ring.e_k[r], 0));            // d_in[r] was read by the kernel of chunk c - DEPTH
+        CP2_HIP(ctx, hipStreamWaitEvent(ctx->stream, ring.e_down[r], 0));     // d_out[r] was downloaded
+      }
+      CP2_HIP(ctx, hipMemcpyAsync(ring.d_in[r].p, in + c * chunk * in_item, m * in_item, hipMemcpyHostToDevice, ring.up));
+      CP2_HIP(ctx, hipEventRecord(ring.e_up[r], ring.up));
+      CP2_HIP(ctx, hipStreamWaitEvent(ctx->stream, ring.e_up[r], 0));
+      CP2_HIP(ctx, launch(ring.d_in[r].p, ring.d_out[r].p, m, ctx->stream));
+      CP2_HIP(ctx, hipEventRecord(ring.e_k[r], ctx->stream));
+      CP2_HIP(ctx, hipStreamWaitEvent(ring.down, ring.e_k[r], 0));
+      CP2_HIP(ctx, hipMemcpyAsync(out + c * chunk * out_item, ring.d_out[r].p, m * out_item, hipMemcpyDeviceToHost, ring.down));
+      CP2_HIP(ctx, hipEventRecord(ring.e_down[r], ring.down));
+    }
+    CP2_HIP(ctx, hipStreamSynchronize(ring.down));
+    if (trace) std::fprintf(stderr, "[cp2 trace] stream_map %zu chunks straight from / to the caller's pinned arrays\n", n_chunks);
+    return CP2_OK;
   }
   const int threads = ctx->ingest_threads > 0 ? ctx->ingest_threads : 8;
   Workers pool(threads > 1 ? threads - 1 : 1);
@@ -378,7 +418,6 @@ int stream_map(cp2_ctx* ctx, const uint8_t* in, size_t in_item, uint8_t* out, si
     pool.wait_idle();
   };
   const size_t n_chunks = (n + CHUNK - 1) / CHUNK;
-  const bool trace = std::getenv("CP2_TRACE") != nullptr;
   double t_wait = 0, t_drain = 0, t_fill = 0, t_enq = 0;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   auto drain = [&](size_t c) -> int {   // chunk c's results from the pinned ring into the caller's array

@@ -131,7 +131,9 @@ int cp2_set_keep_trees(cp2_ctx* ctx, int mode);
 
 /* ---- a1: Poseidon2 t=3 permutation --------------------------------------------------------- */
 /* replaces nim-poseidon2 `perm` as specified by reference/haskell/src/Poseidon2/Permutation.hs:40-45.
- * in/out: n states of 3 field elements (n x 96 bytes). */
+ * in/out: n states of 3 field elements (n x 96 bytes).  Host arrays of more than 2^20 states stream through the device in
+ * chunks (upload, kernel and download overlapped); arrays the caller has pinned (hipHostMalloc, hipHostRegister) are read and
+ * written in place by the copy engines, pageable ones pass through a pinned ring filled by host threads. */
 int cp2_permute_batch(cp2_ctx* ctx, const uint8_t* in, uint8_t* out, size_t n);
 int cp2_permute_batch_dev(cp2_ctx* ctx, const void* d_in, void* d_out, size_t n);
 

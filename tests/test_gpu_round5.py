@@ -404,3 +404,40 @@ def test_slot_files_in_the_page_cache_are_uploaded_straight_from_a_mapping(pkg, 
         ctx.close()
     finally:
         del os.environ["CP2_TRACE"]
+
+
+def test_host_arrays_the_caller_pinned_go_through_without_the_ring(pkg, oracle, capfd):
+    """cp2_permute_batch / cp2_compress_pairs on host arrays (the reference's calling convention: Nim seqs): pageable arrays are copied
+    through a pinned ring by host threads; arrays the caller pinned (hipHostMalloc -- here torch pinned tensors) are read and written
+    in place by the copy engines.  Same results, checked against the C oracle on a sample; the trace says which way it went.  Sizes
+    above the 2^20 items of the single-launch path, ragged."""
+    import ctypes
+    import torch
+    C, _ = oracle
+    os.environ["CP2_TRACE"] = "1"
+    try:
+        ctx = pkg.Context(0)
+        n = (3 << 20) + 12345
+        rng = np.random.default_rng(55)
+        x = rng.integers(0, 256, size=(n, 96), dtype=np.uint8)
+        x[:, 31] &= 0x1f; x[:, 63] &= 0x1f; x[:, 95] &= 0x1f
+        capfd.readouterr()
+        y = ctx.permute_batch(x)
+        err = capfd.readouterr().err
+        assert "stream_map" in err and "straight from" not in err
+        xin = torch.from_numpy(x).pin_memory()
+        xout = torch.zeros_like(xin).pin_memory()
+        ctx._ck(ctx.L.cp2_permute_batch(ctx.h, ctypes.c_void_p(xin.data_ptr()), ctypes.c_void_p(xout.data_ptr()), n), "cp2_permute_batch")
+        err = capfd.readouterr().err
+        assert "straight from / to the caller's pinned arrays" in err, err
+        assert np.array_equal(xout.numpy(), y)
+        idx = np.concatenate([np.arange(64), rng.integers(0, n, size=512), np.arange(n - 64, n)])
+        assert np.array_equal(y[idx], C.permute_batch(x[idx], threads=4))
+        # one pinned, one not: the ring
+        out2 = np.zeros_like(x)
+        ctx._ck(ctx.L.cp2_permute_batch(ctx.h, ctypes.c_void_p(xin.data_ptr()), ctypes.c_void_p(out2.ctypes.data), n), "cp2_permute_batch")
+        err = capfd.readouterr().err
+        assert "straight from" not in err and np.array_equal(out2, y)
+        ctx.close()
+    finally:
+        os.environ.pop("CP2_TRACE", None)
