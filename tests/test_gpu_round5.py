@@ -417,7 +417,7 @@ def test_host_arrays_the_caller_pinned_go_through_without_the_ring(pkg, oracle, 
     os.environ["CP2_TRACE"] = "1"
     try:
         ctx = pkg.Context(0)
-        n = (3 << 20) + 12345
+        n = (5 << 20) + 12345                         # six chunks on the pinned path: its four device buffers are used again
         rng = np.random.default_rng(55)
         x = rng.integers(0, 256, size=(n, 96), dtype=np.uint8)
         x[:, 31] &= 0x1f; x[:, 63] &= 0x1f; x[:, 95] &= 0x1f
