@@ -84,6 +84,15 @@ while time.time() - t0 < budget:
         if not np.array_equal(y[idx], C.permute_batch(x[idx], threads=4)):
             bad += 1
             print("MISMATCH host-array permute", n, flush=True)
+        if it % 20 == 0:         # the same through arrays the caller pinned (no ring, copy engines in place)
+            import ctypes
+            xin = torch.from_numpy(x).pin_memory()
+            xout = torch.zeros_like(xin).pin_memory()
+            ctx._ck(ctx.L.cp2_permute_batch(ctx.h, ctypes.c_void_p(xin.data_ptr()), ctypes.c_void_p(xout.data_ptr()), n), "cp2_permute_batch")
+            if not np.array_equal(xout.numpy(), y):
+                bad += 1
+                print("MISMATCH pinned host-array permute", n, flush=True)
+            del xin, xout
     if it % 20 == 0:
         free, total = torch.cuda.mem_get_info()
         if free0 is None:
