@@ -492,8 +492,9 @@ struct IngestPipe {
   // ---- mapped mode (round 5): chunks of a slot file that sit in the PAGE CACHE go to the device without a CPU copy.  The file is
   // mmap'ed read-only; a chunk whose pages are resident (mincore, sampled) is REGISTERED with the runtime (hipHostRegister pins the
   // page-cache pages themselves: 0.7-2.5 ms per 384 MiB, and it does not wait for the device) and uploaded straight from the
-  // mapping by the copy engine at the pinned H2D rate, 57 GB/s -- where pread into the pinned ring tops out at 37-38 GB/s on 4-8
-  // busy threads (tools/mmap_register_probe.cpp, profiles/r05_mmap_register_probe.txt).  Two things the probe found shape this:
+  // mapping by the copy engine -- no host thread copies, one pass over host memory instead of three (tools/mmap_register_probe.cpp,
+  // profiles/r05_mmap_register_probe.txt).  On one device the build is no faster than through the ring (the hash kernel bounds both:
+  // profiles/r05_slot_files_nominal.txt), hence opt-in.  Two things the probe found shape this:
   //   * hipHostUnregister waits for the whole DEVICE (409 ms beside a 418 ms kernel): unregistering per chunk serialised the pipe to
   //     18 GB/s.  So windows stay registered -- and their mappings mapped -- until the pipe ends (it synchronises there anyway), or
   //     until `mapped_budget` bytes are registered, when everything uploaded so far is released in one go (one bubble per budget).
