@@ -385,7 +385,10 @@ def test_slot_files_in_the_page_cache_are_uploaded_straight_from_a_mapping(pkg, 
         ds = ctx.dataset(cfg)
         err = capfd.readouterr().err
         assert np.array_equal(ds.local_roots(), want)
-        assert "slot files: 0 chunk(s) from the page cache by mapping" in err, err            # nothing was resident: the ring read it all
+        import subprocess
+        fs = subprocess.run(["stat", "-f", "-c", "%T", str(tmp_path)], capture_output=True, text=True).stdout.strip()
+        if fs not in ("tmpfs", "ramfs"):                                                      # (a memory file system has nothing to evict to)
+            assert "slot files: 0 chunk(s) from the page cache by mapping" in err, err        # nothing was resident: the ring read it all
         ds.free()
         # a short file: cells past its end read as zeros, whichever path carried the chunks before
         cells = C.gen_fake_cells(C.slot_seed(777, 0), 0, 1 << 16, 2048)
