@@ -344,6 +344,7 @@ def test_slot_files_in_the_page_cache_are_uploaded_straight_from_a_mapping(pkg, 
     chunk that reaches past its end."""
     C, _ = oracle
     os.environ["CP2_TRACE"] = "1"
+    forced = os.environ.pop("CP2_INGEST_MAPPED", None)      # (the suite is sometimes run with mapping forced on: this test sets the mode itself)
     try:
         ctx = pkg.Context(0)
         for cs, nc, n_slots in ((2048, 1 << 16, 3), (100, 1 << 12, 2)):
@@ -407,6 +408,8 @@ def test_slot_files_in_the_page_cache_are_uploaded_straight_from_a_mapping(pkg, 
         ctx.close()
     finally:
         del os.environ["CP2_TRACE"]
+        if forced is not None:
+            os.environ["CP2_INGEST_MAPPED"] = forced
 
 
 def test_host_arrays_the_caller_pinned_go_through_without_the_ring(pkg, oracle, capfd):
