@@ -496,25 +496,30 @@ static int hash_block_override() {
   return v;
 }
 
-hipError_t launch_hash_cells_block(int block, const void* cells, size_t cell_size, size_t n_cells, void* out, hipStream_t st) {
+// leave_room: 28 KiB of dynamic LDS nobody uses, so that TWO workgroups fit a CU instead of three.  The kernel itself loses under 1 %
+// (issue bound from two waves per SIMD up), and the third of every CU it no longer holds is where the small dependent kernels of the
+// streamed build -- a group's layer passes, its sampling and gathers -- run beside it: next to a launch that holds every workgroup
+// slot such a chain finishes only when the launch drains (tools/coresidency_probe.cpp, profiles/r05_coresidency_probe.txt).
+hipError_t launch_hash_cells_block(int block, const void* cells, size_t cell_size, size_t n_cells, void* out, hipStream_t st, bool leave_room) {
   if (block != 64 && block != 256) return hipErrorInvalidValue;
   if (block == 256) block = CP2_HASH_BT;
+  const unsigned dyn = leave_room ? 28672u : 0u;
   const size_t max_items = MAX_BLOCKS * (size_t)block;
   for (size_t i0 = 0; i0 < n_cells; i0 += max_items) {
     const size_t m = n_cells - i0 < max_items ? n_cells - i0 : max_items;
     const unsigned grid = (unsigned)((m + block - 1) / block);
     const uint8_t* src = (const uint8_t*)cells + i0 * cell_size;
     if (block == 64) CP2K_LAUNCH(k_hash_cells<64>, dim3(grid), dim3(64), 0, st, src, cell_size, m, (uint4*)out + 2 * i0);
-    else CP2K_LAUNCH(k_hash_cells<CP2_HASH_BT>, dim3(grid), dim3(CP2_HASH_BT), 0, st, src, cell_size, m, (uint4*)out + 2 * i0);
+    else CP2K_LAUNCH(k_hash_cells<CP2_HASH_BT>, dim3(grid), dim3(CP2_HASH_BT), dyn, st, src, cell_size, m, (uint4*)out + 2 * i0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
 }
 
-hipError_t launch_hash_cells(const void* cells, size_t cell_size, size_t n_cells, void* out, hipStream_t st) {
+hipError_t launch_hash_cells(const void* cells, size_t cell_size, size_t n_cells, void* out, hipStream_t st, bool leave_room) {
   const int block = hash_block_override();
-  return launch_hash_cells_block(block ? block : 256, cells, cell_size, n_cells, out, st);
+  return launch_hash_cells_block(block ? block : 256, cells, cell_size, n_cells, out, st, leave_room);
 }
 
 hipError_t launch_gen_fake_cells(uint64_t seed0, uint64_t cells_per_slot, uint64_t first, const uint64_t* list,

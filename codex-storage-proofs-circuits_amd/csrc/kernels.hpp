@@ -26,9 +26,9 @@ hipError_t launch_sponge2_felts(const void* felts, size_t nf, size_t nitems, voi
 // k_hash_cells runs 256-lane workgroups at every batch size.  The 64-lane instantiation was measured against it from 2 MiB to
 // 8 GiB (tools/hash_block_sweep.cpp, profiles/r03_hash_block_sweep.txt): identical up to 256 MiB -- a launch lasts at least
 // the lifetime of ONE wave, 34 serial permutations = 3.3 ms, whatever the workgroup shape -- and 5...25 % slower above.
-hipError_t launch_hash_cells(const void* cells, size_t cell_size, size_t n_cells, void* out, hipStream_t st);
+hipError_t launch_hash_cells(const void* cells, size_t cell_size, size_t n_cells, void* out, hipStream_t st, bool leave_room = false);   // leave_room: two workgroups per CU instead of three (kernels.hip)
 // the same with the workgroup size given (64 or 256): measurement tooling only
-hipError_t launch_hash_cells_block(int block, const void* cells, size_t cell_size, size_t n_cells, void* out, hipStream_t st);
+hipError_t launch_hash_cells_block(int block, const void* cells, size_t cell_size, size_t n_cells, void* out, hipStream_t st, bool leave_room = false);
 // cells_per_slot == 0: one slot with seed `seed0`; otherwise global cell g belongs to slot g / cells_per_slot
 // whose seed is seed0 + 1001 * slot.  list (device, may be NULL) selects explicit global cells.
 // units_per_slot > 1: slots cut into units of `cells_per_slot` cells each (batch-local unit g / cells_per_slot is unit

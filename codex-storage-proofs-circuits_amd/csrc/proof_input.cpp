@@ -1214,7 +1214,7 @@ extern "C" int cp2_dataset_export_proof_inputs(cp2_dataset* ds, const uint64_t* 
 namespace {
 
 struct StreamRing {
-  static constexpr int DEPTH = 3;
+  static constexpr int DEPTH = 4;            // pass k being enqueued, k - 1 waiting for its group's hashing (two chunks are in flight), k - 2 landing, k - 3 being formatted
   SampleHost host[DEPTH];
   hipEvent_t landed[DEPTH] = {};
   size_t s0[DEPTH] = {}, s1[DEPTH] = {};   // slot range parked in host[r]
@@ -1354,8 +1354,10 @@ static int build_streamed_in_mode(cp2_ctx* ctx, const cp2_config* cfg, uint64_t 
         ring.s0[r] = slot_base + g0;                           // dataset-local slot indices (bodies, file names); g0 counts inside `t`
         ring.s1[r] = slot_base + g1;
         ++n_groups;
-        // the pass before this one has had a whole group's hashing time to land: hand it out now
-        while (consumed + 1 < n_groups) { CP2_TRY(consume(consumed)); ++consumed; }
+        // Two chunks are hashed at a time (one per hashing stream), so the pass before this one still waits for its group's
+        // hashing: waiting for it here would keep the builder from enqueueing the next chunk until then.  The pass before THAT
+        // has landed or is about to: hand it out.
+        while (consumed + (stream_serial() ? 1 : 2) < n_groups) { CP2_TRY(consume(consumed)); ++consumed; }
       }
       return CP2_OK;
     };
@@ -1396,10 +1398,10 @@ static int build_streamed_in_mode(cp2_ctx* ctx, const cp2_config* cfg, uint64_t 
         }
       } else {
         // Fake data: the batches PIPELINE (BuildScratch: two node buffers used alternately, nothing synchronised per batch).  A
-        // batch's tail -- the layer passes of its last group on the second stream, that group's sampling, gathers and downloads
-        // on the third, the copy-out of what is kept -- runs while the next batch's generation and hashing already occupy the
-        // first stream (round 4 drained the device here: 816 s against 806 s for the roots alone over 32 TiB).  Node buffer b
-        // goes to batch k + 2 once batch k's copy-out (second stream) and last sampling (third stream) have completed.
+        // batch's tail -- the layer passes of its last group, that group's sampling, gathers and downloads, the copy-out of what
+        // is kept: all on the third stream -- runs while the next batch's generation and hashing already occupy the two hashing
+        // streams (round 4 drained the device here: 816 s against 806 s for the roots alone over 32 TiB).  Node buffer b goes to
+        // batch k + 2 once batch k's copy-out and last sampling have completed.
         BuildScratch scratch;                                    // drains the context's streams before its buffers go
         hipStream_t layer_stream = nullptr;
         if (st == CP2_OK) st = aux_stream(ctx, &layer_stream, 1);
@@ -1419,6 +1421,7 @@ static int build_streamed_in_mode(cp2_ctx* ctx, const cp2_config* cfg, uint64_t 
           have_geom = false;                                     // node offsets are those of THIS batch's layout
           cp2_slot_trees* t = nullptr;
           st = trees_build_fake(ctx, cfgv.seed, first_slot + base, nb, cfgv.cell_size, cfgv.block_size, cfgv.n_cells, group_slots, on_done, &t, 1, true, &scratch, b);
+          layer_stream = scratch.tail_stream ? scratch.tail_stream : layer_stream;         // where the builder put the batch's layer passes (the third stream)
           if (st == CP2_OK) st = dataset_keep_from_batch(dsp, t, base, layer_stream);     // follows the batch's last layer pass on that stream
           if (st == CP2_OK && (hipEventRecord(sampled[b], aux) != hipSuccess || hipStreamWaitEvent(layer_stream, sampled[b], 0) != hipSuccess ||
                                hipEventRecord(done_ev[b], layer_stream) != hipSuccess)) {

@@ -160,9 +160,19 @@ static int trees_build_layers(cp2_slot_trees* t, size_t s0, size_t s1, hipStream
 // stream): consecutive kernels of one stream leave the GPU half empty while the last workgroups of one retire and the
 // next has not started, and with two streams the next chunk's workgroups take the freed CUs at once (ingestion: +7...15 %,
 // profiles/r02_ingest_scaling.txt; fake-data build of 4096 slots: -0.9 %).  With GROUPS (the streamed proof-input path) the
-// fake builder hashes on the context's stream only and the group's layer passes go to the second stream: those small
-// launches, each as long as one permutation chain (~0.1 ms), hide behind the next group's hashing, and groups complete one
-// after the other (two chunks in flight finish together and leave twice the formatting work for the end: +1.8 % measured).
+// group's layer passes -- small launches, each as long as one permutation chain (~0.1 ms) -- and whatever the caller's hook
+// enqueues behind them go to the context's THIRD stream (on a hashing stream they would hold back the chunks queued behind them
+// until the group's last chunk, hashed on the other stream, has finished), and the fake builder's hash launches leave a third
+// of every CU free (launch_hash_cells' leave_room): next to a launch that holds every workgroup slot, a chain of small dependent
+// kernels finishes only when that launch drains.  Rounds 2-4 hashed groups on the first stream alone, one launch after the
+// other, every launch's tail exposed (43 GB/s per launch against 47 with two in flight); round 5's A/B on one box, configs[3]
+// streamed: serial 0.858 s, two streams 0.837 s, two streams with room left 0.813 s (the plain tree build: 0.791 s).
+// CP2_STREAM_SERIAL=1 (A/B tooling) restores the serial order at full occupancy.
+bool cp2i::stream_serial() {
+  static const bool v = [] { const char* e = std::getenv("CP2_STREAM_SERIAL"); return e && e[0] == '1'; }();
+  return v;
+}
+
 namespace {
 struct LayerScheduler {
   cp2_slot_trees* t;
@@ -173,14 +183,15 @@ struct LayerScheduler {
   hipStream_t hs[2] = {nullptr, nullptr};
   hipEvent_t ev[2] = {nullptr, nullptr};     // the latest hashing enqueued on each stream
   bool detached = false;                     // pipelined batches (BuildScratch): nothing is waited for here, the pipeline's owner does
-  hipStream_t tail = nullptr;                // detached, no groups: the layer passes go to the context's THIRD stream -- the first stream must not
-                                             // wait for the last chunk of this batch (hashed on the second), or nothing could overlap that chunk's
-                                             // tail: the next batch's first chunk is queued on the first stream and runs beside it instead
+  hipStream_t tail = nullptr;                // detached or groups: the layer passes go to the context's THIRD stream -- a hashing stream must not
+                                             // wait for a chunk hashed on the other one, or nothing could overlap that chunk's tail: the next
+                                             // chunk (or the next batch's first) is queued on it and runs beside that tail instead
   ~LayerScheduler() {
     for (int i = 0; i < 2; ++i) {
       if (hs[i] && !detached) (void)hipStreamSynchronize(hs[i]);
       if (ev[i]) (void)hipEventDestroy(ev[i]);   // (an event that is still pending is released once it has completed)
     }
+    if (tail && !detached) (void)hipStreamSynchronize(tail);
   }
   int init() {
     cp2_ctx* ctx = t->ctx;
@@ -190,11 +201,11 @@ struct LayerScheduler {
       CP2_HIP(ctx, hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
       CP2_HIP(ctx, hipEventRecord(ev[i], hs[i]));
     }
-    if (detached && !group) CP2_TRY(aux_stream(ctx, &tail, 2));
+    if (detached || group) CP2_TRY(aux_stream(ctx, &tail, 2));
     return CP2_OK;
   }
   // the stream this batch's layer passes (and whatever follows them: the hook, the caller's copy-out) are enqueued on
-  hipStream_t layer_stream() const { return tail ? tail : hs[group ? 1 : 0]; }
+  hipStream_t layer_stream() const { return tail ? tail : hs[0]; }
   // a chunk's hashing has just been enqueued on hs[s]
   int hashed_on(int s) {
     CP2_HIP(t->ctx, hipEventRecord(ev[s], hs[s]));
@@ -212,10 +223,9 @@ struct LayerScheduler {
       else if (final && avail) take = avail;
       if (!take) return CP2_OK;
       (void)s;
-      const int ts = group ? 1 : 0;             // groups: layer passes on the second stream; otherwise everything ends on the context's
-      hipStream_t ls = layer_stream();
-      if (tail) CP2_HIP(ctx, hipStreamWaitEvent(ls, ev[ts], 0));
-      CP2_HIP(ctx, hipStreamWaitEvent(ls, ev[1 - ts], 0));        // cells of these slots were (also) hashed on the other stream
+      hipStream_t ls = layer_stream();          // the third stream (groups, pipelined batches), else everything ends on the context's
+      if (tail) CP2_HIP(ctx, hipStreamWaitEvent(ls, ev[0], 0));
+      CP2_HIP(ctx, hipStreamWaitEvent(ls, ev[1], 0));            // cells of these slots were (also) hashed on the second stream
       CP2_TRY(trees_build_layers(t, built, built + take, ls));
       if (done) CP2_TRY(done(t, built, built + take, ls));
       built += take;
@@ -226,6 +236,7 @@ struct LayerScheduler {
     if (detached) return CP2_OK;
     CP2_HIP(ctx, hipStreamSynchronize(hs[0]));
     CP2_HIP(ctx, hipStreamSynchronize(hs[1]));
+    if (tail) CP2_HIP(ctx, hipStreamSynchronize(tail));
     return CP2_OK;
   }
 };
@@ -253,7 +264,7 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
   size_t chunk = std::max<size_t>(1, std::min(total_cells, ctx->stage_bytes / cell_size));
   if (chunk > n_cells) chunk -= chunk % n_cells;
   if (group && chunk > group * n_cells) chunk = group * n_cells;
-  const bool two = total_cells > chunk && group == 0;          // a second staging buffer only when chunks alternate between the streams
+  const bool two = total_cells > chunk;                        // chunks alternate between the two hashing streams, each with its own staging buffer          // a second staging buffer only when chunks alternate between the streams
   DevBuf own_stage[2];
   DevBuf* stage = scratch ? scratch->stage : own_stage;        // a pipeline's staging outlives this call (its last chunks may still be hashing)
   if (stage[0].bytes < chunk * cell_size) CP2_TRY(stage[0].scratch(ctx, chunk * cell_size));
@@ -272,6 +283,7 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
   const bool ramp = group && chunk >= n_cells && chunk % n_cells == 0 && !(ramp_env && ramp_env[0] == '0');
   const size_t g_slots = ramp ? chunk / n_cells : 0, g_min = ramp ? std::max<size_t>(1, std::min(g_slots, (size_t)768 * 256 / n_cells)) : 0;
   sched.take_all = ramp;
+  const bool serial = group != 0 && stream_serial();            // A/B tooling: groups hashed on the first stream only, as in rounds 2-4
   int st = sched.init();
   size_t turn = 0;
   for (size_t c0 = 0, n = 0; st == CP2_OK && c0 < total_cells; c0 += n, ++turn) {
@@ -280,9 +292,9 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
       const size_t left = (total_cells - c0) / n_cells;
       n = (left >= 2 * g_slots ? g_slots : (left > g_min ? std::max(g_min, (left + 1) / 2) : left)) * n_cells;
     }
-    const int s = group ? 0 : (int)(turn & 1);                 // generation + hashing of this chunk on stream s, in its own staging buffer
+    const int s = serial ? 0 : (int)(turn & 1);                 // generation + hashing of this chunk on stream s, in its own staging buffer
     hipError_t e = cp2k::launch_gen_fake_cells(seed0, n_cells, c0, nullptr, n, cell_size, stage[s].p, sched.hs[s], units_per_slot, first_slot);
-    if (e == hipSuccess) e = cp2k::launch_hash_cells(stage[s].p, cell_size, n, t->nodes.u8() + c0 * 32, sched.hs[s]);
+    if (e == hipSuccess) e = cp2k::launch_hash_cells(stage[s].p, cell_size, n, t->nodes.u8() + c0 * 32, sched.hs[s], group != 0 && !serial);
     if (e != hipSuccess) { ctx->err = hipGetErrorString(e); st = CP2_ERR_HIP; break; }
     st = sched.hashed_on(s);
     if (st == CP2_OK) st = sched.advance(c0 + n, c0 + n == total_cells, s);

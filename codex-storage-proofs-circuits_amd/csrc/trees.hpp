@@ -88,6 +88,8 @@ int kept_load(cp2_ctx* ctx, const char* path, const KeptMeta& want, void* d_buf,
 int dataset_own_roots_in_place(cp2_dataset* ds, bool* ok);
 
 // stage timings on stderr when CP2_TRACE is set (the reference's only tracing is shell `time`, workflow/prove.sh:30-37)
+bool stream_serial();   // CP2_STREAM_SERIAL=1 (A/B tooling): the streamed build hashes its groups one launch after the other, as rounds 2-4 did
+
 struct StageTimer {
   bool on;
   double t0;
