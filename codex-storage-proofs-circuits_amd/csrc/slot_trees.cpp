@@ -264,12 +264,6 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
   size_t chunk = std::max<size_t>(1, std::min(total_cells, ctx->stage_bytes / cell_size));
   if (chunk > n_cells) chunk -= chunk % n_cells;
   if (group && chunk > group * n_cells) chunk = group * n_cells;
-  const bool two = total_cells > chunk;                        // chunks alternate between the two hashing streams, each with its own staging buffer          // a second staging buffer only when chunks alternate between the streams
-  DevBuf own_stage[2];
-  DevBuf* stage = scratch ? scratch->stage : own_stage;        // a pipeline's staging outlives this call (its last chunks may still be hashing)
-  if (stage[0].bytes < chunk * cell_size) CP2_TRY(stage[0].scratch(ctx, chunk * cell_size));
-  if (two && stage[1].bytes < chunk * cell_size) CP2_TRY(stage[1].scratch(ctx, chunk * cell_size));
-  trace.lap("fake slots: node + staging buffers");
   // whole slots: the seed of the batch's first slot, the generator counts slots from there; units: the seed of slot 0 of the
   // dataset, the generator places unit first_slot + i inside slot (first_slot + i) / units_per_slot
   const uint64_t seed0 = cp2_slot_seed(dataset_seed, units_per_slot > 1 ? 0 : first_slot);
@@ -282,6 +276,14 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
   const char* ramp_env = std::getenv("CP2_STREAM_RAMP");                                                  // "0": A/B tooling
   const bool ramp = group && chunk >= n_cells && chunk % n_cells == 0 && !(ramp_env && ramp_env[0] == '0');
   const size_t g_slots = ramp ? chunk / n_cells : 0, g_min = ramp ? std::max<size_t>(1, std::min(g_slots, (size_t)768 * 256 / n_cells)) : 0;
+  // turns alternate between the two hashing streams, each with its own staging buffer: a second one whenever there is a second
+  // turn -- more cells than one chunk, or a ramp that cuts even a single chunk into several turns
+  const bool two = total_cells > chunk || (ramp && n_slots > g_min);
+  DevBuf own_stage[2];
+  DevBuf* stage = scratch ? scratch->stage : own_stage;        // a pipeline's staging outlives this call (its last chunks may still be hashing)
+  if (stage[0].bytes < chunk * cell_size) CP2_TRY(stage[0].scratch(ctx, chunk * cell_size));
+  if (two && stage[1].bytes < chunk * cell_size) CP2_TRY(stage[1].scratch(ctx, chunk * cell_size));
+  trace.lap("fake slots: node + staging buffers");
   sched.take_all = ramp;
   const bool serial = group != 0 && stream_serial();            // A/B tooling: groups hashed on the first stream only, as in rounds 2-4
   int st = sched.init();
@@ -292,7 +294,8 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
       const size_t left = (total_cells - c0) / n_cells;
       n = (left >= 2 * g_slots ? g_slots : (left > g_min ? std::max(g_min, (left + 1) / 2) : left)) * n_cells;
     }
-    const int s = serial ? 0 : (int)(turn & 1);                 // generation + hashing of this chunk on stream s, in its own staging buffer
+    const int s = (serial || !two) ? 0 : (int)(turn & 1);
+    if (!stage[s].p || stage[s].bytes < n * cell_size) { ctx->err = "fake builder: staging buffer missing for a turn"; st = CP2_ERR_INVALID; break; }   // (never: checked because a null one is a GPU fault)                 // generation + hashing of this chunk on stream s, in its own staging buffer
     hipError_t e = cp2k::launch_gen_fake_cells(seed0, n_cells, c0, nullptr, n, cell_size, stage[s].p, sched.hs[s], units_per_slot, first_slot);
     if (e == hipSuccess) e = cp2k::launch_hash_cells(stage[s].p, cell_size, n, t->nodes.u8() + c0 * 32, sched.hs[s], group != 0 && !serial);
     if (e != hipSuccess) { ctx->err = hipGetErrorString(e); st = CP2_ERR_HIP; break; }

@@ -447,3 +447,36 @@ def test_host_arrays_the_caller_pinned_go_through_without_the_ring(pkg, oracle, 
         ctx.close()
     finally:
         os.environ.pop("CP2_TRACE", None)
+
+
+@pytest.mark.parametrize("n_slots,n_cells,stage_mb", [(100, 1 << 12, 0), (61, 1 << 12, 0), (37, 1 << 13, 0), (64, 1 << 12, 96), (3, 1 << 17, 0)])
+def test_streamed_build_whose_single_chunk_the_ramp_cuts_into_several_turns(pkg, oracle, n_slots, n_cells, stage_mb):
+    """The streamed build hashes its groups alternately on two streams, each with its own staging buffer, and the ramp-down at the end
+    of the fake builder cuts even a dataset that fits ONE staging chunk into several turns once it holds more than one residency of the
+    hash kernel (768 x 256 cells): the second turn needs the second buffer.  (Round 5's soak found the case: a null staging pointer
+    is a GPU memory fault.)  Sizes between one residency and one chunk, an odd slot count, a small staging chunk (many turns), slots
+    larger than a residency: streamed text = object path on every slot, roots = C oracle on three."""
+    C, P = oracle
+    if stage_mb:
+        os.environ["CODEX_P2_STAGE_MB"] = str(stage_mb)
+    try:
+        ctx = pkg.Context(0)
+        c = dict(maxDepth=20, maxLog2NSlots=7, cellSize=2048, blockSize=65536, nSlots=n_slots, nCells=n_cells, nSamples=7, seed=4242 + n_slots)
+        cfg = pkg.make_config(**c)
+        ref = ctx.dataset(cfg)
+        for k in (0, n_slots // 2, n_slots - 1):
+            assert np.array_equal(ref.local_roots()[k], C.fake_slot_root(C.slot_seed(c["seed"], k), 2048, 65536, n_cells, 8)), k
+        for keep in (-1, 2, 0):
+            ctx.set_keep_trees(keep)
+            sd = ctx.dataset_streamed(cfg, 987654321, threads=4)
+            sd.set_roots(None)
+            sd.export_streamed(None, threads=4)
+            assert np.array_equal(sd.local_roots(), ref.local_roots()), keep
+            for s_ in range(n_slots):
+                assert sd.streamed_json(s_) == ref.proof_input(s_, 987654321).json(), (keep, s_)
+            sd.free()
+        ctx.set_keep_trees(-1)
+        ref.free()
+        ctx.close()
+    finally:
+        os.environ.pop("CODEX_P2_STAGE_MB", None)
