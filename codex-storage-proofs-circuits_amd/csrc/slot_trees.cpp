@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "trees.hpp"
+#include "fake_turns.hpp"
 
 using namespace cp2i;
 
@@ -259,43 +260,33 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
   StageTimer trace;
   if (scratch) scratch->ctx = ctx;
   CP2_TRY(trees_layout(t.get(), scratch ? &scratch->nodes[node_slot & 1] : nullptr));
-  const size_t total_cells = n_slots * n_cells;
-  // staging chunk: up to 2 GiB of generated cells, a whole number of slots when slots are smaller than that
-  size_t chunk = std::max<size_t>(1, std::min(total_cells, ctx->stage_bytes / cell_size));
-  if (chunk > n_cells) chunk -= chunk % n_cells;
-  if (group && chunk > group * n_cells) chunk = group * n_cells;
+  // how the batch is cut into turns -- staging chunks of up to 2 GiB, the ramp-down of the last groups, which of the two staging
+  // buffers a turn uses: csrc/fake_turns.hpp (plain arithmetic; the CPU suite walks it over thousands of shapes)
+  const char* ramp_env = std::getenv("CP2_STREAM_RAMP");                                                  // "0": A/B tooling
+  const FakeTurnPlan plan = fake_turn_plan(n_slots, n_cells, cell_size, ctx->stage_bytes, group, !(ramp_env && ramp_env[0] == '0'));
+  const size_t total_cells = plan.total_cells;
   // whole slots: the seed of the batch's first slot, the generator counts slots from there; units: the seed of slot 0 of the
   // dataset, the generator places unit first_slot + i inside slot (first_slot + i) / units_per_slot
   const uint64_t seed0 = cp2_slot_seed(dataset_seed, units_per_slot > 1 ? 0 : first_slot);
   LayerScheduler sched{t.get(), group, done};
   sched.detached = scratch != nullptr;        // (before init(): the choice of the layer stream depends on it)
-  // Groups (the streamed proof-input path): what follows a group on the host -- the JSON bodies of its slots -- overlaps the
-  // hashing of the NEXT group, so the last group's formatting overlaps nothing.  When a chunk is a whole number of slots the
-  // last groups are therefore halved down to one residency of the hash kernel (768 x 256 cells): 256, 256, ..., 128, 64, 48
-  // slots of 2^12 cells instead of a final 256, and the un-overlapped tail shrinks from ~50 ms of formatting to ~10.
-  const char* ramp_env = std::getenv("CP2_STREAM_RAMP");                                                  // "0": A/B tooling
-  const bool ramp = group && chunk >= n_cells && chunk % n_cells == 0 && !(ramp_env && ramp_env[0] == '0');
-  const size_t g_slots = ramp ? chunk / n_cells : 0, g_min = ramp ? std::max<size_t>(1, std::min(g_slots, (size_t)768 * 256 / n_cells)) : 0;
-  // turns alternate between the two hashing streams, each with its own staging buffer: a second one whenever there is a second
-  // turn -- more cells than one chunk, or a ramp that cuts even a single chunk into several turns
-  const bool two = total_cells > chunk || (ramp && n_slots > g_min);
   DevBuf own_stage[2];
   DevBuf* stage = scratch ? scratch->stage : own_stage;        // a pipeline's staging outlives this call (its last chunks may still be hashing)
-  if (stage[0].bytes < chunk * cell_size) CP2_TRY(stage[0].scratch(ctx, chunk * cell_size));
-  if (two && stage[1].bytes < chunk * cell_size) CP2_TRY(stage[1].scratch(ctx, chunk * cell_size));
+  if (stage[0].bytes < plan.chunk * cell_size) CP2_TRY(stage[0].scratch(ctx, plan.chunk * cell_size));
+  if (plan.two && stage[1].bytes < plan.chunk * cell_size) CP2_TRY(stage[1].scratch(ctx, plan.chunk * cell_size));
   trace.lap("fake slots: node + staging buffers");
-  sched.take_all = ramp;
+  sched.take_all = plan.ramp;
   const bool serial = group != 0 && stream_serial();            // A/B tooling: groups hashed on the first stream only, as in rounds 2-4
   int st = sched.init();
   size_t turn = 0;
   for (size_t c0 = 0, n = 0; st == CP2_OK && c0 < total_cells; c0 += n, ++turn) {
-    n = std::min(chunk, total_cells - c0);
-    if (ramp) {
-      const size_t left = (total_cells - c0) / n_cells;
-      n = (left >= 2 * g_slots ? g_slots : (left > g_min ? std::max(g_min, (left + 1) / 2) : left)) * n_cells;
+    n = fake_turn_cells(plan, n_cells, c0);
+    const int s = fake_turn_side(plan, turn, serial);           // generation + hashing of this turn on stream s, in its own staging buffer
+    if (n == 0 || !stage[s].p || stage[s].bytes < n * cell_size) {   // (never: checked because a null or short buffer is a GPU fault)
+      ctx->err = "fake builder: no staging buffer for a turn";
+      st = CP2_ERR_INVALID;
+      break;
     }
-    const int s = (serial || !two) ? 0 : (int)(turn & 1);
-    if (!stage[s].p || stage[s].bytes < n * cell_size) { ctx->err = "fake builder: staging buffer missing for a turn"; st = CP2_ERR_INVALID; break; }   // (never: checked because a null one is a GPU fault)                 // generation + hashing of this chunk on stream s, in its own staging buffer
     hipError_t e = cp2k::launch_gen_fake_cells(seed0, n_cells, c0, nullptr, n, cell_size, stage[s].p, sched.hs[s], units_per_slot, first_slot);
     if (e == hipSuccess) e = cp2k::launch_hash_cells(stage[s].p, cell_size, n, t->nodes.u8() + c0 * 32, sched.hs[s], group != 0 && !serial);
     if (e != hipSuccess) { ctx->err = hipGetErrorString(e); st = CP2_ERR_HIP; break; }
