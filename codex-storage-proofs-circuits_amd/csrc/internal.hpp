@@ -118,7 +118,7 @@ struct cp2_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipStream_t aux_stream = nullptr;   // second hashing stream: chunks alternate between `stream` and this one (created on first use)
-  hipStream_t aux2_stream = nullptr;  // sampling, gathers and downloads of the streamed proof-input path (created on first use)
+  hipStream_t aux2_stream = nullptr;  // third stream: the layer passes of groups / pipelined batches, sampling, gathers and downloads of the streamed proof-input path (created on first use)
   std::shared_ptr<cp2i::BlockPool> pool = std::make_shared<cp2i::BlockPool>();
   size_t stage_bytes = (size_t)1 << 31;   // device staging chunk of the fake-data builder
   int ingest_threads = 0, ingest_ring = 0;   // 0: CP2_INGEST_* environment or the built-in default (cp2_set_ingest)

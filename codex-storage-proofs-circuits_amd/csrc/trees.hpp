@@ -34,14 +34,14 @@ constexpr uint64_t NO_ROW = ~0ULL;
 
 // Called by the builders each time the trees of slots [s0, s1) (indices inside the batch) are complete ON STREAM `st`
 // (everything enqueued, nothing synchronised): the streamed proof-input path hangs its sampling / gather / download
-// of those slots on that stream while later slots are still hashing on the context's stream.
+// of those slots on that stream (the context's third) while later slots are still hashing on the other two.
 using SlotsDone = std::function<int(cp2_slot_trees* t, size_t s0, size_t s1, hipStream_t st)>;
 
 // Scratch that outlives one builder call, so that consecutive batches of a transient (compact / roots-only) build PIPELINE instead of
 // draining the device between them: two staging buffers for generated cells and two node buffers used alternately.  With it
 // trees_build_fake returns with its work ENQUEUED (nothing synchronised, the batch's nodes a borrowed view of nodes[node_slot]):
-// the next batch's generation and hashing start on the context's second stream while this batch's layer passes and copy-outs
-// still run on the first.  The owner waits for whatever reads nodes[b] before it hands slot b to another batch, and drains the
+// the next batch's generation and hashing start on the context's two hashing streams while this batch's layer passes and
+// copy-outs still run on the third.  The owner waits for whatever reads nodes[b] before it hands slot b to another batch, and drains the
 // context's streams before the scratch goes (its destructor does).
 struct BuildScratch {
   cp2_ctx* ctx = nullptr;
