@@ -10,6 +10,7 @@
 // All global-memory field elements are 32-byte little-endian canonical integers (the ABI format).
 #include "kernels.hpp"
 
+#include <atomic>
 #include <cstdlib>
 
 #include "poseidon2_dev.hpp"
@@ -503,7 +504,8 @@ static int hash_block_override() {
 hipError_t launch_hash_cells_block(int block, const void* cells, size_t cell_size, size_t n_cells, void* out, hipStream_t st, bool leave_room) {
   if (block != 64 && block != 256) return hipErrorInvalidValue;
   if (block == 256) block = CP2_HASH_BT;
-  const unsigned dyn = leave_room ? 28672u : 0u;
+  static std::atomic<bool> room_refused{false};   // a runtime that refuses the larger LDS request: full occupancy from then on (the room is a matter of speed only)
+  const unsigned dyn = (leave_room && !room_refused) ? 28672u : 0u;
   const size_t max_items = MAX_BLOCKS * (size_t)block;
   for (size_t i0 = 0; i0 < n_cells; i0 += max_items) {
     const size_t m = n_cells - i0 < max_items ? n_cells - i0 : max_items;
@@ -512,6 +514,11 @@ hipError_t launch_hash_cells_block(int block, const void* cells, size_t cell_siz
     if (block == 64) CP2K_LAUNCH(k_hash_cells<64>, dim3(grid), dim3(64), 0, st, src, cell_size, m, (uint4*)out + 2 * i0);
     else CP2K_LAUNCH(k_hash_cells<CP2_HASH_BT>, dim3(grid), dim3(CP2_HASH_BT), dyn, st, src, cell_size, m, (uint4*)out + 2 * i0);
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess && dyn && block != 64) {
+      room_refused = true;
+      CP2K_LAUNCH(k_hash_cells<CP2_HASH_BT>, dim3(grid), dim3(CP2_HASH_BT), 0, st, src, cell_size, m, (uint4*)out + 2 * i0);
+      e = hipGetLastError();
+    }
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
