@@ -15,6 +15,7 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION_MAJOR, ABI_VERSION_MINOR = 1, 0      # CP2_ABI_VERSION_* of the include/codex_p2.h this binding was written against (tests keep them equal)
 LIB_PATH = os.environ.get("CODEX_P2_LIB") or os.path.join(_HERE, "libcodex_p2.so")   # env override: kernel-variant A/B runs
 CLI_PATH = os.path.join(_HERE, "cli")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "codex_p2.h")
@@ -84,6 +85,19 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
     L = ctypes.CDLL(LIB_PATH)
+    # The entry points below are bound by name: the boundary's version is what tells a library built from another header
+    # (include/codex_p2.h, CP2_ABI_VERSION_*).  Another major, or a minor older than this binding's, is refused.
+    try:
+        L.cp2_abi_version.restype, L.cp2_abi_version.argtypes = ctypes.c_int, []
+        v = L.cp2_abi_version()
+    except AttributeError:
+        v = None
+    if v is None:
+        if not os.environ.get("CODEX_P2_LIB"):          # (A/B tooling may name an older library on purpose)
+            raise RuntimeError("%s predates the versioned boundary (no cp2_abi_version): rebuild it" % LIB_PATH)
+    elif (v >> 16) != ABI_VERSION_MAJOR or (v & 0xffff) < ABI_VERSION_MINOR:
+        raise RuntimeError("%s has ABI version %d.%d, this binding was written against %d.%d (include/codex_p2.h)" %
+                           (LIB_PATH, v >> 16, v & 0xffff, ABI_VERSION_MAJOR, ABI_VERSION_MINOR))
     vp, sz, u64, u32, i32, cp = (ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
                                  ctypes.c_char_p)
     pvp = ctypes.POINTER(ctypes.c_void_p)
@@ -97,6 +111,7 @@ def load_library():
         "cp2_last_error": (cp, [vp]),
         "cp2_device_is_native": (i32, [vp]),
         "cp2_check_environment": (i32, [cp, sz]),
+        "cp2_abi_version": (i32, []),
         "cp2_set_ingest": (i32, [vp, i32, i32, sz]),
         "cp2_set_ingest_direct": (i32, [vp, i32]),
         "cp2_set_ingest_mapped": (i32, [vp, i32]),

@@ -118,6 +118,8 @@ size_t dev_bytes_held() {
 
 }  // namespace cp2i
 
+extern "C" int cp2_abi_version(void) { return CP2_ABI_VERSION; }   // what THIS library was built from (include/codex_p2.h)
+
 // Host-only: every CODEX_P2_* variable holds what it takes, or the first one that does not is named in `msg`.
 extern "C" int cp2_check_environment(char* msg, size_t msg_len) try {
   auto fail = [&](const char* var, const char* takes) {
@@ -154,6 +156,7 @@ extern "C" int cp2_check_environment(char* msg, size_t msg_len) try {
   if (!env_decimal("CODEX_P2_SPLIT", &v, &set) || (set && v > 1 && (v & (v - 1)))) return fail("CODEX_P2_SPLIT", "0 (choose), 1 (whole slots) or a power of two (units per slot)");
   if (!env_decimal("CODEX_P2_MEM_LIMIT_MB", &v, &set)) return fail("CODEX_P2_MEM_LIMIT_MB", "a decimal number of MiB (0 = no cap)");
   if (!env_decimal("CODEX_P2_EXCHANGE_TIMEOUT_S", &v, &set)) return fail("CODEX_P2_EXCHANGE_TIMEOUT_S", "a decimal number of seconds (0 = wait for ever)");
+  if (!env_decimal("CODEX_P2_TEST_LDS_LIMIT", &v, &set)) return fail("CODEX_P2_TEST_LDS_LIMIT", "a decimal number of bytes (test hook: the LDS per workgroup cp2_init's launch-shape decision sees)");
   if (!env_decimal("CODEX_P2_STAGE_MB", &v, &set) || (set && (v < 1 || v > 65536))) return fail("CODEX_P2_STAGE_MB", "a decimal number of MiB between 1 and 65536");
   if (const char* e = std::getenv("CODEX_P2_GATHER"))
     if (*e && std::strcmp(e, "auto") && std::strcmp(e, "rccl") && std::strcmp(e, "host") && std::strcmp(e, "copy"))
@@ -198,9 +201,17 @@ extern "C" int cp2_init(int device, cp2_ctx** out) try {
     if (env_decimal("CODEX_P2_STAGE_MB", &mb, &set) && set) c->stage_bytes = (size_t)mb << 20;
   }
   trace.lap("context: stream");
-  if (trace.on) {   // tracing only: the code object is otherwise loaded by the first launch, inside that launch's time
-    (void)cp2k::load_code_object();
-    trace.lap("context: code object load");
+  {   // Can the hash kernel be launched two workgroups to a CU (the streamed builds' co-residency, kernels.hip)?  Decided here, once;
+      // CODEX_P2_TEST_LDS_LIMIT (test hook) caps the LDS per workgroup the decision sees, so that the "no" branch can be reached on gfx950.
+    uint64_t cap = 0;
+    bool set = false;
+    (void)env_decimal("CODEX_P2_TEST_LDS_LIMIT", &cap, &set);
+    std::string why;
+    c->hash_room = cp2k::hash_cells_can_leave_room(set ? (size_t)cap : 0, &why);
+    if (trace.on) {
+      std::fprintf(stderr, "[cp2 trace] context: hash launches beside the streamed builds' small kernels %s (%s)\n", c->hash_room ? "leave room: two workgroups per CU" : "hold every workgroup slot: no room", why.c_str());
+      trace.lap("context: code object load + launch shape");
+    }
   }
   *out = c;
   return CP2_OK;
@@ -213,6 +224,11 @@ extern "C" int cp2_init(int device, cp2_ctx** out) try {
 extern "C" void cp2_free(cp2_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->stuck) {        // its stream will not drain: nothing is waited for, nothing of it is handed back to the device (a stated leak)
+    ctx->pool->abandon();
+    delete ctx;
+    return;
+  }
   (void)hipStreamSynchronize(ctx->stream);
   for (hipStream_t st : {ctx->aux_stream, ctx->aux2_stream})
     if (st) {
@@ -246,6 +262,7 @@ extern "C" int cp2_reset_stream(cp2_ctx* ctx) try {
 
 extern "C" int cp2_sync(cp2_ctx* ctx) try {
   if (!ctx) return CP2_ERR_INVALID;
+  CP2_REFUSE_STUCK(ctx);
   CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return CP2_OK;
 } catch (const std::bad_alloc&) {
@@ -256,6 +273,7 @@ extern "C" int cp2_sync(cp2_ctx* ctx) try {
 
 extern "C" int cp2_trim(cp2_ctx* ctx) try {
   if (!ctx) return CP2_ERR_INVALID;
+  CP2_REFUSE_STUCK(ctx);
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   CP2_HIP(ctx, hipStreamSynchronize(ctx->stream));            // nothing in flight may still touch a cached block
   if (ctx->aux_stream) CP2_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
@@ -332,6 +350,15 @@ static bool host_pinned(const void* p) {
   if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
   return a.type == hipMemoryTypeHost;
 }
+// ... the whole range: probed at the start of every `step` bytes (one chunk of the direct path) and at its last byte, so an array
+// stitched together from several registrations with a pageable hole between them is not taken for pinned on the strength of its
+// two ends (a hole would still be copied correctly -- the runtime stages pageable memory itself -- only synchronously and slowly)
+static bool host_range_pinned(const uint8_t* p, size_t bytes, size_t step) {
+  if (bytes == 0) return false;
+  for (size_t at = 0; at < bytes; at += step)
+    if (!host_pinned(p + at)) return false;
+  return host_pinned(p + bytes - 1);
+}
 template <typename Launch>
 int stream_map(cp2_ctx* ctx, const uint8_t* in, size_t in_item, uint8_t* out, size_t out_item, size_t n, Launch launch) {
   constexpr int MAX_DEPTH = 4;
@@ -374,7 +401,7 @@ int stream_map(cp2_ctx* ctx, const uint8_t* in, size_t in_item, uint8_t* out, si
   const bool trace = std::getenv("CP2_TRACE") != nullptr;
   // the caller's arrays are pinned (hipHostMalloc / hipHostRegister): the copy engines read and write them in place -- no pinned
   // ring, no host thread copies; chunks of 2^20 items, every dependency a device-side event wait, one host wait at the end
-  const bool direct = host_pinned(in) && host_pinned(in + (n - 1) * in_item) && host_pinned(out) && host_pinned(out + (n - 1) * out_item);
+  const bool direct = host_range_pinned(in, n * in_item, ((size_t)1 << 20) * in_item) && host_range_pinned(out, n * out_item, ((size_t)1 << 20) * out_item);
   const size_t chunk = direct ? (size_t)1 << 20 : CHUNK;
   for (int r = 0; r < DEPTH; ++r) {
     CP2_HIP(ctx, hipEventCreateWithFlags(&ring.e_up[r], hipEventDisableTiming));

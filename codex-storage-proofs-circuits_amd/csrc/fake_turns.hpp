@@ -18,10 +18,13 @@ struct FakeTurnPlan {
   bool two = false;        // more than one turn: turns alternate between two staging buffers (and hashing streams)
 };
 
-// residency of k_hash_cells: 768 workgroups x 256 cells (what the ramp-down halves the last groups down to)
-constexpr size_t FAKE_RESIDENCY_CELLS = (size_t)768 * 256;
+// One residency of k_hash_cells -- what the ramp-down halves the last groups down to: 256 CUs x 3 workgroups x 256 cells at full
+// occupancy, x 2 workgroups when the launches leave room (group builds: launch_hash_cells' leave_room).  The builder passes the one
+// it launches with.
+constexpr size_t FAKE_RESIDENCY_CELLS = (size_t)768 * 256, FAKE_RESIDENCY_CELLS_WITH_ROOM = (size_t)512 * 256;
 
-inline FakeTurnPlan fake_turn_plan(size_t n_slots, size_t n_cells, size_t cell_size, size_t stage_bytes, size_t group, bool ramp_allowed) {
+inline FakeTurnPlan fake_turn_plan(size_t n_slots, size_t n_cells, size_t cell_size, size_t stage_bytes, size_t group, bool ramp_allowed,
+                                   size_t residency_cells = FAKE_RESIDENCY_CELLS) {
   FakeTurnPlan p;
   p.total_cells = n_slots * n_cells;
   // staging chunk: up to `stage_bytes` of generated cells, a whole number of slots when slots are smaller than that
@@ -34,7 +37,7 @@ inline FakeTurnPlan fake_turn_plan(size_t n_slots, size_t n_cells, size_t cell_s
   // instead of a final 256, and the un-overlapped tail shrinks from ~50 ms of formatting to ~10.
   p.ramp = group && ramp_allowed && p.chunk >= n_cells && p.chunk % n_cells == 0;
   p.g_slots = p.ramp ? p.chunk / n_cells : 0;
-  p.g_min = p.ramp ? std::max<size_t>(1, std::min(p.g_slots, FAKE_RESIDENCY_CELLS / n_cells)) : 0;
+  p.g_min = p.ramp ? std::max<size_t>(1, std::min(p.g_slots, std::max<size_t>(1, residency_cells) / n_cells)) : 0;
   // a second staging buffer whenever there is a second turn: more cells than one chunk, or a ramp that cuts even a single
   // chunk into several turns
   p.two = p.total_cells > p.chunk || (p.ramp && n_slots > p.g_min);

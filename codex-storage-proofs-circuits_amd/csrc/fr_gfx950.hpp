@@ -319,8 +319,8 @@ __device__ __forceinline__ Fe from_wide(const Wide& a) {
 // Table of (bias - q*N) rows lives in LDS (filled by qtab_fill): row q, 5 x 64 bits, bias = {2^58, 2^58-1, 2^58-1,
 // 2^58-1, -1} (sums to zero as a number, so  v + row(q) == v - q*N  with every limb 0..3 non-negative; the last
 // limb wraps modulo 2^64 and comes out right because the true result is non-negative).
-constexpr int QTAB_ROWS = 96;                // q <= 90 in the worst case of the internal rounds (poseidon2_dev.hpp); 96 rows keep
-                                             // k_hash_cells at 54 016 B of LDS per block, three blocks per CU
+constexpr int QTAB_ROWS = 96;                // q <= 90 in the worst case of the internal rounds (poseidon2_dev.hpp); 96 rows = 3 840 B, which
+                                             // with the 47-word line ring puts k_hash_cells at 51 968 B of LDS per block: three blocks per CU
 constexpr int QTAB_WORDS = QTAB_ROWS * NW;   // 64-bit words
 struct alignas(8) QTab {
   uint64_t row[QTAB_ROWS][NW];

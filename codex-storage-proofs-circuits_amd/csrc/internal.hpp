@@ -77,6 +77,7 @@ class BlockPool {
     if (!p) return;
     {
       std::lock_guard<std::mutex> lk(mu_);
+      if (dead_) return;
       size_t& cached = pinned ? cached_pin_ : cached_dev_;
       if (cached + bytes <= (pinned ? MAX_CACHED_PIN : MAX_CACHED_DEV)) {
         (pinned ? pin_ : dev_).push_back({p, bytes});
@@ -85,6 +86,14 @@ class BlockPool {
       }
     }
     if (pinned) (void)hipHostFree(p); else dev_free(p, bytes);
+  }
+  // the owning context's stream will not drain (cp2_ctx::stuck): cached blocks are forgotten, not freed (freeing device memory
+  // waits for the device), and blocks that come back later are dropped too
+  void abandon() {
+    std::lock_guard<std::mutex> lk(mu_);
+    dead_ = true;
+    dev_.clear(); pin_.clear();
+    cached_dev_ = cached_pin_ = 0;
   }
   void trim() {
     std::vector<Blk> d, h;
@@ -108,6 +117,7 @@ class BlockPool {
   std::mutex mu_;
   std::vector<Blk> dev_, pin_;
   size_t cached_dev_ = 0, cached_pin_ = 0;
+  bool dead_ = false;
 };
 
 }  // namespace cp2i
@@ -127,6 +137,9 @@ struct cp2_ctx {
   int ingest_direct = -1;                    // SlotFile reads with O_DIRECT: 1 on, 0 off, -1 = environment CP2_INGEST_DIRECT (cp2_set_ingest_direct)
   size_t body_budget = 0;                    // streamed proof-input bodies kept in host memory; 0: CP2_BODY_BUDGET_MB or 4 GiB (cp2_set_body_budget)
   size_t mem_allowance = 0;                  // device bytes this context may plan with in its automatic residency choice; 0: ask the device.  cp2_multi sets it for the duration of a build: what the device had free BEFORE its shards started, divided by the number of contexts placed on that device
+  bool stuck = false;                        // work that will not complete is queued on this context's stream (a multi-device exchange timed out): nothing waits
+                                             // for its streams any more -- pooled buffers are dropped from the books, builders refuse, cp2_free does not drain
+  bool hash_room = false;                    // this device takes k_hash_cells launches that leave a third of every CU free (decided once, by cp2_init: kernels.hip)
   int keep_trees = -1;                       // what cp2_dataset_build keeps of the slot trees in device memory: 1 every node, 2 block roots and up, 0 roots only, -1 = CODEX_P2_KEEP_TREES or the most that fits (cp2_set_keep_trees)
   std::string spill_dir;                     // where bodies beyond the budget go; empty: $TMPDIR or /tmp
   std::string err;
@@ -143,6 +156,15 @@ namespace cp2i {
     }                                                                                             \
   } while (0)
 
+// builders and synchronising entry points refuse a context whose stream will not drain (cp2_ctx::stuck) instead of waiting on it
+#define CP2_REFUSE_STUCK(ctx)                                                                                                  \
+  do {                                                                                                                         \
+    if ((ctx)->stuck) {                                                                                                        \
+      (ctx)->err = "this context takes no further work: a multi-device exchange timed out with work still queued on its stream"; \
+      return CP2_ERR_HIP;                                                                                                      \
+    }                                                                                                                          \
+  } while (0)
+
 #define CP2_TRY(call)                 \
   do {                                \
     int s__ = (call);                 \
@@ -155,6 +177,7 @@ struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
   cp2_ctx* owner = nullptr;   // non-null: pooled
+  cp2_ctx* home = nullptr;    // alloc(): the context the block was allocated for (a block of a stuck context is dropped, not freed: hipFree waits for the device)
   bool borrowed = false;      // a view of memory someone else owns (a batch's nodes inside a pipeline's scratch): never freed from here
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
@@ -168,18 +191,21 @@ struct DevBuf {
   }
   void release() {
     if (p && !borrowed) {
-      if (owner) {
+      if (owner && owner->stuck) {
+        // the context's stream will not drain: the block may still be touched by what is queued there -- it is dropped, not recycled
+      } else if (owner) {
         (void)hipStreamSynchronize(owner->stream);
         if (owner->aux_stream) (void)hipStreamSynchronize(owner->aux_stream);
         if (owner->aux2_stream) (void)hipStreamSynchronize(owner->aux2_stream);
         owner->pool->put(false, p, bytes);
-      } else {
+      } else if (!(home && home->stuck)) {
         dev_free(p, bytes);
       }
     }
     p = nullptr;
     bytes = 0;
     owner = nullptr;
+    home = nullptr;
     borrowed = false;
   }
   int alloc(cp2_ctx* ctx, size_t n) {
@@ -198,6 +224,7 @@ struct DevBuf {
       return CP2_ERR_ALLOC;
     }
     bytes = n;
+    home = ctx;
     return CP2_OK;
   }
   int scratch(cp2_ctx* ctx, size_t n) {

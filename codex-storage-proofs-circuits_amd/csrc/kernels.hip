@@ -10,8 +10,9 @@
 // All global-memory field elements are 32-byte little-endian canonical integers (the ABI format).
 #include "kernels.hpp"
 
-#include <atomic>
+#include <algorithm>
 #include <cstdlib>
+#include <string>
 
 #include "poseidon2_dev.hpp"
 
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(TPB) k_sponge2_felts(const uint4* __restrict__
 //
 // Staging: the stream is fetched in whole 128-byte lines, each exactly once.  Per stage a wave copies one
 // line of each of its 64 cells into a per-cell LDS ring: lane-linear dword loads, 32 consecutive lanes read
-// one full line (perfectly coalesced), and the ring row stride of 49 dwords is odd, so the per-lane reads
+// one full line (perfectly coalesced), and the ring row stride of 47 dwords is odd, so the per-lane reads
 // are bank-conflict free.  The sponge consumes 62 bytes per permutation, the producer adds 128 per stage,
 // so at most 60 bytes wait in the ring when the next line lands (what is left is even and below 62): 188 bytes, the ring's size.
 // A lane's 17-dword read window (68 bytes for 62) may run a few bytes past the valid data; chunk_pair uses 512 bits of it.  (The first
@@ -190,8 +191,8 @@ __device__ __forceinline__ void chunk_pair(const uint32_t (&w)[17], Fe& a, Fe& b
 // LDS allows three workgroups per CU = three waves per SIMD: tell the register allocator that is also the MOST it will
 // ever get, so that it uses the registers (up to 168) instead of squeezing the staging loops for an occupancy it cannot have
 //
-// BT = threads per workgroup: 256 (four waves share one reduction table: 54 016 B of LDS, three workgroups per CU; what the
-// product launches) or 64 (one wave per workgroup: 16 384 B, ten per CU; kept for tools/hash_block_sweep.cpp, which showed
+// BT = threads per workgroup: 256 (four waves share one reduction table: 51 968 B of LDS with the 47-word ring, three workgroups
+// per CU -- two when a launch leaves room; what the product launches) or 64 (one wave per workgroup: 16 384 B, ten per CU; kept for tools/hash_block_sweep.cpp, which showed
 // that the workgroup shape does not matter below 256 MiB and that 64 lanes lose above: profiles/r03_hash_block_sweep.txt).
 template <int BT>
 __global__ void __launch_bounds__(BT, CP2_HASH_WAVES) __attribute__((amdgpu_waves_per_eu(CP2_HASH_WAVES, CP2_HASH_WAVES))) k_hash_cells(const uint8_t* __restrict__ cells, size_t cell_size,
@@ -501,11 +502,40 @@ static int hash_block_override() {
 // (issue bound from two waves per SIMD up), and the third of every CU it no longer holds is where the small dependent kernels of the
 // streamed build -- a group's layer passes, its sampling and gathers -- run beside it: next to a launch that holds every workgroup
 // slot such a chain finishes only when the launch drains (tools/coresidency_probe.cpp, profiles/r05_coresidency_probe.txt).
+// Whether a device takes the larger request is decided ONCE, when a context is made on it (hash_cells_can_leave_room, called by
+// cp2_init; the callers pass leave_room only where it said yes): a launch is never retried, so an error at a launch is that launch's.
+constexpr unsigned HASH_ROOM_BYTES = 28672;
+
+bool hash_cells_can_leave_room(size_t lds_cap, std::string* why) {
+  int dev = 0, max_lds = 0;
+  hipFuncAttributes fa;
+  hipError_t e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+  if (e == hipSuccess) e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_hash_cells<CP2_HASH_BT>));
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (why) *why = std::string("the device could not be asked (") + hipGetErrorString(e) + ")";
+    return false;
+  }
+  const size_t limit = lds_cap ? std::min<size_t>(lds_cap, (size_t)max_lds) : (size_t)max_lds;
+  if (fa.sharedSizeBytes + HASH_ROOM_BYTES > limit) {
+    if (why) *why = "the kernel's " + std::to_string(fa.sharedSizeBytes) + " B of LDS + " + std::to_string(HASH_ROOM_BYTES) + " B exceed the " + std::to_string(limit) + " B a workgroup may hold";
+    return false;
+  }
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hash_cells<CP2_HASH_BT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HASH_ROOM_BYTES);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (why) *why = std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize) refused (") + hipGetErrorString(e) + ")";
+    return false;
+  }
+  if (why) *why = std::to_string(fa.sharedSizeBytes) + " + " + std::to_string(HASH_ROOM_BYTES) + " B of " + std::to_string(limit) + " B per workgroup";
+  return true;
+}
+
 hipError_t launch_hash_cells_block(int block, const void* cells, size_t cell_size, size_t n_cells, void* out, hipStream_t st, bool leave_room) {
   if (block != 64 && block != 256) return hipErrorInvalidValue;
   if (block == 256) block = CP2_HASH_BT;
-  static std::atomic<bool> room_refused{false};   // a runtime that refuses the larger LDS request: full occupancy from then on (the room is a matter of speed only)
-  const unsigned dyn = (leave_room && !room_refused) ? 28672u : 0u;
+  const unsigned dyn = (leave_room && block != 64) ? HASH_ROOM_BYTES : 0u;
   const size_t max_items = MAX_BLOCKS * (size_t)block;
   for (size_t i0 = 0; i0 < n_cells; i0 += max_items) {
     const size_t m = n_cells - i0 < max_items ? n_cells - i0 : max_items;
@@ -514,11 +544,6 @@ hipError_t launch_hash_cells_block(int block, const void* cells, size_t cell_siz
     if (block == 64) CP2K_LAUNCH(k_hash_cells<64>, dim3(grid), dim3(64), 0, st, src, cell_size, m, (uint4*)out + 2 * i0);
     else CP2K_LAUNCH(k_hash_cells<CP2_HASH_BT>, dim3(grid), dim3(CP2_HASH_BT), dyn, st, src, cell_size, m, (uint4*)out + 2 * i0);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess && dyn && block != 64) {
-      room_refused = true;
-      CP2K_LAUNCH(k_hash_cells<CP2_HASH_BT>, dim3(grid), dim3(CP2_HASH_BT), 0, st, src, cell_size, m, (uint4*)out + 2 * i0);
-      e = hipGetLastError();
-    }
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
@@ -546,13 +571,6 @@ hipError_t launch_sample_paths(const TreeGeom& g, const void* nodes, const void*
   CP2K_LAUNCH(k_sample_paths, dim3(grid_for(n_items * ns)), dim3(TPB), 0, st, g, (const uint4*)nodes, (const uint4*)d_entropy,
                      slots, slot0, n_items, ns, md, indices, gcell, rows);
   return hipGetLastError();
-}
-
-// Forces the code object of this library onto the current device without launching anything (what the first launch of a
-// process otherwise does implicitly): lets a trace show module loading apart from the first kernel's own time.
-hipError_t load_code_object() {
-  hipFuncAttributes a;
-  return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_permute_batch));
 }
 
 hipError_t launch_gather_rows(const void* src, const uint64_t* index, size_t nrows, size_t row_bytes, void* out, hipStream_t st) {

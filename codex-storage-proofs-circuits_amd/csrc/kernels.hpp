@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <string>
+
 namespace cp2k {
 
 // Kernel-argument copy of the layer-major node layout of a batch of slot trees (proof_input.cpp, trees_layout):
@@ -27,6 +29,10 @@ hipError_t launch_sponge2_felts(const void* felts, size_t nf, size_t nitems, voi
 // 8 GiB (tools/hash_block_sweep.cpp, profiles/r03_hash_block_sweep.txt): identical up to 256 MiB -- a launch lasts at least
 // the lifetime of ONE wave, 34 serial permutations = 3.3 ms, whatever the workgroup shape -- and 5...25 % slower above.
 hipError_t launch_hash_cells(const void* cells, size_t cell_size, size_t n_cells, void* out, hipStream_t st, bool leave_room = false);   // leave_room: two workgroups per CU instead of three (kernels.hip)
+// Can k_hash_cells be launched with leave_room on the CURRENT device?  Asked once per context (cp2_init): the device's LDS per
+// workgroup (never more than lds_cap when that is non-zero: test hook) must hold the kernel's own LDS plus the room, and the kernel's
+// dynamic-LDS ceiling is raised to the room.  *why says what was found either way.  A launch itself is never retried.
+bool hash_cells_can_leave_room(size_t lds_cap, std::string* why);
 // the same with the workgroup size given (64 or 256): measurement tooling only
 hipError_t launch_hash_cells_block(int block, const void* cells, size_t cell_size, size_t n_cells, void* out, hipStream_t st, bool leave_room = false);
 // cells_per_slot == 0: one slot with seed `seed0`; otherwise global cell g belongs to slot g / cells_per_slot
@@ -44,8 +50,6 @@ hipError_t launch_gen_fake_cells(uint64_t seed0, uint64_t cells_per_slot, uint64
 hipError_t launch_sample_paths(const TreeGeom& g, const void* nodes, const void* d_entropy, const uint64_t* slots, uint64_t slot0,
                                size_t n_items, uint32_t ns, uint32_t md, uint64_t* indices, uint64_t* gcell, uint64_t* rows,
                                hipStream_t st);
-// load this library's code object on the current device now (tracing only; launches do it implicitly)
-hipError_t load_code_object();
 hipError_t launch_gather_rows(const void* src, const uint64_t* index, size_t nrows, size_t row_bytes, void* out,
                               hipStream_t st);
 

@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "trees.hpp"
+#include "exchange_policy.hpp"
 
 using namespace cp2i;
 
@@ -304,6 +305,8 @@ struct Exchanged {
   std::vector<const void*> dev;
   std::vector<uint8_t> host;
   bool on_device = false;
+  bool timed_out = false;   // the exchange was given up with work still queued on the participating streams: NOT a failed or mis-verified
+                            // exchange -- nothing more may be enqueued on those streams (a retry through host memory would wait on them for ever)
   // work that may still be reading or writing these buffers could not be waited for (it timed out): they must never go back to
   // a pool or to the device's allocator -- they are dropped from the books instead (a leak, said so in the error message)
   void abandon() {
@@ -348,7 +351,11 @@ struct ExchangeGuard {
   bool done = false;                   // set on the success path, which drains (and checks) by itself
   ~ExchangeGuard() {
     if (done) return;
-    if (!drain_streams(parts, timeout_s)) ex.abandon();
+    if (!drain_streams(parts, timeout_s)) {
+      ex.abandon();
+      ex.timed_out = true;
+      for (auto& p : parts) p.ctx->stuck = true;
+    }
   }
 };
 
@@ -502,13 +509,25 @@ int exchange_roots(cp2_multi* m, const std::vector<RootsPart>& parts, uint64_t n
           CP2_HIP(ctx, hipMemsetAsync(const_cast<uint8_t*>(static_cast<const uint8_t*>(ex.dev[i])) + 5, 0x5a, 1, ctx->stream));
         }
     }
+    if (const char* fault = std::getenv("CODEX_P2_TEST_EXCHANGE_FAULT")) {
+      // test-only: a collective that does not complete in time -- a host function that sleeps for the time-out and five seconds more on
+      // every participating stream (bounded: the streams do drain in the end, the device itself is never made to spin)
+      if (std::strcmp(fault, "hang_collective") == 0)
+        for (auto& p : parts) {
+          CP2_HIP(p.ctx, hipSetDevice(p.ctx->device));
+          CP2_HIP(p.ctx, hipLaunchHostFunc(p.ctx->stream, [](void* ms) { std::this_thread::sleep_for(std::chrono::milliseconds((long)(intptr_t)ms)); },
+                                           reinterpret_cast<void*>((intptr_t)((timeout_s > 0 ? timeout_s : 1) * 1000 + 5000))));
+        }
+    }
     // the exchange is COMPLETE when this returns: a context's buffers are read by its peers (RCCL kernels, peer copies), so none
     // of them may go back to its pool on the strength of its own stream alone
     if (!drain_streams(parts, timeout_s)) {
       ex.abandon();
+      ex.timed_out = true;
+      for (auto& p : parts) p.ctx->stuck = true;   // whatever is enqueued on these streams from now on waits behind the collective
       guard.done = true;
       m->err = "the exchange of slot roots (" + m->gather_note + ") did not complete within " + std::to_string((int)timeout_s) +
-               " s; its device buffers are abandoned (CODEX_P2_EXCHANGE_TIMEOUT_S, CODEX_P2_GATHER=host)";
+               " s; its device buffers are abandoned and the participating contexts take no further work (CODEX_P2_EXCHANGE_TIMEOUT_S, CODEX_P2_GATHER=host)";
       if (use_rccl) { Rccl::get().abandoned = true; Rccl::get().why = "an all-gather did not complete in time"; m->comms.clear(); m->comm_world = 0; }
       return CP2_ERR_HIP;
     }
@@ -547,7 +566,7 @@ int gather_roots_and_build_trees(cp2_multi_dataset* mds) {
     Exchanged ex;
     int st = exchange_roots(m, parts, mds->cfg.n_slots, ex, attempt == 1);
     if (st != CP2_OK) {
-      if (attempt == 0 && m->gather == CP2_GATHER_AUTO && world > 1 && st == CP2_ERR_HIP) {   // the device path broke: host memory carries 1 MiB just as well
+      if (exchange_may_retry_on_host(st, ex.timed_out, m->gather, world, attempt)) {   // the device path broke (NOT: timed out): host memory carries 1 MiB just as well
         const std::string first = m->err;
         m->err.clear();
         Exchanged ex2;
@@ -614,7 +633,7 @@ int gather_unit_roots_and_build_upper(cp2_multi_dataset* mds) {
     Exchanged ex;
     int st = exchange_roots(m, parts, n_units, ex, attempt == 1);
     if (st != CP2_OK) {
-      if (attempt == 0 && m->gather == CP2_GATHER_AUTO && parts.size() > 1 && st == CP2_ERR_HIP) { m->gather_note += " [failed: " + m->err + "]"; m->err.clear(); continue; }
+      if (exchange_may_retry_on_host(st, ex.timed_out, m->gather, parts.size(), attempt)) { m->gather_note += " [failed: " + m->err + "]"; m->err.clear(); continue; }
       return st;
     }
     CP2_HIP(ctx, hipSetDevice(ctx->device));

@@ -209,13 +209,13 @@ static int dataset_keep_from_batch(cp2_dataset* ds, const cp2_slot_trees* t, siz
 // compact / roots-only build: batches of at most ~1 GiB of nodes (transient_batch_slots: 4 slots of 8 GiB; at least one slot), every
 // batch a normal builder call; what the mode keeps is copied out, the rest is overwritten by the batch after next.
 //
-// Fake data: the batches PIPELINE (BuildScratch: two node buffers used alternately, staging that outlives a builder call, nothing
-// synchronised per batch).  A batch ends with its tree-layer passes -- 22 launches for 2^22-cell slots, the top 16 of them one lone
+// The batches PIPELINE, from either source (BuildScratch: two node buffers used alternately, staging -- or, for slot files, the whole
+// ingestion pipe -- that outlives a builder call, nothing synchronised per batch).  A batch ends with its tree-layer passes -- 22 launches for 2^22-cell slots, the top 16 of them one lone
 // permutation latency each -- and the copy-out of what is kept, all on the context's THIRD stream; the next batch's generation and
 // hashing go on alternating between the first two meanwhile, so the device does not drain between batches and the tail of a
 // batch's last hash launch has the next batch's first one beside it (round 4 synchronised and freed here).  Node buffer b is handed
-// to batch k + 2 once batch k's copy-out has completed (an event; long past by then).
-// Slot files: batch by batch as before -- the ingestion pipe owns its ring and drains it, and that path is bound by the storage.
+// to batch k + 2 once batch k's copy-out has completed (an event; long past by then).  (Until round 6 slot files went batch by batch, a new
+// pipe set up and drained for each: "bound by the storage" is true of cold files, not of files in the page cache.)
 static int dataset_build_transient(cp2_dataset* ds, int mode, bool allocated = false) {
   cp2_ctx* ctx = ds->ctx;
   const cp2_config& c = ds->cfg;
@@ -223,21 +223,6 @@ static int dataset_build_transient(cp2_dataset* ds, int mode, bool allocated = f
   if (!allocated) CP2_TRY(dataset_alloc_kept(ds, mode));
   const char* what = mode == 2 ? "compact" : "roots-only";
   StageTimer trace;
-  if (ds->from_file) {
-    for (size_t s0 = 0; s0 < ds->n_local; s0 += batch) {
-      const size_t n = std::min(batch, (size_t)ds->n_local - s0);
-      cp2_slot_trees* t = nullptr;
-      CP2_TRY(dataset_transient_trees(ds, s0, n, &t));
-      int st = dataset_keep_from_batch(ds, t, s0);
-      if (st == CP2_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = std::string(what) + " build: copy out of a batch failed"; st = CP2_ERR_HIP; }
-      cp2_slot_trees_free(t);
-      if (st != CP2_OK) return st;
-      if (trace.on && ((s0 / batch) % 32 == 31 || s0 + n == ds->n_local))   // a long build says where it is (CP2_TRACE)
-        std::fprintf(stderr, "[cp2 trace] %s build: %zu of %llu slots\n", what, s0 + n, (unsigned long long)ds->n_local);
-    }
-    trace.lap(mode == 2 ? "compact build (block layers dropped)" : "roots-only build (trees dropped)");
-    return CP2_OK;
-  }
   int st = CP2_OK;
   {
     BuildScratch scratch;                       // drains the context's streams before its buffers go, whatever path leaves this scope
@@ -250,7 +235,8 @@ static int dataset_build_transient(cp2_dataset* ds, int mode, bool allocated = f
       const int b = (int)(k & 1);
       if (k >= 2 && hipEventSynchronize(kept[b]) != hipSuccess) { ctx->err = std::string(what) + " build: a batch failed on the device"; st = CP2_ERR_HIP; break; }
       cp2_slot_trees* t = nullptr;
-      st = trees_build_fake(ctx, c.seed, ds->first_slot + s0, n, c.cell_size, c.block_size, c.n_cells, 0, nullptr, &t, 1, true, &scratch, b);
+      st = ds->from_file ? trees_build_files(ctx, ds->file_base, ds->first_slot + s0, n, c.cell_size, c.block_size, c.n_cells, 0, nullptr, &t, 1, true, &scratch, b)
+                         : trees_build_fake(ctx, c.seed, ds->first_slot + s0, n, c.cell_size, c.block_size, c.n_cells, 0, nullptr, &t, 1, true, &scratch, b);
       hipStream_t tail = scratch.tail_stream ? scratch.tail_stream : ctx->stream;
       if (st == CP2_OK) st = dataset_keep_from_batch(ds, t, s0, tail);    // follows the batch's layer passes on their stream (the context's third)
       if (st == CP2_OK && hipEventRecord(kept[b], tail) != hipSuccess) { ctx->err = "hipEventRecord failed"; st = CP2_ERR_HIP; }
@@ -290,6 +276,7 @@ static bool step_down(cp2_ctx* ctx, int* mode, const char* what) {
 static int dataset_build(cp2_ctx* ctx, const cp2_config* cfg, uint64_t first_slot, uint64_t n_local, bool always_keep_trees, cp2_dataset** out) {
   if (!ctx || !cfg || !out) return CP2_ERR_INVALID;
   *out = nullptr;
+  CP2_REFUSE_STUCK(ctx);
   CP2_TRY(dataset_check(cfg, first_slot, n_local));
   CP2_TRY(trees_check_geometry(cfg->cell_size, cfg->block_size, cfg->n_cells, n_local));
   CP2_HIP(ctx, hipSetDevice(ctx->device));
@@ -377,6 +364,7 @@ extern "C" int cp2_dataset_build_cached(cp2_ctx* ctx, const cp2_config* cfg, uin
                                         const char* cache_path, cp2_dataset** out) try {
   if (!ctx || !cfg || !out || !cache_path) return CP2_ERR_INVALID;
   *out = nullptr;
+  CP2_REFUSE_STUCK(ctx);
   CP2_TRY(dataset_check(cfg, first_slot, n_local));
   CP2_TRY(trees_check_geometry(cfg->cell_size, cfg->block_size, cfg->n_cells, n_local));
   CP2_HIP(ctx, hipSetDevice(ctx->device));
@@ -1214,10 +1202,16 @@ extern "C" int cp2_dataset_export_proof_inputs(cp2_dataset* ds, const uint64_t* 
 namespace {
 
 struct StreamRing {
-  static constexpr int DEPTH = 4;            // pass k being enqueued, k - 1 waiting for its group's hashing (two chunks are in flight), k - 2 landing, k - 3 being formatted
-  SampleHost host[DEPTH];
-  hipEvent_t landed[DEPTH] = {};
-  size_t s0[DEPTH] = {}, s1[DEPTH] = {};   // slot range parked in host[r]
+  // Fake data (depth 4): pass k being enqueued, k - 1 waiting for its group's hashing (two chunks are in flight), k - 2 landing, k - 3
+  // being formatted.  Slot files (depth 8): the building thread is also what FILLS the ingestion ring, so it must never sleep on a
+  // pass that has not landed yet; it hands out the passes it finds landed (a query per turn) and blocks only when this ring is full --
+  // on a pass enqueued eight turns earlier, while the device runs at most four turns behind the host.  (Without sampled cells -- the
+  // formatting workers read those from the slot files -- a landing buffer is a third of the fake path's.)
+  static constexpr int MAX_DEPTH = 8;
+  int depth = 4;
+  SampleHost host[MAX_DEPTH];
+  hipEvent_t landed[MAX_DEPTH] = {};
+  size_t s0[MAX_DEPTH] = {}, s1[MAX_DEPTH] = {};   // slot range parked in host[r]
   ~StreamRing() { for (auto e : landed) if (e) (void)hipEventDestroy(e); }   // host[] drain their stream themselves
   // body tasks still reading host[r]: the build thread sleeps on the condition variable until a ring slot is free
   void begin(int r, size_t n) { std::lock_guard<std::mutex> lk(mu); pending[r] = n; }
@@ -1233,7 +1227,7 @@ struct StreamRing {
  private:
   std::mutex mu;
   std::condition_variable cv;
-  size_t pending[DEPTH] = {};
+  size_t pending[MAX_DEPTH] = {};
 };
 
 }  // namespace
@@ -1273,7 +1267,8 @@ static int build_streamed_in_mode(cp2_ctx* ctx, const cp2_config* cfg, uint64_t 
   SampleDev dev;
   StreamRing ring;
   CP2_TRY(dev.init(ctx, group_slots, ns, md, cs, !from_file));
-  for (int r = 0; r < StreamRing::DEPTH; ++r) {
+  ring.depth = from_file ? StreamRing::MAX_DEPTH : 4;
+  for (int r = 0; r < ring.depth; ++r) {
     CP2_TRY(ring.host[r].init(ctx, group_slots, ns, md, cs, !from_file));
     CP2_HIP(ctx, hipEventCreateWithFlags(&ring.landed[r], hipEventDisableTiming));
   }
@@ -1297,7 +1292,7 @@ static int build_streamed_in_mode(cp2_ctx* ctx, const cp2_config* cfg, uint64_t 
 
     // hand the body tasks of pass `k` to the workers once its downloads have landed
     auto consume = [&](size_t k) -> int {
-      const int r = (int)(k % StreamRing::DEPTH);
+      const int r = (int)(k % (size_t)ring.depth);
       CP2_HIP(ctx, hipEventSynchronize(ring.landed[r]));
       const size_t a = ring.s0[r], b = ring.s1[r];
       ring.begin(r, b - a);
@@ -1343,9 +1338,9 @@ static int build_streamed_in_mode(cp2_ctx* ctx, const cp2_config* cfg, uint64_t 
       for (size_t g0 = a; g0 < b; g0 += group_slots) {
         const size_t g1 = std::min(b, g0 + group_slots);
         const size_t k = n_groups;
-        const int r = (int)(k % StreamRing::DEPTH);
+        const int r = (int)(k % (size_t)ring.depth);
         // ring slot r was last used by pass k - DEPTH: its tasks must have been handed out and finished
-        while (consumed + StreamRing::DEPTH <= k) { CP2_TRY(consume(consumed)); ++consumed; }
+        while (consumed + (size_t)ring.depth <= k) { CP2_TRY(consume(consumed)); ++consumed; }
         ring.wait_free(r);
         CP2_HIP(ctx, hipEventRecord(trees_ready, tree_stream));   // the group's layer passes end on one of the two hashing streams
         CP2_HIP(ctx, hipStreamWaitEvent(aux, trees_ready, 0));
@@ -1357,7 +1352,19 @@ static int build_streamed_in_mode(cp2_ctx* ctx, const cp2_config* cfg, uint64_t 
         // Two chunks are hashed at a time (one per hashing stream), so the pass before this one still waits for its group's
         // hashing: waiting for it here would keep the builder from enqueueing the next chunk until then.  The pass before THAT
         // has landed or is about to: hand it out.
-        while (consumed + (stream_serial() ? 1 : 2) < n_groups) { CP2_TRY(consume(consumed)); ++consumed; }
+        if (!from_file) {
+          while (consumed + (stream_serial() ? 1 : 2) < n_groups) { CP2_TRY(consume(consumed)); ++consumed; }
+        } else {
+          // slot files: this thread fills the ingestion ring between the builder's turns and must not sleep on the device here
+          // (StreamRing): only what has landed already is handed out
+          while (consumed < n_groups) {
+            const hipError_t q = hipEventQuery(ring.landed[consumed % (size_t)ring.depth]);
+            if (q == hipErrorNotReady) { (void)hipGetLastError(); break; }
+            CP2_HIP(ctx, q);
+            CP2_TRY(consume(consumed));
+            ++consumed;
+          }
+        }
       }
       return CP2_OK;
     };
@@ -1377,27 +1384,8 @@ static int build_streamed_in_mode(cp2_ctx* ctx, const cp2_config* cfg, uint64_t 
       size_t batch = transient_batch_slots(ctx, cfgv, n_local);
       batch = std::max(group_slots, batch / group_slots * group_slots);
       st = dataset_alloc_kept(dsp, tree_mode);
-      if (from_file) {
-        // slot files: batch by batch (the ingestion pipe owns and drains its ring; the storage is what bounds this path)
-        for (size_t base = 0; st == CP2_OK && base < n_local; base += batch) {
-          const size_t nb = std::min(batch, (size_t)n_local - base);
-          slot_base = base;
-          have_geom = false;                                     // node offsets are those of THIS batch's layout
-          cp2_slot_trees* t = nullptr;
-          st = trees_build_files(ctx, file_base, first_slot + base, nb, cfgv.cell_size, cfgv.block_size, cfgv.n_cells, group_slots, on_done, &t, 1, true);
-          while (st == CP2_OK && consumed < n_groups) { st = consume(consumed); ++consumed; }
-          pool.wait_idle();                                      // nothing reads this batch's landing buffers or nodes any more
-          (void)hipStreamSynchronize(aux);
-          if (st == CP2_OK && t) {
-            st = dataset_keep_from_batch(dsp, t, base);
-            if (st == CP2_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "streamed build: copy out of a batch failed"; st = CP2_ERR_HIP; }
-          }
-          cp2_slot_trees_free(t);
-          if (trace.on && ((base / batch) % 32 == 31 || base + nb == n_local))
-            std::fprintf(stderr, "[cp2 trace] streamed %s build: %zu of %llu slots\n", tree_mode == 2 ? "compact" : "roots-only", base + nb, (unsigned long long)n_local);
-        }
-      } else {
-        // Fake data: the batches PIPELINE (BuildScratch: two node buffers used alternately, nothing synchronised per batch).  A
+      {
+        // The batches PIPELINE, fake data and slot files alike (BuildScratch: two node buffers used alternately, nothing synchronised per batch).  A
         // batch's tail -- the layer passes of its last group, that group's sampling, gathers and downloads, the copy-out of what
         // is kept: all on the third stream -- runs while the next batch's generation and hashing already occupy the two hashing
         // streams (round 4 drained the device here: 816 s against 806 s for the roots alone over 32 TiB).  Node buffer b goes to
@@ -1420,7 +1408,8 @@ static int build_streamed_in_mode(cp2_ctx* ctx, const cp2_config* cfg, uint64_t 
           slot_base = base;
           have_geom = false;                                     // node offsets are those of THIS batch's layout
           cp2_slot_trees* t = nullptr;
-          st = trees_build_fake(ctx, cfgv.seed, first_slot + base, nb, cfgv.cell_size, cfgv.block_size, cfgv.n_cells, group_slots, on_done, &t, 1, true, &scratch, b);
+          st = from_file ? trees_build_files(ctx, file_base, first_slot + base, nb, cfgv.cell_size, cfgv.block_size, cfgv.n_cells, group_slots, on_done, &t, 1, true, &scratch, b)
+                         : trees_build_fake(ctx, cfgv.seed, first_slot + base, nb, cfgv.cell_size, cfgv.block_size, cfgv.n_cells, group_slots, on_done, &t, 1, true, &scratch, b);
           layer_stream = scratch.tail_stream ? scratch.tail_stream : layer_stream;         // where the builder put the batch's layer passes (the third stream)
           if (st == CP2_OK) st = dataset_keep_from_batch(dsp, t, base, layer_stream);     // follows the batch's last layer pass on that stream
           if (st == CP2_OK && (hipEventRecord(sampled[b], aux) != hipSuccess || hipStreamWaitEvent(layer_stream, sampled[b], 0) != hipSuccess ||
@@ -1458,6 +1447,7 @@ extern "C" int cp2_dataset_build_streamed(cp2_ctx* ctx, const cp2_config* cfg, u
                                           const uint8_t entropy_in[32], int threads, size_t group_slots, cp2_dataset** out) try {
   if (!ctx || !cfg || !out || !entropy_in) return CP2_ERR_INVALID;
   *out = nullptr;
+  CP2_REFUSE_STUCK(ctx);
   CP2_TRY(dataset_check(cfg, first_slot, n_local));
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   bool automatic = false;

@@ -25,6 +25,7 @@
 
 #include "trees.hpp"
 #include "fake_turns.hpp"
+#include "ingest_turns.hpp"
 
 using namespace cp2i;
 
@@ -217,11 +218,7 @@ struct LayerScheduler {
     cp2_ctx* ctx = t->ctx;
     const size_t complete = cells_hashed / t->n_cells;
     for (;;) {
-      const size_t avail = complete - built;
-      size_t take = 0;
-      if (group && take_all) take = avail;
-      else if (group && avail >= group) take = group;
-      else if (final && avail) take = avail;
+      const size_t take = layer_take(complete, built, group, take_all, final);   // csrc/ingest_turns.hpp (walked by the CPU suite)
       if (!take) return CP2_OK;
       (void)s;
       hipStream_t ls = layer_stream();          // the third stream (groups, pipelined batches), else everything ends on the context's
@@ -248,6 +245,7 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
                            uint64_t units_per_slot, bool pooled_nodes, BuildScratch* scratch, int node_slot) {
   *out = nullptr;
   if (units_per_slot == 0) return CP2_ERR_INVALID;
+  CP2_REFUSE_STUCK(ctx);
   CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   std::unique_ptr<cp2_slot_trees> t(trees_new(ctx, n_slots, cell_size, block_size, n_cells));
@@ -263,7 +261,10 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
   // how the batch is cut into turns -- staging chunks of up to 2 GiB, the ramp-down of the last groups, which of the two staging
   // buffers a turn uses: csrc/fake_turns.hpp (plain arithmetic; the CPU suite walks it over thousands of shapes)
   const char* ramp_env = std::getenv("CP2_STREAM_RAMP");                                                  // "0": A/B tooling
-  const FakeTurnPlan plan = fake_turn_plan(n_slots, n_cells, cell_size, ctx->stage_bytes, group, !(ramp_env && ramp_env[0] == '0'));
+  const bool serial = group != 0 && stream_serial();            // A/B tooling: groups hashed on the first stream only, as in rounds 2-4
+  const bool leave_room = group != 0 && !serial && ctx->hash_room;   // group builds: two workgroups per CU, the rest for the layer passes and sampling
+  const FakeTurnPlan plan = fake_turn_plan(n_slots, n_cells, cell_size, ctx->stage_bytes, group, !(ramp_env && ramp_env[0] == '0'),
+                                           leave_room ? FAKE_RESIDENCY_CELLS_WITH_ROOM : FAKE_RESIDENCY_CELLS);
   const size_t total_cells = plan.total_cells;
   // whole slots: the seed of the batch's first slot, the generator counts slots from there; units: the seed of slot 0 of the
   // dataset, the generator places unit first_slot + i inside slot (first_slot + i) / units_per_slot
@@ -276,7 +277,6 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
   if (plan.two && stage[1].bytes < plan.chunk * cell_size) CP2_TRY(stage[1].scratch(ctx, plan.chunk * cell_size));
   trace.lap("fake slots: node + staging buffers");
   sched.take_all = plan.ramp;
-  const bool serial = group != 0 && stream_serial();            // A/B tooling: groups hashed on the first stream only, as in rounds 2-4
   int st = sched.init();
   size_t turn = 0;
   for (size_t c0 = 0, n = 0; st == CP2_OK && c0 < total_cells; c0 += n, ++turn) {
@@ -288,7 +288,7 @@ int cp2i::trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_s
       break;
     }
     hipError_t e = cp2k::launch_gen_fake_cells(seed0, n_cells, c0, nullptr, n, cell_size, stage[s].p, sched.hs[s], units_per_slot, first_slot);
-    if (e == hipSuccess) e = cp2k::launch_hash_cells(stage[s].p, cell_size, n, t->nodes.u8() + c0 * 32, sched.hs[s], group != 0 && !serial);
+    if (e == hipSuccess) e = cp2k::launch_hash_cells(stage[s].p, cell_size, n, t->nodes.u8() + c0 * 32, sched.hs[s], leave_room);
     if (e != hipSuccess) { ctx->err = hipGetErrorString(e); st = CP2_ERR_HIP; break; }
     st = sched.hashed_on(s);
     if (st == CP2_OK) st = sched.advance(c0 + n, c0 + n == total_cells, s);
@@ -352,6 +352,7 @@ extern "C" int cp2_slot_trees_build_dev(cp2_ctx* ctx, const void* d_cells, size_
                                         size_t block_size, size_t n_cells, cp2_slot_trees** out) try {
   if (!ctx || !out || !d_cells) return CP2_ERR_INVALID;
   *out = nullptr;
+  CP2_REFUSE_STUCK(ctx);
   CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   std::unique_ptr<cp2_slot_trees> t(trees_new(ctx, n_slots, cell_size, block_size, n_cells));
@@ -372,17 +373,24 @@ extern "C" int cp2_slot_trees_build_dev(cp2_ctx* ctx, const void* d_cells, size_
 }
 
 // ---- streaming ingestion ----------------------------------------------------
-// Overlapped stages over a ring of `depth` slots: host threads fill a PINNED buffer (pread or memcpy), a dedicated
-// copy stream moves it to the device, the context's stream hashes it.  While chunk i is copied and hashed the host is
-// already filling chunk i+1 (and i+2 with depth 3), so disk / host memory, PCIe and the GPU work concurrently (the
-// reference re-opens the slot file and reads one cell per call, slot.nim:57-68).  Fill threads, ring depth and chunk
-// size are run-time knobs: cp2_set_ingest, or CP2_INGEST_THREADS / CP2_INGEST_RING / CP2_INGEST_CHUNK_MB.
+// Overlapped stages: host threads fill a PINNED buffer (pread or memcpy), a dedicated copy stream moves it into a DEVICE buffer,
+// one of the context's two hashing streams hashes it.  While chunk i is copied and hashed the host is already filling chunk
+// i+1 (and i+2), so disk / host memory, PCIe and the GPU work concurrently (the reference re-opens the slot file and reads one
+// cell per call, slot.nim:57-68).  Fill threads, ring depth and chunk size are run-time knobs: cp2_set_ingest, or
+// CP2_INGEST_THREADS / CP2_INGEST_RING / CP2_INGEST_CHUNK_MB.
 //
 // Chunk size is what matters (measured, tools/ingest_probe.cpp, profiles/r02_ingest_probe.txt): the hash kernel runs
 // one CELL per lane, so a 64 MiB chunk of 2 KiB cells is 128 workgroups on a GPU that holds 768 of them -- the kernel
 // then takes the lifetime of one workgroup (3.75 ms) whatever its size, and the pipe ran at 17 GB/s although host
 // memcpy (130 GB/s on 8 threads), pinned H2D (56 GB/s) and the kernel from HBM (43 GB/s) are each far faster.  The
 // default chunk is therefore one full residency of the kernel: 768 workgroups x 256 cells (384 MiB at 2 KiB cells).
+//
+// Round 6: (1) a chunk is a range of the BATCH's cells and may span many slot files (csrc/ingest_turns.hpp: a dataset of 8 MiB
+// slots used to be hashed 16 workgroups at a time); (2) the pinned ring and the device ring are separate: a pinned buffer is free
+// again once its upload is done (~7 ms), not once its chunk is hashed (two chunks are hashed at a time, ~18 ms each), so three
+// pinned buffers keep the host filling while four device buffers hold one chunk landing, two being hashed and one of slack; the
+// upload into a device buffer waits ON THE DEVICE for the kernel that last read it; (3) the pipe can outlive a builder call
+// (BuildScratch::file_pipe): the batches of a transient build then pipeline like the fake-data ones.
 namespace {
 
 size_t env_size(const char* name, size_t dflt) {
@@ -396,104 +404,184 @@ size_t env_size(const char* name, size_t dflt) {
 struct IngestPipe {
   static constexpr int MAX_DEPTH = 8;
   static constexpr size_t DIRECT_ALIGN = 4096;   // offset, length and address granule of O_DIRECT reads
-  size_t cell_multiple = 1;                      // chunk sizes are multiples of this many cells (direct reads: whole 4 KiB blocks)
+  static constexpr size_t MAX_MAPPED_PIECES = 4; // a turn is uploaded from mappings only when it touches at most this many files
+  size_t cell_multiple = 1;                      // inside a large slot chunk sizes are multiples of this many cells (direct reads: whole 4 KiB blocks)
   cp2_ctx* ctx = nullptr;
   hipStream_t copy = nullptr;
-  int depth = 0;
+  int pin_depth = 0, dev_depth = 0;
   PinBuf pinned[MAX_DEPTH];
   DevBuf dev[MAX_DEPTH];
-  hipEvent_t copied[MAX_DEPTH] = {}, hashed[MAX_DEPTH] = {};
-  size_t chunk = 0, turn = 0;
+  hipEvent_t copied[MAX_DEPTH] = {};     // per PINNED buffer: its upload is done, the host may fill it again
+  hipEvent_t uploaded[MAX_DEPTH] = {};   // per DEVICE buffer: the chunk has landed in it (what the hash launch waits for)
+  hipEvent_t hashed[MAX_DEPTH] = {};     // per DEVICE buffer: the kernel that read it is done (what the next upload into it waits for)
+  size_t chunk = 0;                      // cells per full turn (what a ring buffer holds)
+  size_t cap_bytes = 0;                  // bytes of every ring buffer
+  size_t turn = 0;                       // turns since the pipe was set up (device buffer = turn % dev_depth)
+  size_t pin_turn = 0;                   // ... of which through the pinned ring (pinned buffer = pin_turn % pin_depth)
   int threads = 1;
+  bool serial = false;                   // CP2_STREAM_SERIAL=1 (A/B tooling): every chunk hashed on the first stream
   std::unique_ptr<Workers> pool;
   hipStream_t hash_stream[2] = {nullptr, nullptr};   // chunks alternate between the context's two streams: the next chunk's
                                                      // workgroups fill the CUs as the previous kernel's last ones retire
+  int last_aux_dev = -1;                 // device buffer of the latest chunk hashed on the second stream
 
   ~IngestPipe() {
     if (!ctx) return;
     const bool trace = std::getenv("CP2_TRACE") != nullptr && (mapped_chunks + ring_chunks) > 0;
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t0 = now();
+    const double t0 = now_ms();
+    (void)hipSetDevice(ctx->device);
     (void)finish();
     (void)hipStreamSynchronize(ctx->stream);
+    if (hash_stream[1]) (void)hipStreamSynchronize(hash_stream[1]);
     if (copy) (void)hipStreamSynchronize(copy);
-    const double t1 = now();
+    const double t1 = now_ms();
     for (auto& mp : mappings) mp.open = false;
     (void)release_mapped();
-    const double t2 = now();
-    for (int b = 0; b < depth; ++b) {
+    const double t2 = now_ms();
+    for (int b = 0; b < MAX_DEPTH; ++b) {
       if (copied[b]) (void)hipEventDestroy(copied[b]);
+      if (uploaded[b]) (void)hipEventDestroy(uploaded[b]);
       if (hashed[b]) (void)hipEventDestroy(hashed[b]);
     }
     if (copy) (void)hipStreamDestroy(copy);
-    if (trace) std::fprintf(stderr, "[cp2 trace] slot files: pipe torn down: drain %.1f ms, release %.1f ms, events + copy stream %.1f ms\n", t1 - t0, t2 - t1, now() - t2);
+    if (trace)
+      std::fprintf(stderr, "[cp2 trace] ingestion pipe torn down after %zu chunk(s) by mapping + %zu through the pinned ring: drain %.1f ms, release %.1f ms, events + copy stream %.1f ms\n",
+                   mapped_chunks, ring_chunks, t1 - t0, t2 - t1, now_ms() - t2);
   }
-  int init(cp2_ctx* c, size_t cell_size, size_t max_cells, bool direct_slack = false) {
-    ctx = c;
+  // what a ring buffer of this context holds, in bytes (before it is clipped to the batch)
+  static size_t wanted_chunk_bytes(const cp2_ctx* c, size_t cell_size) {
     size_t chunk_bytes = c->ingest_chunk ? c->ingest_chunk : env_size("CP2_INGEST_CHUNK_MB", 0) << 20;
     if (chunk_bytes == 0) chunk_bytes = std::max<size_t>((size_t)64 << 20, std::min<size_t>((size_t)768 * 256 * cell_size, (size_t)1 << 30));
-    int want_depth = c->ingest_ring ? c->ingest_ring : (int)env_size("CP2_INGEST_RING", 3);
-    want_depth = std::max(2, std::min(want_depth, (int)MAX_DEPTH));
+    return chunk_bytes;
+  }
+  int init(cp2_ctx* c, size_t cell_size, size_t max_cells) {
+    ctx = c;
+    int ring = c->ingest_ring ? c->ingest_ring : (int)env_size("CP2_INGEST_RING", 3);
+    ring = std::max(2, std::min(ring, (int)MAX_DEPTH));
+    const int want_dev = std::min(ring + 1, (int)MAX_DEPTH);
     threads = c->ingest_threads ? c->ingest_threads : (int)env_size("CP2_INGEST_THREADS", 8);
     threads = std::max(1, std::min(threads, 64));
-    chunk = std::max<size_t>(1, std::min(max_cells, chunk_bytes / cell_size));
+    chunk = ingest_chunk_cells(wanted_chunk_bytes(c, cell_size), cell_size, max_cells);
+    cap_bytes = chunk * cell_size;
     CP2_HIP(ctx, hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
     hash_stream[0] = ctx->stream;
     CP2_TRY(aux_stream(ctx, &hash_stream[1]));
-    for (int b = 0; b < want_depth; ++b) {
-      // slack for O_DIRECT only (its last read of a chunk is rounded up to a whole block): without it the default 384 MiB chunk
-      // stays in its own size class of the block pool instead of spilling into the next one (+32 MiB of pinned memory per slot)
-      CP2_TRY(pinned[b].alloc(ctx, chunk * cell_size + (direct_slack ? DIRECT_ALIGN : 0)));
-      CP2_TRY(dev[b].scratch(ctx, chunk * cell_size));
+    for (int b = 0; b < ring; ++b) {
+      CP2_TRY(pinned[b].alloc(ctx, cap_bytes));
       CP2_HIP(ctx, hipEventCreateWithFlags(&copied[b], hipEventDisableTiming));
+      CP2_HIP(ctx, hipEventRecord(copied[b], copy));
+      pin_depth = b + 1;
+    }
+    for (int b = 0; b < want_dev; ++b) {
+      CP2_TRY(dev[b].scratch(ctx, cap_bytes));
+      CP2_HIP(ctx, hipEventCreateWithFlags(&uploaded[b], hipEventDisableTiming));
       CP2_HIP(ctx, hipEventCreateWithFlags(&hashed[b], hipEventDisableTiming));
-      CP2_HIP(ctx, hipEventRecord(hashed[b], ctx->stream));
-      depth = b + 1;
+      CP2_HIP(ctx, hipEventRecord(hashed[b], copy));
+      dev_depth = b + 1;
     }
     if (threads > 1) pool.reset(new Workers(threads - 1));
     return CP2_OK;
   }
+  // a pipe that outlives builder calls: the next batch's chunk size (its buffers were sized by the first batch)
+  bool fits(size_t cell_size) const { return cap_bytes >= cell_size; }
+  void rebatch(size_t cell_size, size_t max_cells) { chunk = std::max<size_t>(1, std::min(max_cells, cap_bytes / cell_size)); }
   // f(a, b) over [0, n) split across the fill threads (the calling thread takes the first range); inner boundaries are
   // multiples of `align` (O_DIRECT reads need block-aligned offsets)
   template <typename F> void parallel_ranges(size_t n, size_t grain, F f, size_t align = 1) {
-    int nt = (int)std::min<size_t>((size_t)threads, std::max<size_t>(1, n / grain));
+    const int nt = ingest_fill_threads(n, grain, threads);
     if (nt <= 1 || !pool) { f(0, n); return; }
-    const size_t units = n / align;                       // whole `align`-sized units are dealt out evenly (any align, not only powers of two)
-    auto cut = [=](int t) { return t >= nt ? n : units * t / nt * align; };
+    auto cut = [=](int t) { return ingest_range_cut(n, align, nt, t); };   // csrc/ingest_turns.hpp
     for (int t = 1; t < nt; ++t) pool->submit([=] { f(cut(t), cut(t + 1)); });
     f(0, cut(1));
     pool->wait_idle();
   }
-  // cells of the next chunk: a quarter, a half, three quarters of the ring slot, then whole slots.  The GPU starts hashing
-  // after a quarter of the fill + upload latency, and each upload (57 GB/s) still lands before the previous, shorter
-  // kernel (43 GB/s, never under 3.75 ms) has finished, so the start-up bubble stays under a millisecond.
-  size_t next_cells(size_t remaining) const {
-    size_t m = turn < 3 ? std::max<size_t>(chunk * (turn + 1) / 4, std::min<size_t>(chunk, 32768)) : chunk;
-    if (m > cell_multiple) m -= m % cell_multiple;
-    return std::min(m, remaining);
-  }
-  // the pinned buffer the host may fill next (blocks until the kernel that last used this ring slot is done)
+  // the pinned buffer the host may fill next (blocks until the upload that last read it is done)
   int acquire(uint8_t** buf) {
-    int b = (int)(turn % depth);
-    CP2_HIP(ctx, hipEventSynchronize(hashed[b]));
+    const int b = (int)(pin_turn % pin_depth);
+    CP2_HIP(ctx, hipEventSynchronize(copied[b]));
     *buf = pinned[b].u8();
     return CP2_OK;
   }
-  // ship the filled buffer: m cells -> leaf hashes at `leaves_out`
-  int submit(size_t m, size_t cell_size, uint8_t* leaves_out) {
-    int b = (int)(turn % depth);
-    CP2_HIP(ctx, hipMemcpyAsync(dev[b].p, pinned[b].p, m * cell_size, hipMemcpyHostToDevice, copy));
-    CP2_HIP(ctx, hipEventRecord(copied[b], copy));
-    hipStream_t hs = hash_stream[turn & 1];
-    CP2_HIP(ctx, hipStreamWaitEvent(hs, copied[b], 0));
-    CP2_HIP(ctx, cp2k::launch_hash_cells(dev[b].p, cell_size, m, leaves_out, hs));
-    CP2_HIP(ctx, hipEventRecord(hashed[b], hs));
-    last_on_aux = (turn & 1) ? b : last_on_aux;
+  // the hash launch of this turn, behind the upload(s) just enqueued on the copy stream; *s = the hashing stream it went to
+  int hash_turn(int d, size_t m, size_t cell_size, uint8_t* leaves_out, bool leave_room, int* s) {
+    CP2_HIP(ctx, hipEventRecord(uploaded[d], copy));
+    const int side = serial ? 0 : (int)(turn & 1);
+    hipStream_t hs = hash_stream[side];
+    CP2_HIP(ctx, hipStreamWaitEvent(hs, uploaded[d], 0));
+    CP2_HIP(ctx, cp2k::launch_hash_cells(dev[d].p, cell_size, m, leaves_out, hs, leave_room));
+    CP2_HIP(ctx, hipEventRecord(hashed[d], hs));
+    if (side) last_aux_dev = d;
+    if (s) *s = side;
     ++turn;
-    ++ring_chunks;
     return CP2_OK;
   }
-  int last_on_aux = -1;
+  // ship the pinned buffer acquire() handed out: m cells -> leaf hashes at `leaves_out`
+  int submit(size_t m, size_t cell_size, uint8_t* leaves_out, bool leave_room = false, int* s = nullptr) {
+    const int b = (int)(pin_turn % pin_depth), d = (int)(turn % dev_depth);
+    if (m == 0 || m * cell_size > cap_bytes || !pinned[b].p || !dev[d].p) {   // (never: checked because a short buffer is a GPU fault)
+      ctx->err = "ingestion pipe: a turn that does not fit its ring buffer";
+      return CP2_ERR_INVALID;
+    }
+    CP2_HIP(ctx, hipStreamWaitEvent(copy, hashed[d], 0));       // the kernel that last read this device buffer
+    CP2_HIP(ctx, hipMemcpyAsync(dev[d].p, pinned[b].p, m * cell_size, hipMemcpyHostToDevice, copy));
+    CP2_HIP(ctx, hipEventRecord(copied[b], copy));
+    ++pin_turn;
+    ++ring_chunks;
+    return hash_turn(d, m, cell_size, leaves_out, leave_room, s);
+  }
+
+  // bytes [0, m * cell_size) of the turn [c0, c0 + m) of batch `g` into `buf`, from the slot files "<base><slot>.dat", zero-filled
+  // past the end of a file (slot.nim:61-66).  Every fill thread walks the pieces of its own byte range (ingest_piece) and opens
+  // the files it needs itself: nothing is held open between turns, however many files a turn touches.
+  // O_DIRECT (cp2_set_ingest_direct / CP2_INGEST_DIRECT=1): slot files that are not in the page cache are read straight into
+  // the pinned ring, whole 4 KiB blocks, without passing through (and evicting) the page cache; a piece whose file offset or
+  // buffer address is not block aligned, the last partial block of a piece, and a file system that refuses O_DIRECT (tmpfs)
+  // are read buffered.
+  int fill_from_files(const IngestGeom& g, const std::string& base, size_t c0, size_t m, uint8_t* buf, bool want_direct) {
+    std::mutex mu;
+    std::string first_bad;
+    parallel_ranges(m * g.cell_size, (size_t)2 << 20, [&](size_t a, size_t b) {
+      for (size_t p = a; p < b;) {
+        const IngestPiece q = ingest_piece(g, c0, p, b);
+        const std::string fname = slot_file_name(base, q.slot);
+        const int fd = open(fname.c_str(), O_RDONLY);
+        if (fd < 0) {
+          std::lock_guard<std::mutex> lk(mu);
+          if (first_bad.empty()) first_bad = fname;
+          std::memset(buf + p, 0, q.len);
+          p += q.len;
+          continue;
+        }
+        size_t pos = 0;
+        if (want_direct && q.len >= DIRECT_ALIGN && q.file_off % DIRECT_ALIGN == 0 && reinterpret_cast<uintptr_t>(buf + p) % DIRECT_ALIGN == 0) {
+          const int dfd = open(fname.c_str(), O_RDONLY | O_DIRECT);
+          if (dfd >= 0) {
+            const size_t whole = q.len / DIRECT_ALIGN * DIRECT_ALIGN;
+            while (pos < whole) {
+              const ssize_t r = pread(dfd, buf + p + pos, whole - pos, (off_t)(q.file_off + pos));
+              if (r <= 0) break;
+              pos += (size_t)r;
+              if ((size_t)r % DIRECT_ALIGN) break;   // short, unaligned: end of file (the buffered reads below see that too)
+            }
+            close(dfd);
+          }
+        }
+        while (pos < q.len) {
+          const ssize_t r = pread(fd, buf + p + pos, q.len - pos, (off_t)(q.file_off + pos));
+          if (r <= 0) break;
+          pos += (size_t)r;
+        }
+        if (pos < q.len) std::memset(buf + p + pos, 0, q.len - pos);
+        close(fd);
+        p += q.len;
+      }
+    }, want_direct ? DIRECT_ALIGN : 1);
+    if (!first_bad.empty()) {
+      ctx->err = "cannot open " + first_bad;
+      return CP2_ERR_IO;
+    }
+    return CP2_OK;
+  }
 
   // ---- mapped mode (round 5): chunks of a slot file that sit in the PAGE CACHE go to the device without a CPU copy.  The file is
   // mmap'ed read-only; a chunk whose pages are resident (mincore, sampled) is REGISTERED with the runtime (hipHostRegister pins the
@@ -506,19 +594,21 @@ struct IngestPipe {
   //     until `mapped_budget` bytes are registered, when everything uploaded so far is released in one go (one bubble per budget).
   //   * uploading from the UNregistered mapping (the runtime pins in place by itself) reaches 55 GB/s beside an idle device but only
   //     30 GB/s beside the hash kernel, and holds the host for the duration: slower than the ring.
-  // A chunk that is not in the cache, reaches past the end of the file or cannot be registered goes through the ring as before; the
-  // two mix freely, chunk by chunk: either way ring slot b's device buffer holds the chunk when `copied[b]` fires.
+  // A turn that is not in the cache, reaches past the end of a file, touches more than MAX_MAPPED_PIECES files (small slots: one
+  // registration per file would cost more than the copy it saves) or cannot be registered goes through the ring as before; the two mix
+  // freely, turn by turn: either way the turn's device buffer holds the chunk when its `uploaded` event fires.
+  // What is mapped of a file is the range of ONE unit (round 6; a whole slot when slots are not cut): S devices sharing a 128 GiB slot no
+  // longer map it S times over.
   bool mapped_allowed = false, mapped_broken = false;
   size_t mapped_chunks = 0, ring_chunks = 0, registered_bytes = 0, mapped_budget = (size_t)32 << 30, releases = 0;
   struct Window { void* p; size_t n; };
-  struct Mapping { uint8_t* base; size_t len; bool open; };
+  struct Mapping { uint8_t* base; size_t len; uint64_t unit; size_t file_off; bool open; };   // bytes [file_off, file_off + len) of the file of dataset unit `unit`
   std::vector<Window> windows;                       // registered, uploads possibly in flight
-  std::vector<Mapping> mappings;                     // every file mapped so far that still has (or may get) windows
-  // all uploads from mappings are complete: unregister every window (this waits for the device) and unmap the files that are done
+  std::vector<Mapping> mappings;                     // every range mapped so far that still has (or may get) windows
+  // all uploads from mappings are complete: unregister every window (this waits for the device) and unmap the ranges that are done
   int release_mapped() {
     const bool trace = std::getenv("CP2_TRACE") != nullptr;
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t0 = now();
+    const double t0 = now_ms();
     const size_t n_windows = windows.size(), bytes = registered_bytes;
     if (!windows.empty()) {
       CP2_HIP(ctx, hipStreamSynchronize(copy));
@@ -527,7 +617,7 @@ struct IngestPipe {
       ++releases;
     }
     registered_bytes = 0;
-    const double t1 = now();
+    const double t1 = now_ms();
     // tearing down the page tables of a mapping whose every page was touched costs 1.1 ms per GiB (measured: 37 ms per 32 GiB) and needs
     // nothing of this pipe, the context or the runtime: a detached thread does it while the build goes on
     std::vector<Mapping> done;
@@ -551,8 +641,34 @@ struct IngestPipe {
     }
     if (trace && n_windows)
       std::fprintf(stderr, "[cp2 trace] slot files: released %zu registered window(s), %.1f GiB: unregister %.1f ms, %zu mapping(s) handed to be unmapped %.1f ms\n", n_windows, bytes / 1073741824.0, t1 - t0,
-                   done.size(), now() - t1);
+                   done.size(), now_ms() - t1);
     return CP2_OK;
+  }
+  // the mapping of dataset unit `unit` (bytes [unit_off, unit_off + unit_bytes) of slot file `fname`, as far as the file reaches),
+  // made on first use; nullptr when the file cannot be mapped (the ring reads it, and reports a file that is not there)
+  const Mapping* mapping_of(uint64_t unit, const std::string& fname, size_t unit_off, size_t unit_bytes) {
+    for (auto& mp : mappings)
+      if (mp.open && mp.unit == unit) return &mp;
+    const int fd = open(fname.c_str(), O_RDONLY);
+    if (fd < 0) return nullptr;
+    struct stat sb;
+    const Mapping* got = nullptr;
+    const size_t page = 4096, lo = unit_off / page * page;
+    if (fstat(fd, &sb) == 0 && (size_t)sb.st_size > lo) {
+      const size_t hi = std::min<size_t>((size_t)sb.st_size, unit_off + unit_bytes);
+      void* p = mmap(nullptr, hi - lo, PROT_READ, MAP_SHARED, fd, (off_t)lo);   // nothing is read by this: pages that are not in the cache stay where they are
+      if (p != MAP_FAILED) {
+        mappings.push_back({static_cast<uint8_t*>(p), hi - lo, unit, lo, true});
+        got = &mappings.back();
+      }
+    }
+    close(fd);
+    return got;
+  }
+  // the builder has moved past every unit before `unit`: their mappings go with the next release
+  void mappings_done_before(uint64_t unit) {
+    for (auto& mp : mappings)
+      if (mp.unit < unit) mp.open = false;
   }
   // bytes [off, off + len) of the mapping `base` (of `map_len` bytes): in the page cache and registrable?  mincore over every page of
   // a 384 MiB chunk costs as much as the upload itself (98 304 page-cache lookups: 7 ms measured), so the chunk is SAMPLED: its
@@ -571,34 +687,59 @@ struct IngestPipe {
     }
     const size_t n = std::min(map_len, (off + len + page - 1) / page * page) - off;
     if (registered_bytes + n > mapped_budget && release_mapped() != CP2_OK) return false;
-    if (hipHostRegister(base + off, n, hipHostRegisterDefault) != hipSuccess) {
+    const hipError_t e = hipHostRegister(base + off, n, hipHostRegisterDefault);
+    if (e != hipSuccess) {
       (void)hipGetLastError();
       mapped_broken = true;                          // this stack does not register file-backed pages: the ring from here on
+      if (std::getenv("CP2_TRACE")) std::fprintf(stderr, "[cp2 trace] slot files: hipHostRegister of %zu mapped bytes refused (%s): the pinned ring from here on\n", n, hipGetErrorString(e));
       return false;
     }
     windows.push_back({base + off, n});
     registered_bytes += n;
     return true;
   }
-  // ship m cells that sit at `src` inside a REGISTERED window: upload on the copy stream, hash, like submit()
-  int submit_mapped(const uint8_t* src, size_t m, size_t cell_size, uint8_t* leaves_out) {
-    int b = (int)(turn % depth);
-    CP2_HIP(ctx, hipMemcpyAsync(dev[b].p, src, m * cell_size, hipMemcpyHostToDevice, copy));
-    CP2_HIP(ctx, hipEventRecord(copied[b], copy));
-    hipStream_t hs = hash_stream[turn & 1];
-    CP2_HIP(ctx, hipStreamWaitEvent(hs, copied[b], 0));
-    CP2_HIP(ctx, cp2k::launch_hash_cells(dev[b].p, cell_size, m, leaves_out, hs));
-    CP2_HIP(ctx, hipEventRecord(hashed[b], hs));
-    last_on_aux = (turn & 1) ? b : last_on_aux;
-    ++turn;
+  // The turn [c0, c0 + m) straight from mappings of its files, when every piece of it is in the page cache and registered: uploads on
+  // the copy stream, then the hash launch, like submit().  false (nothing enqueued): the ring takes the turn.
+  bool try_mapped_turn(const IngestGeom& g, const std::string& base, size_t c0, size_t m, uint8_t* leaves_out, bool leave_room, int* s, int* status) {
+    *status = CP2_OK;
+    if (!mapped_allowed || mapped_broken) return false;
+    size_t u0 = 0, u1 = 0;
+    ingest_turn_units(g, c0, m, &u0, &u1);
+    if (u1 - u0 + 1 > MAX_MAPPED_PIECES) return false;
+    mappings_done_before(g.first_unit + u0);
+    struct Src { const uint8_t* p; size_t at, len; };
+    Src src[MAX_MAPPED_PIECES];
+    size_t n_src = 0;
+    const size_t nbytes = m * g.cell_size;
+    if (nbytes > cap_bytes) return false;
+    for (size_t p = 0; p < nbytes;) {
+      const IngestPiece q = ingest_piece(g, c0, p, nbytes);
+      const uint64_t unit = g.first_unit + q.unit;
+      const Mapping* mp = mapping_of(unit, slot_file_name(base, q.slot), (size_t)(unit % g.units_per_slot) * g.unit_bytes(), g.unit_bytes());
+      if (!mp || q.file_off < mp->file_off || n_src == MAX_MAPPED_PIECES) return false;
+      uint8_t* mbase = mp->base;                    // (try_window may release and drop OTHER mappings: take what is needed of this one first)
+      const size_t mlen = mp->len, moff = q.file_off - mp->file_off;
+      if (!try_window(mbase, mlen, moff, q.len)) return false;
+      src[n_src++] = {mbase + moff, p, q.len};
+      p += q.len;
+    }
+    const int d = (int)(turn % dev_depth);
+    auto fail = [&](hipError_t e, const char* what) { ctx->err = std::string(what) + ": " + hipGetErrorString(e); *status = CP2_ERR_HIP; return true; };
+    hipError_t e = hipStreamWaitEvent(copy, hashed[d], 0);
+    if (e != hipSuccess) return fail(e, "hipStreamWaitEvent");
+    for (size_t i = 0; i < n_src; ++i) {
+      e = hipMemcpyAsync(dev[d].u8() + src[i].at, src[i].p, src[i].len, hipMemcpyHostToDevice, copy);
+      if (e != hipSuccess) return fail(e, "hipMemcpyAsync from a mapped slot file");
+    }
     ++mapped_chunks;
-    return CP2_OK;
+    *status = hash_turn(d, m, g.cell_size, leaves_out, leave_room, s);
+    return true;
   }
   // everything hashed on the second stream is ordered before whatever the caller enqueues next on the context's stream
   int finish() {
-    if (last_on_aux >= 0) {
-      CP2_HIP(ctx, hipStreamWaitEvent(ctx->stream, hashed[last_on_aux], 0));
-      last_on_aux = -1;
+    if (last_aux_dev >= 0) {
+      CP2_HIP(ctx, hipStreamWaitEvent(ctx->stream, hashed[last_aux_dev], 0));
+      last_aux_dev = -1;
     }
     return CP2_OK;
   }
@@ -608,8 +749,10 @@ struct IngestPipe {
 int cp2i::hash_host_cells_pipelined(cp2_ctx* ctx, const uint8_t* cells, size_t cell_size, size_t n, uint8_t* d_leaves) {
   IngestPipe pipe;
   CP2_TRY(pipe.init(ctx, cell_size, n));
+  IngestGeom g;
+  g.n_units = 1; g.n_cells = n; g.cell_size = cell_size;
   for (size_t c0 = 0, m = 0; c0 < n; c0 += m) {
-    m = pipe.next_cells(n - c0);
+    m = ingest_turn_cells(g, pipe.chunk, 1, pipe.turn, c0);
     uint8_t* buf = nullptr;
     CP2_TRY(pipe.acquire(&buf));
     const uint8_t* src = cells + c0 * cell_size;
@@ -623,6 +766,7 @@ extern "C" int cp2_slot_trees_build_host(cp2_ctx* ctx, const uint8_t* cells, siz
                                          size_t block_size, size_t n_cells, cp2_slot_trees** out) try {
   if (!ctx || !out || !cells) return CP2_ERR_INVALID;
   *out = nullptr;
+  CP2_REFUSE_STUCK(ctx);
   CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   std::unique_ptr<cp2_slot_trees> t(trees_new(ctx, n_slots, cell_size, block_size, n_cells));
@@ -642,12 +786,18 @@ extern "C" int cp2_slot_trees_build_host(cp2_ctx* ctx, const uint8_t* cells, siz
   return CP2_ERR_INVALID;
 }
 
-// slot files "<base><k>.dat" (dataset.nim:34) streamed through the ingestion pipe; short files read as zeros
+// slot files "<base><k>.dat" (dataset.nim:34) streamed through the ingestion pipe; short files read as zeros.
+// With GROUPS (the streamed proof-input path) the file builder does what the fake-data builder does (round 6): the layer passes of
+// the slots a turn completed -- and the sampling, gathers and downloads the caller's hook hangs behind them -- go to the context's
+// THIRD stream while the two hashing streams carry on with the next turns; the hash launches leave a third of every CU free for
+// them (launch_hash_cells' leave_room); nothing joins the two hashing streams per slot.  Rounds 2-5 launched at full occupancy and
+// made the first stream wait for the second after every slot.
 int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t first_slot, size_t n_slots, size_t cell_size,
                             size_t block_size, size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out,
-                            uint64_t units_per_slot, bool pooled_nodes) {
+                            uint64_t units_per_slot, bool pooled_nodes, BuildScratch* scratch, int node_slot) {
   *out = nullptr;
   if (units_per_slot == 0) return CP2_ERR_INVALID;
+  CP2_REFUSE_STUCK(ctx);
   CP2_TRY(trees_check_geometry(cell_size, block_size, n_cells, n_slots));
   CP2_HIP(ctx, hipSetDevice(ctx->device));
   std::unique_ptr<cp2_slot_trees> t(trees_new(ctx, n_slots, cell_size, block_size, n_cells));
@@ -657,97 +807,74 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
   t->first_slot = first_slot;
   t->units_per_slot = units_per_slot;
   t->pooled_nodes = pooled_nodes;
-  CP2_TRY(trees_layout(t.get()));
+  if (scratch) scratch->ctx = ctx;
+  CP2_TRY(trees_layout(t.get(), scratch ? &scratch->nodes[node_slot & 1] : nullptr));
+  IngestGeom g;
+  g.n_units = n_slots; g.n_cells = n_cells; g.cell_size = cell_size; g.first_unit = first_slot; g.units_per_slot = units_per_slot;
+  const size_t total_cells = g.total_cells();
+  const bool want_direct = ctx->ingest_direct > 0 || (ctx->ingest_direct < 0 && env_size("CP2_INGEST_DIRECT", 0) != 0);
   int st = CP2_OK;
   {
-    IngestPipe pipe;
-    const bool want_direct = ctx->ingest_direct > 0 || (ctx->ingest_direct < 0 && env_size("CP2_INGEST_DIRECT", 0) != 0);
+    // the pipe: this call's own (drained and torn down when the call ends), or the pipeline's (BuildScratch: it outlives the call
+    // with this batch's last chunks still in flight, and serves the next batch)
+    IngestPipe own_pipe;
+    IngestPipe* pipe = &own_pipe;
+    if (scratch) {
+      if (scratch->file_pipe && !static_cast<IngestPipe*>(scratch->file_pipe.get())->fits(cell_size)) scratch->file_pipe.reset();
+      if (!scratch->file_pipe) scratch->file_pipe = std::make_shared<IngestPipe>();
+      pipe = static_cast<IngestPipe*>(scratch->file_pipe.get());
+    }
     StageTimer init_trace;
-    st = pipe.init(ctx, cell_size, n_cells, want_direct);
-    if (init_trace.on) init_trace.lap("slot files: pipe set up (ring, events, copy stream)");
+    if (!pipe->ctx) {
+      st = pipe->init(ctx, cell_size, total_cells);
+      if (init_trace.on) init_trace.lap("slot files: pipe set up (rings, events, copy stream)");
+    } else {
+      pipe->rebatch(cell_size, total_cells);
+    }
     LayerScheduler sched{t.get(), group, done};
+    sched.detached = scratch != nullptr;          // (before init(): the choice of the layer stream depends on it)
+    sched.take_all = group != 0;                  // groups: the slots a turn completed go at once, the passes follow the turns
+    const bool serial = group != 0 && stream_serial();             // A/B tooling: groups hashed on the first stream only, full occupancy
+    const bool leave_room = group != 0 && !serial && ctx->hash_room;
+    pipe->serial = serial;
     if (st == CP2_OK) st = sched.init();
-    // O_DIRECT (cp2_set_ingest_direct / CP2_INGEST_DIRECT=1): slot files that are not in the page cache are read straight into
-    // the pinned ring, block-aligned, without passing through (and evicting) the page cache.  Chunks then start on 4 KiB file
-    // offsets (a whole number of `cell_multiple` cells); a file system that refuses O_DIRECT (tmpfs) is read buffered.
+    pipe->cell_multiple = 1;
     if (want_direct) {
-      size_t g = cell_size, h = IngestPipe::DIRECT_ALIGN;
-      while (h) { size_t r = g % h; g = h; h = r; }               // gcd(cell_size, 4096)
-      pipe.cell_multiple = IngestPipe::DIRECT_ALIGN / g;
+      size_t a = cell_size, h = IngestPipe::DIRECT_ALIGN;
+      while (h) { size_t r = a % h; a = h; h = r; }               // gcd(cell_size, 4096)
+      pipe->cell_multiple = IngestPipe::DIRECT_ALIGN / a;
     }
     // mapped mode (cp2_set_ingest_mapped / CP2_INGEST_MAPPED, default off): chunks that sit in the page cache are uploaded straight
     // from a mapping of the file, no CPU copy; not with O_DIRECT, whose point is to leave the page cache alone
-    pipe.mapped_allowed = !want_direct && (ctx->ingest_mapped > 0 || (ctx->ingest_mapped < 0 && env_size("CP2_INGEST_MAPPED", 0) != 0));
+    pipe->mapped_allowed = !want_direct && (ctx->ingest_mapped > 0 || (ctx->ingest_mapped < 0 && env_size("CP2_INGEST_MAPPED", 0) != 0));
+    const size_t mapped0 = pipe->mapped_chunks, ring0 = pipe->ring_chunks;
     StageTimer ingest_trace;
-    for (size_t s = 0; st == CP2_OK && s < n_slots; ++s) {
-      // unit s of the batch = cells [unit_off, unit_off + n_cells) of the file of slot (first_slot + s) / units_per_slot
-      const uint64_t unit = first_slot + s;
-      const size_t unit_off = (size_t)(unit % units_per_slot) * n_cells * cell_size;
-      std::string fname = slot_file_name(base, unit / units_per_slot);
-      int fd = open(fname.c_str(), O_RDONLY);
-      if (fd < 0) { ctx->err = "cannot open " + fname; st = CP2_ERR_IO; break; }
-      const int dfd = want_direct ? open(fname.c_str(), O_RDONLY | O_DIRECT) : -1;
-      // the whole file mapped read-only (nothing is read by this: pages that are not in the cache stay where they are)
-      uint8_t* map = nullptr;
-      size_t map_len = 0;
-      if (pipe.mapped_allowed && !pipe.mapped_broken) {
-        struct stat sb;
-        if (fstat(fd, &sb) == 0 && sb.st_size > 0) {
-          void* p = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_SHARED, fd, 0);
-          if (p != MAP_FAILED) {
-            map = static_cast<uint8_t*>(p);
-            map_len = (size_t)sb.st_size;
-            pipe.mappings.push_back({map, map_len, true});
-          }
-        }
+    for (size_t c0 = 0, m = 0; st == CP2_OK && c0 < total_cells; c0 += m) {
+      m = ingest_turn_cells(g, pipe->chunk, pipe->cell_multiple, pipe->turn, c0);
+      if (m == 0 || m > pipe->chunk || c0 + m > total_cells) {   // (never: csrc/ingest_turns.hpp is walked by the CPU suite; a wrong turn is a GPU fault)
+        ctx->err = "slot-file builder: a turn outside its ring buffer or its batch";
+        st = CP2_ERR_INVALID;
+        break;
       }
-      for (size_t c0 = 0, m = 0; st == CP2_OK && c0 < n_cells; c0 += m) {
-        m = pipe.next_cells(n_cells - c0);
+      uint8_t* leaves_out = t->nodes.u8() + c0 * 32;
+      int side = 0;
+      if (!pipe->try_mapped_turn(g, base, c0, m, leaves_out, leave_room, &side, &st)) {
         uint8_t* buf = nullptr;
-        st = pipe.acquire(&buf);
-        if (st != CP2_OK) break;
-        const size_t off = unit_off + c0 * cell_size;
-        if (pipe.try_window(map, map_len, off, m * cell_size)) {
-          st = pipe.submit_mapped(map + off, m, cell_size, t->nodes.u8() + (s * n_cells + c0) * 32);
-          continue;
-        }
-        const bool direct = dfd >= 0 && off % IngestPipe::DIRECT_ALIGN == 0;
-        // bytes [off, off+n) of the file into the pinned buffer, zero-filled past EOF (slot.nim:61-66)
-        pipe.parallel_ranges(m * cell_size, (size_t)2 << 20, [=](size_t a, size_t b) {
-          size_t pos = a;
-          if (direct) {          // a is block aligned; the last request is rounded up into the buffer's slack
-            while (pos < b) {
-              const size_t want = (b - pos + IngestPipe::DIRECT_ALIGN - 1) / IngestPipe::DIRECT_ALIGN * IngestPipe::DIRECT_ALIGN;
-              ssize_t r = pread(dfd, buf + pos, want, (off_t)(off + pos));
-              if (r <= 0) break;
-              pos += std::min<size_t>((size_t)r, b - pos);
-              if ((size_t)r % IngestPipe::DIRECT_ALIGN) break;   // short, unaligned: end of file (or the buffered path finishes it)
-            }
-          }
-          while (pos < b) {
-            ssize_t r = pread(fd, buf + pos, b - pos, (off_t)(off + pos));
-            if (r <= 0) break;
-            pos += (size_t)r;
-          }
-          if (pos < b) std::memset(buf + pos, 0, b - pos);
-        }, direct ? IngestPipe::DIRECT_ALIGN : 1);
-        st = pipe.submit(m, cell_size, t->nodes.u8() + (s * n_cells + c0) * 32);
+        st = pipe->acquire(&buf);
+        if (st == CP2_OK) st = pipe->fill_from_files(g, base, c0, m, buf, want_direct);
+        if (st == CP2_OK) st = pipe->submit(m, cell_size, leaves_out, leave_room, &side);
       }
-      if (map)                                    // the mapping stays until its windows are released (the pipe's end, or the next release)
-        for (auto& mp : pipe.mappings)
-          if (mp.base == map) mp.open = false;
-      if (dfd >= 0) close(dfd);
-      close(fd);
-      if (st == CP2_OK) st = pipe.finish();   // the context's stream now follows everything hashed on the second one
-      if (st == CP2_OK) st = sched.hashed_on(0);
-      if (st == CP2_OK) st = sched.advance((s + 1) * n_cells, s + 1 == n_slots, 0);
+      if (st == CP2_OK) st = sched.hashed_on(side);
+      if (st == CP2_OK) st = sched.advance(c0 + m, c0 + m == total_cells, side);
     }
+    pipe->mappings_done_before(~0ULL);            // (they stay mapped until their windows are released: the pipe's end, or the next release)
+    if (scratch) scratch->tail_stream = sched.layer_stream();   // where the batch ends: the caller's copy-out follows the layer passes there
     int fin = sched.finish();
     if (st == CP2_OK) st = fin;
     if (ingest_trace.on) {
       char what[160];
-      std::snprintf(what, sizeof what, "slot files: %zu chunk(s) from the page cache by mapping, %zu through the pinned ring%s", pipe.mapped_chunks, pipe.ring_chunks,
-                    pipe.mapped_broken ? " (registration refused)" : "");
+      std::snprintf(what, sizeof what, "slot files: %zu chunk(s) from the page cache by mapping, %zu through the pinned ring%s", pipe->mapped_chunks - mapped0,
+                    pipe->ring_chunks - ring0, pipe->mapped_broken ? " (registration refused)" : "");
       ingest_trace.lap(what);
     }
   }

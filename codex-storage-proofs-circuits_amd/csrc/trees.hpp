@@ -47,6 +47,8 @@ struct BuildScratch {
   cp2_ctx* ctx = nullptr;
   DevBuf stage[2], nodes[2];
   hipStream_t tail_stream = nullptr;   // set by the builder: the stream the last batch's layer passes were enqueued on
+  std::shared_ptr<void> file_pipe;     // slot files: the ingestion pipe (pinned ring, device ring, copy stream) the batches share; declared
+                                       // last, so it drains and goes before the buffers above
   ~BuildScratch();
 };
 
@@ -54,13 +56,13 @@ int trees_check_geometry(size_t cell_size, size_t block_size, size_t n_cells, si
 // fake-data or slot-file trees; `group` = how many finished slots to batch per layer pass / callback (0: all at the end)
 // units_per_slot > 1: first_slot / n_slots / n_cells count UNITS and the cells of one unit (cp2_slot_trees above)
 // pooled_nodes: the node buffer comes from (and goes back to) the context's scratch pool instead of hipMalloc / hipFree
-// scratch != nullptr: pipelined (BuildScratch above); the returned batch borrows scratch->nodes[node_slot]
+// scratch != nullptr: pipelined (BuildScratch above); the returned batch borrows scratch->nodes[node_slot] (both builders)
 int trees_build_fake(cp2_ctx* ctx, uint64_t dataset_seed, uint64_t first_slot, size_t n_slots, size_t cell_size, size_t block_size,
                      size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out, uint64_t units_per_slot = 1,
                      bool pooled_nodes = false, BuildScratch* scratch = nullptr, int node_slot = 0);
 int trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t first_slot, size_t n_slots, size_t cell_size,
                       size_t block_size, size_t n_cells, size_t group, const SlotsDone& done, cp2_slot_trees** out,
-                      uint64_t units_per_slot = 1, bool pooled_nodes = false);
+                      uint64_t units_per_slot = 1, bool pooled_nodes = false, BuildScratch* scratch = nullptr, int node_slot = 0);
 // bytes of the node buffer of a batch of n_slots slots of this geometry (all layers, 32 bytes per node)
 size_t trees_node_bytes(size_t n_slots, size_t cell_size, size_t block_size, size_t n_cells);
 void trees_geom(const cp2_slot_trees* t, cp2k::TreeGeom* g);

@@ -117,7 +117,16 @@ class Engine {
     throw std::runtime_error(msg);
   }
  private:
+  // The header this program was COMPILED against and the library it found at run time must be of one major version, the
+  // library's minor at least the header's (include/codex_p2.h, CP2_ABI_VERSION_*): refused with both numbers otherwise.
+  static void requireAbi() {
+    const int v = cp2_abi_version();
+    if ((v >> 16) != CP2_ABI_VERSION_MAJOR || (v & 0xffff) < CP2_ABI_VERSION_MINOR)
+      throw std::runtime_error("libcodex_p2.so has ABI version " + std::to_string(v >> 16) + "." + std::to_string(v & 0xffff) + ", this program was built against " +
+                               std::to_string(CP2_ABI_VERSION_MAJOR) + "." + std::to_string(CP2_ABI_VERSION_MINOR));
+  }
   void init(const int* devices, int n) {
+    requireAbi();
     int st = cp2_multi_init(devices, n, &multi_);
     if (st != CP2_OK) {
       char why[512] = "";

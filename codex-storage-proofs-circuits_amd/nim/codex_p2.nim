@@ -15,6 +15,9 @@
 import std/os                  # getEnv: CODEX_P2_CACHE, as in the cli twin
 
 const libName = "libcodex_p2.so"
+const
+  abiVersionMajor* = 1         ## CP2_ABI_VERSION_MAJOR / _MINOR of the include/codex_p2.h this binding was written against
+  abiVersionMinor* = 0         ## (tests/test_nim_binding.py keeps the two files equal)
 
 type
   F* = array[32, byte]          ## canonical little-endian field element (NOT constantine's Montgomery limbs)
@@ -29,6 +32,7 @@ type
     fileBase*: cstring
 
 {.push cdecl, dynlib: libName.}
+proc cp2_abi_version(): cint {.importc.}
 proc cp2_init(device: cint, ctx: ptr Cp2Ctx): cint {.importc.}
 proc cp2_free(ctx: Cp2Ctx) {.importc.}
 proc cp2_strerror(status: cint): cstring {.importc.}
@@ -92,12 +96,22 @@ proc cp2_multi_dataset_export_streamed(ds: Cp2MultiDataset, dir: cstring, thread
 
 var gMulti: Cp2Multi
 
+proc requireAbi() =
+  ## The entry points are bound by name when the library is loaded: only this number tells a library built from another header.
+  ## Another MAJOR is refused outright, an older MINOR too (an entry point this binding imports may be missing).
+  let v = int(cp2_abi_version())
+  let (major, minor) = (v shr 16, v and 0xffff)
+  if major != abiVersionMajor or minor < abiVersionMinor:
+    raiseAssert("libcodex_p2.so has ABI version " & $major & "." & $minor & ", this binding was written against " &
+                $abiVersionMajor & "." & $abiVersionMinor & " (include/codex_p2.h, CP2_ABI_VERSION_*)")
+
 proc multi(): Cp2Multi =
   ## one engine per process (the reference is single threaded, cli.nim:208-237): the seam calls run on the first device's
   ## context, generateProofInput cuts the dataset's slots over all the engine's devices.  The environment variable
   ## CODEX_P2_GPUS ("all", "<count>" or an index list) names the devices -- unset: ONE device, several are opt-in (INTEGRATION.md
   ## section 1); nothing in cli.nim changes.
   if pointer(gMulti) == nil:
+    requireAbi()
     let st = cp2_multi_init(nil, 0, addr gMulti)
     if st != 0:
       var why: array[512, char]            # a CODEX_P2_* variable that does not hold what it takes is named, not guessed at

@@ -30,6 +30,20 @@ extern "C" {
 
 #define CP2_FELT_BYTES 32
 
+/* ---- version of this boundary --------------------------------------------------------------
+ * Callers bind the entry points BY NAME at load time (the Nim `dynlib` binding nim/codex_p2.nim, the ctypes binding, dlopen), so
+ * nothing but this number tells a caller built against one header from a library built from another.
+ *   MAJOR  changes when an existing entry point, struct or status code changes meaning or layout, or one is removed: a caller built
+ *          for another major MUST refuse the library (every binding in this repository does, naming both numbers).  The library's
+ *          SONAME carries it: libcodex_p2.so.<MAJOR>.
+ *   MINOR  grows with every release that only ADDS entry points; a caller needs library minor >= the minor it was written against.
+ * cp2_abi_version() returns what the LIBRARY was built from: (MAJOR << 16) | MINOR.  It touches no device and needs no context.
+ * History: 1.0 = the 105 entry points of round 5 + this function + cp2_set_ingest's two rings (round 6).                        */
+#define CP2_ABI_VERSION_MAJOR 1
+#define CP2_ABI_VERSION_MINOR 0
+#define CP2_ABI_VERSION ((CP2_ABI_VERSION_MAJOR << 16) | CP2_ABI_VERSION_MINOR)
+int cp2_abi_version(void);
+
 typedef enum cp2_status {
   CP2_OK = 0,
   CP2_ERR_INVALID = -1,    /* bad argument (the reference would fail an assert)            */
@@ -69,13 +83,25 @@ int cp2_device_is_native(const cp2_ctx* ctx);
  *                        holds half of it in tree nodes per batch
  *   CODEX_P2_MEM_LIMIT_MB        (tests) a cap, in MiB per device, on the device memory this process may hold through the library:
  *                        the automatic residency choice sees min(free, cap left) and an allocation beyond the cap fails like a real
- *                        out-of-memory, so all residency modes and the fallback between them can be reached on an empty 288 GB device */
+ *                        out-of-memory, so all residency modes and the fallback between them can be reached on an empty 288 GB device
+ * Test hooks the shipped library also reads (they exist so that branches a healthy MI355X never takes can be reached by the suite;
+ * none of them can change a result, only which path produces it or turn a run into an error):
+ *   CODEX_P2_TEST_LDS_LIMIT      a decimal number of bytes: the LDS per workgroup cp2_init's launch-shape decision sees (65536 makes
+ *                        the hash launches of the streamed builds hold every workgroup slot instead of leaving room; parsed strictly)
+ *   CODEX_P2_TEST_OPTIMISTIC     "1": the automatic residency choice starts at "every node" without looking at the device, so that
+ *                        the step-down chain is what finds the mode that fits (anything else: ignored)
+ *   CODEX_P2_TEST_EXCHANGE_FAULT "hang_init" | "hang_collective" | "init" | "collective" | "corrupt": the multi-device exchange of
+ *                        slot roots stalls, fails or delivers wrong rows at that point (cp2_multi_*; anything else: ignored)
+ * and the A/B knobs of the measurement tools, read leniently (anything but the value named means "off"): CP2_STREAM_SERIAL=1,
+ * CP2_STREAM_RAMP=0, CP2_HASH_BLOCK=64, CP2_TRACE (any value: stage timings on stderr). */
 int cp2_check_environment(char* msg, size_t msg_len);
 /* Tuning of the host -> GPU ingestion pipe used by cp2_slot_trees_build_host, cp2_hash_cells (large inputs) and the
  * SlotFile data source (the reference reads one cell per call, reference/nim/proof_input/src/slot.nim:57-68):
  * host threads filling the pinned ring, ring depth (2..8) and bytes per chunk.  0 = keep the default
  * (environment CP2_INGEST_THREADS / CP2_INGEST_RING / CP2_INGEST_CHUNK_MB, else 8 threads, depth 3 and one full
- * residency of the hash kernel per chunk: 768 x 256 cells, 384 MiB at 2 KiB cells). */
+ * residency of the hash kernel per chunk: 768 x 256 cells, 384 MiB at 2 KiB cells).  `ring_depth` pinned host buffers
+ * (free again as soon as their upload is done) feed ring_depth + 1 device buffers (one landing, two being hashed, slack).
+ * A chunk is a range of the BATCH's cells: it holds many small slot files, or a piece of a large one. */
 int cp2_set_ingest(cp2_ctx* ctx, int fill_threads, int ring_depth, size_t chunk_bytes);
 /* SlotFile source: read the slot files with O_DIRECT (block-aligned requests straight into the pinned ring, no page-cache copy
  * and no eviction of what the cache holds): for files that are NOT cached -- a cached file reads faster through the cache.

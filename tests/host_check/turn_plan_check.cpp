@@ -14,8 +14,10 @@ using namespace cp2i;
 static uint64_t rng_state = 0x9e3779b97f4a7c15ULL;
 static uint64_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
 
+static size_t residency = FAKE_RESIDENCY_CELLS;   // the builder passes 768 x 256 (full occupancy) or 512 x 256 (launches that leave room)
+
 static long check_shape(size_t n_slots, size_t n_cells, size_t cell_size, size_t stage_bytes, size_t group, bool ramp_allowed, bool serial) {
-  const FakeTurnPlan p = fake_turn_plan(n_slots, n_cells, cell_size, stage_bytes, group, ramp_allowed);
+  const FakeTurnPlan p = fake_turn_plan(n_slots, n_cells, cell_size, stage_bytes, group, ramp_allowed, residency);
   auto fail = [&](const char* what, size_t turn, size_t c0, size_t n) {
     std::printf("FAILED: %s  (n_slots %zu n_cells %zu cell_size %zu stage %zu group %zu ramp %d serial %d: turn %zu at cell %zu, %zu cells; chunk %zu two %d)\n", what, n_slots,
                 n_cells, cell_size, stage_bytes, group, (int)ramp_allowed, (int)serial, turn, c0, n, p.chunk, (int)p.two);
@@ -62,12 +64,13 @@ int main() {
       const FakeTurnPlan q = fake_turn_plan(n_slots, n_cells, cs, stage, group, true);
       if (q.total_cells / q.chunk > 100000) continue;
     }
+    residency = (it & 1) ? FAKE_RESIDENCY_CELLS_WITH_ROOM : FAKE_RESIDENCY_CELLS;
     for (int ramp = 0; ramp < 2; ++ramp)
       for (int serial = 0; serial < 2; ++serial) {
         const long t = check_shape(n_slots, n_cells, cs, stage, group, ramp != 0, serial != 0);
         ++shapes;
         turns += t;
-        const FakeTurnPlan p = fake_turn_plan(n_slots, n_cells, cs, stage, group, ramp != 0);
+        const FakeTurnPlan p = fake_turn_plan(n_slots, n_cells, cs, stage, group, ramp != 0, residency);
         multi_turn_single_chunk += (p.total_cells <= p.chunk && t > 1);
       }
   }

@@ -264,10 +264,10 @@ def test_environment_is_parsed_strictly_and_the_offender_is_named(pkg, tmp_path)
     bad = [("CODEX_P2_GATHER", "rcl"), ("CODEX_P2_GATHER", "RCCL"), ("CODEX_P2_GATHER", "rccl "), ("CODEX_P2_KEEP_TREES", "3"), ("CODEX_P2_KEEP_TREES", "-1"),
            ("CODEX_P2_KEEP_TREES", "compact"), ("CODEX_P2_GPUS", "two"), ("CODEX_P2_GPUS", "0,x"), ("CODEX_P2_GPUS", "ALL"), ("CODEX_P2_GPUS", "0"),
            ("CODEX_P2_SPLIT", "3"), ("CODEX_P2_MIN_CELLS", "1e6"), ("CODEX_P2_MEM_LIMIT_MB", "1g"), ("CODEX_P2_MEM_LIMIT_MB", "-5"),
-           ("CODEX_P2_EXCHANGE_TIMEOUT_S", "soon"), ("CODEX_P2_STAGE_MB", "0"), ("CODEX_P2_STAGE_MB", "big")]
+           ("CODEX_P2_EXCHANGE_TIMEOUT_S", "soon"), ("CODEX_P2_STAGE_MB", "0"), ("CODEX_P2_STAGE_MB", "big"), ("CODEX_P2_TEST_LDS_LIMIT", "64k")]
     good = [("CODEX_P2_GATHER", "auto"), ("CODEX_P2_GATHER", "rccl"), ("CODEX_P2_GATHER", "copy"), ("CODEX_P2_GATHER", "host"), ("CODEX_P2_KEEP_TREES", "auto"),
             ("CODEX_P2_KEEP_TREES", "0"), ("CODEX_P2_KEEP_TREES", "2"), ("CODEX_P2_GPUS", "all"), ("CODEX_P2_GPUS", "8"), ("CODEX_P2_GPUS", "0,0"), ("CODEX_P2_GPUS", "2,"),
-            ("CODEX_P2_SPLIT", "4"), ("CODEX_P2_MEM_LIMIT_MB", "4096"), ("CODEX_P2_EXCHANGE_TIMEOUT_S", "0"), ("CODEX_P2_STAGE_MB", "64")]
+            ("CODEX_P2_SPLIT", "4"), ("CODEX_P2_MEM_LIMIT_MB", "4096"), ("CODEX_P2_EXCHANGE_TIMEOUT_S", "0"), ("CODEX_P2_STAGE_MB", "64"), ("CODEX_P2_TEST_LDS_LIMIT", "65536")]
     clean = {k: v for k, v in os.environ.items() if not k.startswith("CODEX_P2_")}
     saved = {k: os.environ.pop(k) for k in list(os.environ) if k.startswith("CODEX_P2_")}
     try:
