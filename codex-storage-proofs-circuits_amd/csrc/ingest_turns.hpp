@@ -20,10 +20,26 @@ namespace cp2i {
 //   group == 0            one pass over everything at the end (`final`)
 //   group, !take_all      passes of exactly `group` slots; what is left at the end goes as one shorter pass
 //   group, take_all       every complete slot goes at once (passes follow the builder's turns)
-inline size_t layer_take(size_t complete, size_t built, size_t group, bool take_all, bool final) {
+//   group, !take_all, ramp_min   ... and the LAST passes shrink: once fewer than two groups are left (of `n_slots` in the batch) a pass
+//                         takes half of what is left, never less than `ramp_min` slots -- what follows a pass on the host (the JSON
+//                         bodies of its slots) overlaps the hashing of the next pass, so the last pass's formatting overlaps nothing
+//                         and should be small.  The slot-file builder runs like this (ramp_min = the slots of one ring turn).
+// Why not a pass per ring turn (round 6 tried): a pass is a chain of ~15 small dependent kernels on the third stream (the block- and
+// slot-tree layers, sampling, gathers), each of which takes 0.7 ms BESIDE the hash launches against 0.1 ms alone -- about 10 ms per
+// pass whatever its size.  A pass per 512 MiB turn (14 ms) keeps that stream three quarters busy, per 256 MiB turn it is the bottleneck
+// (profiles/r06_streamed_files_ab.txt: 0.77 / 0.86 / 0.97 of the fake source's rate at 256 / 512 / 1024 MiB turns).
+inline size_t layer_take(size_t complete, size_t built, size_t group, bool take_all, bool final, size_t n_slots = 0, size_t ramp_min = 0) {
   const size_t avail = complete > built ? complete - built : 0;
   if (group && take_all) return avail;
-  if (group && avail >= group) return group;
+  if (group) {
+    size_t want = group;
+    if (ramp_min && n_slots > built) {
+      const size_t left = n_slots - built;
+      if (left < 2 * group) want = left > ramp_min ? std::max(std::min(ramp_min, group), (left + 1) / 2) : left;
+      if (want > group) want = group;
+    }
+    if (want && avail >= want) return want;
+  }
   if (final) return avail;
   return 0;
 }
@@ -94,6 +110,15 @@ inline int ingest_fill_threads(size_t n, size_t grain, int threads) {
 inline size_t ingest_range_cut(size_t n, size_t align, int nt, int t) {
   if (t >= nt) return n;
   return (size_t)((unsigned __int128)(n / align) * (unsigned)t / (unsigned)nt) * align;
+}
+
+// The fill of a slot-file turn: grains of INGEST_FILL_GRAIN bytes (a multiple of the O_DIRECT granule), taken by the fill threads
+// from a shared counter; grain i of a turn of n bytes is [a, b).
+constexpr size_t INGEST_FILL_GRAIN = (size_t)4 << 20;
+inline size_t ingest_grain_count(size_t n, size_t grain) { return (n + grain - 1) / grain; }
+inline void ingest_grain(size_t n, size_t grain, size_t i, size_t* a, size_t* b) {
+  *a = std::min(n, i * grain);
+  *b = std::min(n, (i + 1) * grain);
 }
 
 // the units a turn of m cells starting at cell c0 touches: [first, last]

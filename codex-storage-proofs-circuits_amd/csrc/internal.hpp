@@ -2,6 +2,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <sys/resource.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <condition_variable>
 #include <cstdint>
 #include <deque>
@@ -281,7 +285,10 @@ struct PinBuf {
 // ever destroyed, whatever path leaves the owning scope).
 class Workers {
  public:
-  explicit Workers(int n) {
+  // nice_inc > 0: the threads give way to the process's other threads when cores are short (Linux: a thread's nice value is its own).
+  // The streamed build's formatting threads run like that: what they produce is needed at the END of the build, while the fill
+  // threads of the slot-file pipe and the building thread feed the device NOW.
+  explicit Workers(int n, int nice_inc = 0) : nice_inc_(nice_inc) {
     if (n < 1) n = 1;
     for (int i = 0; i < n; ++i) th_.emplace_back([this] { run(); });
   }
@@ -308,6 +315,7 @@ class Workers {
 
  private:
   void run() {
+    if (nice_inc_ > 0) (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), nice_inc_);
     for (;;) {
       std::function<void()> f;
       {
@@ -332,6 +340,7 @@ class Workers {
   std::deque<std::function<void()>> q_;
   size_t busy_ = 0;
   bool stop_ = false;
+  int nice_inc_ = 0;
 };
 
 // element counts of all layers of a tree over n leaves, bottom first (merkle/bn254.nim:29-58):

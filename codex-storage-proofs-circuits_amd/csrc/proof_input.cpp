@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1288,7 +1289,7 @@ static int build_streamed_in_mode(cp2_ctx* ctx, const cp2_config* cfg, uint64_t 
   size_t slot_base = 0;         // roots-only build: dataset-local index of the first slot of the batch being built
   StageTimer trace;
   {
-    Workers pool(threads);      // declared last: joins before anything above is destroyed
+    Workers pool(threads, 10);  // declared last: joins before anything above is destroyed.  Niced: the bodies are needed at the end, the device is fed now
 
     // hand the body tasks of pass `k` to the workers once its downloads have landed
     auto consume = [&](size_t k) -> int {
@@ -1333,15 +1334,19 @@ static int build_streamed_in_mode(cp2_ctx* ctx, const cp2_config* cfg, uint64_t 
     };
 
     // the builders call this each time the trees of slots [a, b) are complete on the context's stream
+    double hook_wait_ms = 0, hook_enqueue_ms = 0, hook_handout_ms = 0;   // CP2_TRACE: where the hook's time goes (it runs on the building thread)
+    auto clock_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     SlotsDone on_done = [&](cp2_slot_trees* t, size_t a, size_t b, hipStream_t tree_stream) -> int {
       if (!have_geom) { trees_geom(t, &geom); have_geom = true; }
       for (size_t g0 = a; g0 < b; g0 += group_slots) {
         const size_t g1 = std::min(b, g0 + group_slots);
         const size_t k = n_groups;
         const int r = (int)(k % (size_t)ring.depth);
+        const double h0 = trace.on ? clock_ms() : 0;
         // ring slot r was last used by pass k - DEPTH: its tasks must have been handed out and finished
         while (consumed + (size_t)ring.depth <= k) { CP2_TRY(consume(consumed)); ++consumed; }
         ring.wait_free(r);
+        const double h1 = trace.on ? clock_ms() : 0;
         CP2_HIP(ctx, hipEventRecord(trees_ready, tree_stream));   // the group's layer passes end on one of the two hashing streams
         CP2_HIP(ctx, hipStreamWaitEvent(aux, trees_ready, 0));
         CP2_TRY(enqueue_sampling(t, geom, dev, ring.host[r], nullptr, g0, g1 - g0, ns, md, !from_file, aux));
@@ -1349,6 +1354,7 @@ static int build_streamed_in_mode(cp2_ctx* ctx, const cp2_config* cfg, uint64_t 
         ring.s0[r] = slot_base + g0;                           // dataset-local slot indices (bodies, file names); g0 counts inside `t`
         ring.s1[r] = slot_base + g1;
         ++n_groups;
+        const double h2 = trace.on ? clock_ms() : 0;
         // Two chunks are hashed at a time (one per hashing stream), so the pass before this one still waits for its group's
         // hashing: waiting for it here would keep the builder from enqueueing the next chunk until then.  The pass before THAT
         // has landed or is about to: hand it out.
@@ -1365,6 +1371,7 @@ static int build_streamed_in_mode(cp2_ctx* ctx, const cp2_config* cfg, uint64_t 
             ++consumed;
           }
         }
+        if (trace.on) { const double h3 = clock_ms(); hook_wait_ms += h1 - h0; hook_enqueue_ms += h2 - h1; hook_handout_ms += h3 - h2; }
       }
       return CP2_OK;
     };
@@ -1373,6 +1380,7 @@ static int build_streamed_in_mode(cp2_ctx* ctx, const cp2_config* cfg, uint64_t 
     if (tree_mode == 1) {
       st = dataset_build_trees(dsp, group_slots, on_done);
       trace.lap("trees (sampling overlapped)");
+      if (trace.on) std::fprintf(stderr, "[cp2 trace] the sampling hook over %zu passes: %.1f ms waiting for a free landing buffer, %.1f ms enqueueing, %.1f ms handing landed passes to the formatting threads\n", n_groups, hook_wait_ms, hook_enqueue_ms, hook_handout_ms);
       while (st == CP2_OK && consumed < n_groups) { st = consume(consumed); ++consumed; }
       pool.wait_idle();
       (void)hipStreamSynchronize(aux);

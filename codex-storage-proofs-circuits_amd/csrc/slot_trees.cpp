@@ -12,6 +12,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -182,6 +183,7 @@ struct LayerScheduler {
   const SlotsDone& done;
   size_t built = 0;
   bool take_all = false;                     // groups of varying size (the fake builder's ramp-down): every complete slot goes at once
+  size_t ramp_min = 0;                       // groups of `group` slots whose last passes shrink down to this many slots (the slot-file builder; layer_take)
   hipStream_t hs[2] = {nullptr, nullptr};
   hipEvent_t ev[2] = {nullptr, nullptr};     // the latest hashing enqueued on each stream
   bool detached = false;                     // pipelined batches (BuildScratch): nothing is waited for here, the pipeline's owner does
@@ -218,7 +220,7 @@ struct LayerScheduler {
     cp2_ctx* ctx = t->ctx;
     const size_t complete = cells_hashed / t->n_cells;
     for (;;) {
-      const size_t take = layer_take(complete, built, group, take_all, final);   // csrc/ingest_turns.hpp (walked by the CPU suite)
+      const size_t take = layer_take(complete, built, group, take_all, final, t->n_slots, ramp_min);   // csrc/ingest_turns.hpp (walked by the CPU suite)
       if (!take) return CP2_OK;
       (void)s;
       hipStream_t ls = layer_stream();          // the third stream (groups, pipelined batches), else everything ends on the context's
@@ -373,8 +375,8 @@ extern "C" int cp2_slot_trees_build_dev(cp2_ctx* ctx, const void* d_cells, size_
 }
 
 // ---- streaming ingestion ----------------------------------------------------
-// Overlapped stages: host threads fill a PINNED buffer (pread or memcpy), a dedicated copy stream moves it into a DEVICE buffer,
-// one of the context's two hashing streams hashes it.  While chunk i is copied and hashed the host is already filling chunk
+// Overlapped stages: host threads fill a PINNED buffer (pread or memcpy), the copy engine moves it into a DEVICE buffer,
+// one of the context's two hashing streams hashes it (the upload rides on that same stream, ahead of its kernel: upload_stream).  While chunk i is copied and hashed the host is already filling chunk
 // i+1 (and i+2), so disk / host memory, PCIe and the GPU work concurrently (the reference re-opens the slot file and reads one
 // cell per call, slot.nim:57-68).  Fill threads, ring depth and chunk size are run-time knobs: cp2_set_ingest, or
 // CP2_INGEST_THREADS / CP2_INGEST_RING / CP2_INGEST_CHUNK_MB.
@@ -404,7 +406,6 @@ size_t env_size(const char* name, size_t dflt) {
 struct IngestPipe {
   static constexpr int MAX_DEPTH = 8;
   static constexpr size_t DIRECT_ALIGN = 4096;   // offset, length and address granule of O_DIRECT reads
-  static constexpr size_t MAX_MAPPED_PIECES = 4; // a turn is uploaded from mappings only when it touches at most this many files
   size_t cell_multiple = 1;                      // inside a large slot chunk sizes are multiples of this many cells (direct reads: whole 4 KiB blocks)
   cp2_ctx* ctx = nullptr;
   hipStream_t copy = nullptr;
@@ -427,6 +428,7 @@ struct IngestPipe {
 
   ~IngestPipe() {
     if (!ctx) return;
+    fill_join_all();                      // (an error path may leave with fills in flight: the workers write into the pinned ring)
     const bool trace = std::getenv("CP2_TRACE") != nullptr && (mapped_chunks + ring_chunks) > 0;
     const double t0 = now_ms();
     (void)hipSetDevice(ctx->device);
@@ -449,34 +451,41 @@ struct IngestPipe {
                    mapped_chunks, ring_chunks, t1 - t0, t2 - t1, now_ms() - t2);
   }
   // what a ring buffer of this context holds, in bytes (before it is clipped to the batch)
-  static size_t wanted_chunk_bytes(const cp2_ctx* c, size_t cell_size) {
+  // Default: a whole number of residencies of the hash kernel at the occupancy it will be launched with -- 256 CUs x 3 workgroups x
+  // 256 cells (one residency: 384 MiB at 2 KiB cells), and, when the launches leave room, 256 CUs x 2 workgroups x 256 cells TWICE
+  // (512 MiB).  Every workgroup of a launch runs the same instruction stream for the same time, so a launch costs a whole number of
+  // waves of workgroups: round 6's first trace of the streamed build from files showed 768-workgroup launches on the 512 slots a
+  // launch with room has -- two waves for the price of 1.5, 11.6 ms per chunk where 8.9 would do (profiles/r06_streamed_files_trace.txt);
+  // and of the sizes that are whole waves the larger won on the box (one wave 0.76, 1.5 waves 0.83, two waves 0.86 of the fake
+  // source's rate before the fill was rebalanced: fewer turns, fewer joins).
+  static size_t wanted_chunk_bytes(const cp2_ctx* c, size_t cell_size, bool leave_room) {
     size_t chunk_bytes = c->ingest_chunk ? c->ingest_chunk : env_size("CP2_INGEST_CHUNK_MB", 0) << 20;
-    if (chunk_bytes == 0) chunk_bytes = std::max<size_t>((size_t)64 << 20, std::min<size_t>((size_t)768 * 256 * cell_size, (size_t)1 << 30));
+    if (chunk_bytes == 0) chunk_bytes = std::max<size_t>((size_t)64 << 20, std::min<size_t>((size_t)(leave_room ? 1024 : 768) * 256 * cell_size, (size_t)1 << 30));
     return chunk_bytes;
   }
-  int init(cp2_ctx* c, size_t cell_size, size_t max_cells) {
+  int init(cp2_ctx* c, size_t cell_size, size_t max_cells, bool leave_room = false) {
     ctx = c;
     int ring = c->ingest_ring ? c->ingest_ring : (int)env_size("CP2_INGEST_RING", 3);
     ring = std::max(2, std::min(ring, (int)MAX_DEPTH));
     const int want_dev = std::min(ring + 1, (int)MAX_DEPTH);
     threads = c->ingest_threads ? c->ingest_threads : (int)env_size("CP2_INGEST_THREADS", 8);
     threads = std::max(1, std::min(threads, 64));
-    chunk = ingest_chunk_cells(wanted_chunk_bytes(c, cell_size), cell_size, max_cells);
+    chunk = ingest_chunk_cells(wanted_chunk_bytes(c, cell_size, leave_room), cell_size, max_cells);
     cap_bytes = chunk * cell_size;
-    CP2_HIP(ctx, hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
     hash_stream[0] = ctx->stream;
     CP2_TRY(aux_stream(ctx, &hash_stream[1]));
+    separate_copy_stream = env_size("CP2_INGEST_COPY_STREAM", 0) != 0;     // A/B tooling: uploads on a stream of their own, as until round 6
     for (int b = 0; b < ring; ++b) {
       CP2_TRY(pinned[b].alloc(ctx, cap_bytes));
       CP2_HIP(ctx, hipEventCreateWithFlags(&copied[b], hipEventDisableTiming));
-      CP2_HIP(ctx, hipEventRecord(copied[b], copy));
+      CP2_HIP(ctx, hipEventRecord(copied[b], ctx->stream));
       pin_depth = b + 1;
     }
     for (int b = 0; b < want_dev; ++b) {
       CP2_TRY(dev[b].scratch(ctx, cap_bytes));
       CP2_HIP(ctx, hipEventCreateWithFlags(&uploaded[b], hipEventDisableTiming));
       CP2_HIP(ctx, hipEventCreateWithFlags(&hashed[b], hipEventDisableTiming));
-      CP2_HIP(ctx, hipEventRecord(hashed[b], copy));
+      CP2_HIP(ctx, hipEventRecord(hashed[b], ctx->stream));
       dev_depth = b + 1;
     }
     if (threads > 1) pool.reset(new Workers(threads - 1));
@@ -496,18 +505,35 @@ struct IngestPipe {
     pool->wait_idle();
   }
   // the pinned buffer the host may fill next (blocks until the upload that last read it is done)
-  int acquire(uint8_t** buf) {
-    const int b = (int)(pin_turn % pin_depth);
+  int acquire(uint8_t** buf, size_t ahead = 0) {   // ahead = 1: the buffer of the ring turn AFTER the one about to be shipped
+    const int b = (int)((pin_turn + ahead) % pin_depth);
     CP2_HIP(ctx, hipEventSynchronize(copied[b]));
     *buf = pinned[b].u8();
     return CP2_OK;
   }
-  // the hash launch of this turn, behind the upload(s) just enqueued on the copy stream; *s = the hashing stream it went to
-  int hash_turn(int d, size_t m, size_t cell_size, uint8_t* leaves_out, bool leave_room, int* s) {
-    CP2_HIP(ctx, hipEventRecord(uploaded[d], copy));
-    const int side = serial ? 0 : (int)(turn & 1);
+  // Which stream carries a turn's upload?  The turn's OWN hashing stream (round 6): upload k, hash k, upload k + 2, hash k + 2 in order on
+  // one stream, the odd turns on the other -- while one stream hashes, the other uploads, and nothing needs an event between an upload and
+  // its kernel.  Until round 6 the uploads had a stream of their own; the runtime maps streams onto FOUR hardware queues, and with the
+  // null stream, the context's three and that one it was the fifth: it shared a queue with the second hashing stream, and every odd
+  // upload waited behind the hash launch queued there two turns earlier (first trace of the streamed build from files: uploads in pairs,
+  // the first of each pair starting exactly when hash k - 2 ended; profiles/r06_streamed_files_trace.txt).  The serial A/B order (one
+  // hashing stream) and CP2_INGEST_COPY_STREAM=1 keep the separate stream.
+  bool separate_copy_stream = false;
+  int upload_stream(int side, hipStream_t* us) {
+    if (!serial && !separate_copy_stream) { *us = hash_stream[side]; return CP2_OK; }
+    if (!copy) CP2_HIP(ctx, hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+    *us = copy;
+    return CP2_OK;
+  }
+  int turn_side() const { return serial ? 0 : (int)(turn & 1); }
+  // the hash launch of this turn, behind the upload(s) just enqueued on `us`; *s = the hashing stream it went to
+  int hash_turn(int d, size_t m, size_t cell_size, uint8_t* leaves_out, bool leave_room, int* s, hipStream_t us) {
+    const int side = turn_side();
     hipStream_t hs = hash_stream[side];
-    CP2_HIP(ctx, hipStreamWaitEvent(hs, uploaded[d], 0));
+    if (us != hs) {
+      CP2_HIP(ctx, hipEventRecord(uploaded[d], us));
+      CP2_HIP(ctx, hipStreamWaitEvent(hs, uploaded[d], 0));
+    }
     CP2_HIP(ctx, cp2k::launch_hash_cells(dev[d].p, cell_size, m, leaves_out, hs, leave_room));
     CP2_HIP(ctx, hipEventRecord(hashed[d], hs));
     if (side) last_aux_dev = d;
@@ -522,65 +548,132 @@ struct IngestPipe {
       ctx->err = "ingestion pipe: a turn that does not fit its ring buffer";
       return CP2_ERR_INVALID;
     }
-    CP2_HIP(ctx, hipStreamWaitEvent(copy, hashed[d], 0));       // the kernel that last read this device buffer
-    CP2_HIP(ctx, hipMemcpyAsync(dev[d].p, pinned[b].p, m * cell_size, hipMemcpyHostToDevice, copy));
-    CP2_HIP(ctx, hipEventRecord(copied[b], copy));
+    hipStream_t us = nullptr;
+    CP2_TRY(upload_stream(turn_side(), &us));
+    CP2_HIP(ctx, hipStreamWaitEvent(us, hashed[d], 0));         // the kernel that last read this device buffer (the same stream's own, with an even device ring)
+    CP2_HIP(ctx, hipMemcpyAsync(dev[d].p, pinned[b].p, m * cell_size, hipMemcpyHostToDevice, us));
+    CP2_HIP(ctx, hipEventRecord(copied[b], us));
     ++pin_turn;
     ++ring_chunks;
-    return hash_turn(d, m, cell_size, leaves_out, leave_room, s);
+    return hash_turn(d, m, cell_size, leaves_out, leave_room, s, us);
   }
 
-  // bytes [0, m * cell_size) of the turn [c0, c0 + m) of batch `g` into `buf`, from the slot files "<base><slot>.dat", zero-filled
-  // past the end of a file (slot.nim:61-66).  Every fill thread walks the pieces of its own byte range (ingest_piece) and opens
-  // the files it needs itself: nothing is held open between turns, however many files a turn touches.
+  // Bytes [0, m * cell_size) of the turn [c0, c0 + m) of batch `g` into `buf`, from the slot files "<base><slot>.dat", zero-filled
+  // past the end of a file (slot.nim:61-66).  The turn is cut into GRAINS of 4 MiB which the fill threads take from a shared counter
+  // (round 6; equal byte ranges, one per thread, before): the formatting threads of a streamed build compete for the same cores, and a
+  // fill thread that loses its core for a scheduler slice used to hold up the whole turn -- 2 ms per turn on configs[3] from files,
+  // whatever the turn's size (tools/streamed_files_ab.py over three chunk sizes).  Every thread walks the pieces of its grain
+  // (ingest_piece) and opens the files it needs itself: nothing is held open between turns, however many files a turn touches.
+  // The fill is POSTED and JOINED apart (fill_begin / fill_join), two turns deep: the building thread posts turn k + 1's fill before it
+  // joins turn k's, so a worker that finds no grain of turn k left goes straight on to turn k + 1 -- no thread waits at a turn's end
+  // for the slowest one (the joins cost the small-slot build a millisecond per turn while there was one fill at a time) -- and turn
+  // k's scheduling work (layer passes, the caller's sampling hook) runs on the building thread while the workers read.
   // O_DIRECT (cp2_set_ingest_direct / CP2_INGEST_DIRECT=1): slot files that are not in the page cache are read straight into
   // the pinned ring, whole 4 KiB blocks, without passing through (and evicting) the page cache; a piece whose file offset or
   // buffer address is not block aligned, the last partial block of a piece, and a file system that refuses O_DIRECT (tmpfs)
   // are read buffered.
-  int fill_from_files(const IngestGeom& g, const std::string& base, size_t c0, size_t m, uint8_t* buf, bool want_direct) {
+  struct FillJob {
+    IngestGeom g;
+    std::string base;
+    size_t c0 = 0, nbytes = 0, n_grains = 0;
+    uint8_t* buf = nullptr;
+    bool direct = false;
+    std::atomic<size_t> next{0};            // the next grain nobody has taken yet
     std::mutex mu;
-    std::string first_bad;
-    parallel_ranges(m * g.cell_size, (size_t)2 << 20, [&](size_t a, size_t b) {
-      for (size_t p = a; p < b;) {
-        const IngestPiece q = ingest_piece(g, c0, p, b);
-        const std::string fname = slot_file_name(base, q.slot);
-        const int fd = open(fname.c_str(), O_RDONLY);
-        if (fd < 0) {
-          std::lock_guard<std::mutex> lk(mu);
-          if (first_bad.empty()) first_bad = fname;
-          std::memset(buf + p, 0, q.len);
-          p += q.len;
-          continue;
+    std::condition_variable cv;
+    size_t done = 0;                        // grains completed (under mu)
+    std::string first_bad;                  // of the files that cannot be opened, the one of the LOWEST slot (whichever thread met it)
+    uint64_t first_bad_slot = ~0ULL;
+  };
+  std::deque<std::shared_ptr<FillJob>> jobs;   // posted, not yet joined: at most two (the turn about to be shipped and the one after it)
+  static void fill_range(FillJob& job, size_t a, size_t b) {
+    const IngestGeom& g = job.g;
+    uint8_t* buf = job.buf;
+    for (size_t p = a; p < b;) {
+      const IngestPiece q = ingest_piece(g, job.c0, p, b);
+      const std::string fname = slot_file_name(job.base, q.slot);
+      const int fd = open(fname.c_str(), O_RDONLY);
+      if (fd < 0) {
+        {
+          std::lock_guard<std::mutex> lk(job.mu);
+          if (q.slot < job.first_bad_slot) { job.first_bad_slot = q.slot; job.first_bad = fname; }
         }
-        size_t pos = 0;
-        if (want_direct && q.len >= DIRECT_ALIGN && q.file_off % DIRECT_ALIGN == 0 && reinterpret_cast<uintptr_t>(buf + p) % DIRECT_ALIGN == 0) {
-          const int dfd = open(fname.c_str(), O_RDONLY | O_DIRECT);
-          if (dfd >= 0) {
-            const size_t whole = q.len / DIRECT_ALIGN * DIRECT_ALIGN;
-            while (pos < whole) {
-              const ssize_t r = pread(dfd, buf + p + pos, whole - pos, (off_t)(q.file_off + pos));
-              if (r <= 0) break;
-              pos += (size_t)r;
-              if ((size_t)r % DIRECT_ALIGN) break;   // short, unaligned: end of file (the buffered reads below see that too)
-            }
-            close(dfd);
-          }
-        }
-        while (pos < q.len) {
-          const ssize_t r = pread(fd, buf + p + pos, q.len - pos, (off_t)(q.file_off + pos));
-          if (r <= 0) break;
-          pos += (size_t)r;
-        }
-        if (pos < q.len) std::memset(buf + p + pos, 0, q.len - pos);
-        close(fd);
+        std::memset(buf + p, 0, q.len);
         p += q.len;
+        continue;
       }
-    }, want_direct ? DIRECT_ALIGN : 1);
-    if (!first_bad.empty()) {
-      ctx->err = "cannot open " + first_bad;
+      size_t pos = 0;
+      if (job.direct && q.len >= DIRECT_ALIGN && q.file_off % DIRECT_ALIGN == 0 && reinterpret_cast<uintptr_t>(buf + p) % DIRECT_ALIGN == 0) {
+        const int dfd = open(fname.c_str(), O_RDONLY | O_DIRECT);
+        if (dfd >= 0) {
+          const size_t whole = q.len / DIRECT_ALIGN * DIRECT_ALIGN;
+          while (pos < whole) {
+            const ssize_t r = pread(dfd, buf + p + pos, whole - pos, (off_t)(q.file_off + pos));
+            if (r <= 0) break;
+            pos += (size_t)r;
+            if ((size_t)r % DIRECT_ALIGN) break;   // short, unaligned: end of file (the buffered reads below see that too)
+          }
+          close(dfd);
+        }
+      }
+      while (pos < q.len) {
+        const ssize_t r = pread(fd, buf + p + pos, q.len - pos, (off_t)(q.file_off + pos));
+        if (r <= 0) break;
+        pos += (size_t)r;
+      }
+      if (pos < q.len) std::memset(buf + p + pos, 0, q.len - pos);
+      close(fd);
+      p += q.len;
+    }
+  }
+  static void fill_grains(const std::shared_ptr<FillJob>& job) {   // any thread: grains of this job until none is left
+    size_t mine = 0;
+    for (;;) {
+      const size_t i = job->next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= job->n_grains) break;
+      size_t a = 0, b = 0;
+      ingest_grain(job->nbytes, INGEST_FILL_GRAIN, i, &a, &b);
+      fill_range(*job, a, b);
+      ++mine;
+    }
+    if (mine) {
+      std::lock_guard<std::mutex> lk(job->mu);
+      job->done += mine;
+      if (job->done == job->n_grains) job->cv.notify_all();
+    }
+  }
+  // post the fill of the turn [c0, c0 + m) into `buf`: the workers start on it as soon as they run out of grains of the job before
+  void fill_begin(const IngestGeom& g, const std::string& base, size_t c0, size_t m, uint8_t* buf, bool want_direct) {
+    auto job = std::make_shared<FillJob>();
+    job->g = g;
+    job->base = base;
+    job->c0 = c0;
+    job->nbytes = m * g.cell_size;
+    job->n_grains = ingest_grain_count(job->nbytes, INGEST_FILL_GRAIN);
+    job->buf = buf;
+    job->direct = want_direct;
+    jobs.push_back(job);
+    if (pool)
+      for (size_t t = 1; t < (size_t)threads && t < job->n_grains; ++t) pool->submit([job] { fill_grains(job); });
+  }
+  // the OLDEST posted fill is complete (this thread takes grains of it too; the workers may already be on the next job)
+  int fill_join() {
+    if (jobs.empty()) return CP2_OK;
+    std::shared_ptr<FillJob> job = jobs.front();
+    jobs.pop_front();
+    fill_grains(job);
+    {
+      std::unique_lock<std::mutex> lk(job->mu);
+      job->cv.wait(lk, [&] { return job->done == job->n_grains; });
+    }
+    if (!job->first_bad.empty()) {
+      ctx->err = "cannot open " + job->first_bad;
       return CP2_ERR_IO;
     }
     return CP2_OK;
+  }
+  void fill_join_all() {
+    while (!jobs.empty()) (void)fill_join();
   }
 
   // ---- mapped mode (round 5): chunks of a slot file that sit in the PAGE CACHE go to the device without a CPU copy.  The file is
@@ -594,9 +687,8 @@ struct IngestPipe {
   //     until `mapped_budget` bytes are registered, when everything uploaded so far is released in one go (one bubble per budget).
   //   * uploading from the UNregistered mapping (the runtime pins in place by itself) reaches 55 GB/s beside an idle device but only
   //     30 GB/s beside the hash kernel, and holds the host for the duration: slower than the ring.
-  // A turn that is not in the cache, reaches past the end of a file, touches more than MAX_MAPPED_PIECES files (small slots: one
-  // registration per file would cost more than the copy it saves) or cannot be registered goes through the ring as before; the two mix
-  // freely, turn by turn: either way the turn's device buffer holds the chunk when its `uploaded` event fires.
+  // A turn that is not (all) in the cache, reaches past the end of a file or cannot be registered goes through the ring as before; the
+  // two mix freely, turn by turn: either way the turn's device buffer holds the chunk when its `uploaded` event fires.
   // What is mapped of a file is the range of ONE unit (round 6; a whole slot when slots are not cut): S devices sharing a 128 GiB slot no
   // longer map it S times over.
   bool mapped_allowed = false, mapped_broken = false;
@@ -611,7 +703,8 @@ struct IngestPipe {
     const double t0 = now_ms();
     const size_t n_windows = windows.size(), bytes = registered_bytes;
     if (!windows.empty()) {
-      CP2_HIP(ctx, hipStreamSynchronize(copy));
+      for (hipStream_t st : {copy, hash_stream[0], hash_stream[1]})      // whichever carried uploads from these windows
+        if (st) CP2_HIP(ctx, hipStreamSynchronize(st));
       for (auto& w : windows) (void)hipHostUnregister(w.p);
       windows.clear();
       ++releases;
@@ -644,95 +737,119 @@ struct IngestPipe {
                    done.size(), now_ms() - t1);
     return CP2_OK;
   }
-  // the mapping of dataset unit `unit` (bytes [unit_off, unit_off + unit_bytes) of slot file `fname`, as far as the file reaches),
-  // made on first use; nullptr when the file cannot be mapped (the ring reads it, and reports a file that is not there)
-  const Mapping* mapping_of(uint64_t unit, const std::string& fname, size_t unit_off, size_t unit_bytes) {
-    for (auto& mp : mappings)
-      if (mp.open && mp.unit == unit) return &mp;
-    const int fd = open(fname.c_str(), O_RDONLY);
-    if (fd < 0) return nullptr;
-    struct stat sb;
-    const Mapping* got = nullptr;
-    const size_t page = 4096, lo = unit_off / page * page;
-    if (fstat(fd, &sb) == 0 && (size_t)sb.st_size > lo) {
-      const size_t hi = std::min<size_t>((size_t)sb.st_size, unit_off + unit_bytes);
-      void* p = mmap(nullptr, hi - lo, PROT_READ, MAP_SHARED, fd, (off_t)lo);   // nothing is read by this: pages that are not in the cache stay where they are
-      if (p != MAP_FAILED) {
-        mappings.push_back({static_cast<uint8_t*>(p), hi - lo, unit, lo, true});
-        got = &mappings.back();
-      }
-    }
-    close(fd);
-    return got;
-  }
   // the builder has moved past every unit before `unit`: their mappings go with the next release
   void mappings_done_before(uint64_t unit) {
     for (auto& mp : mappings)
       if (mp.unit < unit) mp.open = false;
   }
-  // bytes [off, off + len) of the mapping `base` (of `map_len` bytes): in the page cache and registrable?  mincore over every page of
-  // a 384 MiB chunk costs as much as the upload itself (98 304 page-cache lookups: 7 ms measured), so the chunk is SAMPLED: its
-  // first and last page and one page in every 256 KiB.  Caches fill and evict in far larger runs than that; a chunk that passes with
-  // a hole in it is still read correctly (the missing pages are faulted in while they are pinned), only more slowly.
-  bool try_window(uint8_t* base, size_t map_len, size_t off, size_t len) {
-    if (!mapped_allowed || mapped_broken || !base || len == 0 || off + len > map_len) return false;
-    const size_t page = 4096;
-    if (off % page || ((off + len) % page && off + len != map_len)) return false;   // windows are whole pages of their own: two registrations never share a page
-    const size_t stride = (size_t)256 << 10, last = (off + len - 1) / page * page;
-    unsigned char r = 0;
-    for (size_t at = off;; at += stride) {
-      if (at > last) at = last;
-      if (mincore(base + at, page, &r) != 0 || !(r & 1)) return false;   // not in the page cache: the ring path reads the chunk (buffered or O_DIRECT)
-      if (at == last) break;
-    }
-    const size_t n = std::min(map_len, (off + len + page - 1) / page * page) - off;
-    if (registered_bytes + n > mapped_budget && release_mapped() != CP2_OK) return false;
-    const hipError_t e = hipHostRegister(base + off, n, hipHostRegisterDefault);
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      mapped_broken = true;                          // this stack does not register file-backed pages: the ring from here on
-      if (std::getenv("CP2_TRACE")) std::fprintf(stderr, "[cp2 trace] slot files: hipHostRegister of %zu mapped bytes refused (%s): the pinned ring from here on\n", n, hipGetErrorString(e));
-      return false;
-    }
-    windows.push_back({base + off, n});
-    registered_bytes += n;
-    return true;
+  // f(i) for i in [0, n) dealt out over the fill threads (the calling thread takes its share)
+  template <typename F> void parallel_items(size_t n, F f) {
+    const int nt = (int)std::min<size_t>((size_t)threads, n);
+    if (nt <= 1 || !pool) { for (size_t i = 0; i < n; ++i) f(i); return; }
+    for (int t = 1; t < nt; ++t) pool->submit([=] { for (size_t i = (size_t)t; i < n; i += (size_t)nt) f(i); });
+    for (size_t i = 0; i < n; i += (size_t)nt) f(i);
+    pool->wait_idle();
   }
   // The turn [c0, c0 + m) straight from mappings of its files, when every piece of it is in the page cache and registered: uploads on
   // the copy stream, then the hash launch, like submit().  false (nothing enqueued): the ring takes the turn.
+  //
+  // One piece per file the turn touches.  Each piece needs its file mapped (the range of its unit, made on first use: a large slot's
+  // mapping serves all its turns), its pages found resident -- mincore, SAMPLED: over every page of a 384 MiB chunk it costs as much as
+  // the upload itself (98 304 page-cache lookups: 7 ms measured), so the first and last page and a page in every 256 KiB (at least every
+  // 16th of the piece) are looked at; caches fill and evict in far larger runs than that, and a piece that passes with a hole in it is
+  // still read correctly (the missing pages are faulted in while they are pinned), only more slowly -- and its window registered: whole
+  // pages of its own, two registrations never share a page.  Round 6: a turn of MANY small files goes this way too, the open / mmap /
+  // mincore / hipHostRegister of its pieces dealt out over the fill threads (48 files of 8 MiB per turn: registering them one after the
+  // other on the building thread would cost what the copy saves).
   bool try_mapped_turn(const IngestGeom& g, const std::string& base, size_t c0, size_t m, uint8_t* leaves_out, bool leave_room, int* s, int* status) {
     *status = CP2_OK;
     if (!mapped_allowed || mapped_broken) return false;
+    const size_t nbytes = m * g.cell_size, page = 4096, ub = g.unit_bytes();
+    if (nbytes > cap_bytes) return false;
     size_t u0 = 0, u1 = 0;
     ingest_turn_units(g, c0, m, &u0, &u1);
-    if (u1 - u0 + 1 > MAX_MAPPED_PIECES) return false;
     mappings_done_before(g.first_unit + u0);
-    struct Src { const uint8_t* p; size_t at, len; };
-    Src src[MAX_MAPPED_PIECES];
-    size_t n_src = 0;
-    const size_t nbytes = m * g.cell_size;
-    if (nbytes > cap_bytes) return false;
+    if (registered_bytes + nbytes + (u1 - u0 + 1) * page > mapped_budget && release_mapped() != CP2_OK) return false;
+    struct Pc {
+      IngestPiece q;
+      size_t at = 0;                                   // byte position in the turn's buffer
+      uint8_t* mbase = nullptr; size_t mlen = 0, moff = 0;   // the mapping (existing or made here) and where it starts in the file
+      bool made = false, registered = false;
+      size_t win_off = 0, win_n = 0;
+    };
+    std::vector<Pc> pcs;
     for (size_t p = 0; p < nbytes;) {
-      const IngestPiece q = ingest_piece(g, c0, p, nbytes);
-      const uint64_t unit = g.first_unit + q.unit;
-      const Mapping* mp = mapping_of(unit, slot_file_name(base, q.slot), (size_t)(unit % g.units_per_slot) * g.unit_bytes(), g.unit_bytes());
-      if (!mp || q.file_off < mp->file_off || n_src == MAX_MAPPED_PIECES) return false;
-      uint8_t* mbase = mp->base;                    // (try_window may release and drop OTHER mappings: take what is needed of this one first)
-      const size_t mlen = mp->len, moff = q.file_off - mp->file_off;
-      if (!try_window(mbase, mlen, moff, q.len)) return false;
-      src[n_src++] = {mbase + moff, p, q.len};
-      p += q.len;
+      Pc pc;
+      pc.q = ingest_piece(g, c0, p, nbytes);
+      pc.at = p;
+      const uint64_t unit = g.first_unit + pc.q.unit;
+      for (size_t i = mappings.size(); i-- > 0;)       // (the newest first: a large slot's mapping was made a few turns ago)
+        if (mappings[i].open && mappings[i].unit == unit) { pc.mbase = mappings[i].base; pc.mlen = mappings[i].len; pc.moff = mappings[i].file_off; break; }
+      pcs.push_back(pc);
+      p += pc.q.len;
     }
+    std::atomic<bool> refused{false};
+    std::atomic<int> refused_code{0};
+    const int device = ctx->device;
+    parallel_items(pcs.size(), [&](size_t i) {
+      Pc& pc = pcs[i];
+      if (!pc.mbase) {                                 // map the range of this piece's unit, as far as the file reaches
+        const uint64_t unit = g.first_unit + pc.q.unit;
+        const size_t unit_off = (size_t)(unit % g.units_per_slot) * ub, lo = unit_off / page * page;
+        const int fd = open(slot_file_name(base, pc.q.slot).c_str(), O_RDONLY);
+        if (fd < 0) return;                            // (the ring reads the turn, and reports a file that is not there)
+        struct stat sb;
+        if (fstat(fd, &sb) == 0 && (size_t)sb.st_size > lo) {
+          const size_t hi = std::min<size_t>((size_t)sb.st_size, unit_off + ub);
+          void* mp = mmap(nullptr, hi - lo, PROT_READ, MAP_SHARED, fd, (off_t)lo);   // nothing is read by this: pages that are not in the cache stay where they are
+          if (mp != MAP_FAILED) { pc.mbase = static_cast<uint8_t*>(mp); pc.mlen = hi - lo; pc.moff = lo; pc.made = true; }
+        }
+        close(fd);
+        if (!pc.mbase) return;
+      }
+      if (pc.q.file_off < pc.moff) return;
+      const size_t off = pc.q.file_off - pc.moff, len = pc.q.len;
+      if (off + len > pc.mlen) return;                                                   // reaches past the end of the file: the ring zero-fills
+      if (off % page || ((off + len) % page && off + len != pc.mlen)) return;            // windows are whole pages of their own
+      const size_t stride = std::max<size_t>((size_t)256 << 10, len / 16 / page * page), last = (off + len - 1) / page * page;
+      unsigned char r = 0;
+      for (size_t at = off;; at += stride) {
+        if (at > last) at = last;
+        if (mincore(pc.mbase + at, page, &r) != 0 || !(r & 1)) return;                   // not in the page cache: the ring reads the turn (buffered or O_DIRECT)
+        if (at == last) break;
+      }
+      const size_t n = std::min(pc.mlen, (off + len + page - 1) / page * page) - off;
+      (void)hipSetDevice(device);
+      const hipError_t e = hipHostRegister(pc.mbase + off, n, hipHostRegisterDefault);
+      if (e != hipSuccess) { refused = true; refused_code = (int)e; return; }
+      pc.registered = true;
+      pc.win_off = off;
+      pc.win_n = n;
+    });
+    bool all = true;
+    for (auto& pc : pcs) {
+      if (pc.made) mappings.push_back({pc.mbase, pc.mlen, g.first_unit + pc.q.unit, pc.moff, true});
+      if (pc.registered) { windows.push_back({pc.mbase + pc.win_off, pc.win_n}); registered_bytes += pc.win_n; }
+      else all = false;
+    }
+    if (refused) {
+      (void)hipGetLastError();
+      mapped_broken = true;                          // this stack does not register file-backed pages: the ring from here on
+      if (std::getenv("CP2_TRACE")) std::fprintf(stderr, "[cp2 trace] slot files: hipHostRegister of mapped file pages refused (%s): the pinned ring from here on\n", hipGetErrorString((hipError_t)refused_code.load()));
+    }
+    if (!all) return false;
     const int d = (int)(turn % dev_depth);
     auto fail = [&](hipError_t e, const char* what) { ctx->err = std::string(what) + ": " + hipGetErrorString(e); *status = CP2_ERR_HIP; return true; };
-    hipError_t e = hipStreamWaitEvent(copy, hashed[d], 0);
+    hipStream_t us = nullptr;
+    if (upload_stream(turn_side(), &us) != CP2_OK) { *status = CP2_ERR_HIP; return true; }
+    hipError_t e = hipStreamWaitEvent(us, hashed[d], 0);
     if (e != hipSuccess) return fail(e, "hipStreamWaitEvent");
-    for (size_t i = 0; i < n_src; ++i) {
-      e = hipMemcpyAsync(dev[d].u8() + src[i].at, src[i].p, src[i].len, hipMemcpyHostToDevice, copy);
+    for (auto& pc : pcs) {
+      e = hipMemcpyAsync(dev[d].u8() + pc.at, pc.mbase + pc.win_off, pc.q.len, hipMemcpyHostToDevice, us);
       if (e != hipSuccess) return fail(e, "hipMemcpyAsync from a mapped slot file");
     }
     ++mapped_chunks;
-    *status = hash_turn(d, m, g.cell_size, leaves_out, leave_room, s);
+    *status = hash_turn(d, m, g.cell_size, leaves_out, leave_room, s, us);
     return true;
   }
   // everything hashed on the second stream is ordered before whatever the caller enqueues next on the context's stream
@@ -824,18 +941,21 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
       if (!scratch->file_pipe) scratch->file_pipe = std::make_shared<IngestPipe>();
       pipe = static_cast<IngestPipe*>(scratch->file_pipe.get());
     }
+    const bool serial = group != 0 && stream_serial();             // A/B tooling: groups hashed on the first stream only, full occupancy
+    const bool leave_room = group != 0 && !serial && ctx->hash_room;
     StageTimer init_trace;
     if (!pipe->ctx) {
-      st = pipe->init(ctx, cell_size, total_cells);
+      st = pipe->init(ctx, cell_size, total_cells, leave_room);
       if (init_trace.on) init_trace.lap("slot files: pipe set up (rings, events, copy stream)");
     } else {
       pipe->rebatch(cell_size, total_cells);
     }
     LayerScheduler sched{t.get(), group, done};
     sched.detached = scratch != nullptr;          // (before init(): the choice of the layer stream depends on it)
-    sched.take_all = group != 0;                  // groups: the slots a turn completed go at once, the passes follow the turns
-    const bool serial = group != 0 && stream_serial();             // A/B tooling: groups hashed on the first stream only, full occupancy
-    const bool leave_room = group != 0 && !serial && ctx->hash_room;
+    // groups: passes of `group` slots (the caller's landing buffers hold that many), the last ones halving down to one ring turn's
+    // worth -- NOT a pass per turn: a pass costs the third stream ~10 ms whatever its size (layer_take, csrc/ingest_turns.hpp)
+    const char* ramp_env = std::getenv("CP2_STREAM_RAMP");                                                  // "0": A/B tooling
+    if (group != 0 && !(ramp_env && ramp_env[0] == '0')) sched.ramp_min = std::max<size_t>(1, pipe->chunk / n_cells);
     pipe->serial = serial;
     if (st == CP2_OK) st = sched.init();
     pipe->cell_multiple = 1;
@@ -849,24 +969,63 @@ int cp2i::trees_build_files(cp2_ctx* ctx, const std::string& base, uint64_t firs
     pipe->mapped_allowed = !want_direct && (ctx->ingest_mapped > 0 || (ctx->ingest_mapped < 0 && env_size("CP2_INGEST_MAPPED", 0) != 0));
     const size_t mapped0 = pipe->mapped_chunks, ring0 = pipe->ring_chunks;
     StageTimer ingest_trace;
-    for (size_t c0 = 0, m = 0; st == CP2_OK && c0 < total_cells; c0 += m) {
-      m = ingest_turn_cells(g, pipe->chunk, pipe->cell_multiple, pipe->turn, c0);
-      if (m == 0 || m > pipe->chunk || c0 + m > total_cells) {   // (never: csrc/ingest_turns.hpp is walked by the CPU suite; a wrong turn is a GPU fault)
+    // One turn = cells [c0, c0 + m) of the batch.  Ring turns are double-buffered on the HOST side too: turn k + 1's fill is posted
+    // behind turn k's before that is joined (the workers never idle between turns), and turn k's scheduling work -- the layer passes of
+    // the slots it completed and the caller's hook behind them (sampling, gathers, downloads, the hand-out of landed passes to the
+    // formatting threads: 30-odd runtime calls per turn) -- is done on this thread while they read.  With mapped ingestion allowed the
+    // turns go one after the other (whether a turn can be mapped is only known by trying, and a mapped turn has no fill to overlap).
+    struct Turn { size_t m = 0; uint8_t* buf = nullptr; bool filling = false; };
+    auto turn_cells = [&](size_t c0, size_t ahead, size_t* m) -> int {
+      *m = ingest_turn_cells(g, pipe->chunk, pipe->cell_multiple, pipe->turn + ahead, c0);
+      if (*m == 0 || *m > pipe->chunk || c0 + *m > total_cells) {   // (never: csrc/ingest_turns.hpp is walked by the CPU suite; a wrong turn is a GPU fault)
         ctx->err = "slot-file builder: a turn outside its ring buffer or its batch";
-        st = CP2_ERR_INVALID;
-        break;
+        return CP2_ERR_INVALID;
       }
-      uint8_t* leaves_out = t->nodes.u8() + c0 * 32;
+      return CP2_OK;
+    };
+    auto begin_turn = [&](size_t c0, size_t ahead, Turn* tn) -> int {      // size the turn, take a pinned buffer, post its fill
+      CP2_TRY(turn_cells(c0, ahead, &tn->m));
+      CP2_TRY(pipe->acquire(&tn->buf, ahead));
+      pipe->fill_begin(g, base, c0, tn->m, tn->buf, want_direct);
+      tn->filling = true;
+      return CP2_OK;
+    };
+    const bool ahead_ok = !pipe->mapped_allowed && pipe->pin_depth >= 2;
+    Turn cur;
+    double t_post = 0, t_join = 0, t_submit = 0, t_sched = 0;   // CP2_TRACE: where the building thread's time goes
+    size_t n_turns = 0;
+    for (size_t c0 = 0; st == CP2_OK && c0 < total_cells; ++n_turns) {
       int side = 0;
-      if (!pipe->try_mapped_turn(g, base, c0, m, leaves_out, leave_room, &side, &st)) {
-        uint8_t* buf = nullptr;
-        st = pipe->acquire(&buf);
-        if (st == CP2_OK) st = pipe->fill_from_files(g, base, c0, m, buf, want_direct);
-        if (st == CP2_OK) st = pipe->submit(m, cell_size, leaves_out, leave_room, &side);
+      bool mapped = false;
+      double w0 = ingest_trace.on ? now_ms() : 0;
+      if (!cur.filling) {
+        st = turn_cells(c0, 0, &cur.m);
+        if (st != CP2_OK) break;
+        if (pipe->mapped_allowed) mapped = pipe->try_mapped_turn(g, base, c0, cur.m, t->nodes.u8() + c0 * 32, leave_room, &side, &st);
+        if (!mapped && st == CP2_OK) st = begin_turn(c0, 0, &cur);
       }
+      const size_t c1 = c0 + cur.m;
+      Turn nxt;
+      if (!mapped && st == CP2_OK && c1 < total_cells && ahead_ok) st = begin_turn(c1, 1, &nxt);   // posted BEHIND this turn's fill, before it is joined
+      double w1 = ingest_trace.on ? now_ms() : 0;
+      double w2 = w1;
+      if (!mapped && st == CP2_OK) {
+        st = pipe->fill_join();
+        cur.filling = false;
+        w2 = ingest_trace.on ? now_ms() : 0;
+        if (st == CP2_OK) st = pipe->submit(cur.m, cell_size, t->nodes.u8() + c0 * 32, leave_room, &side);
+      }
+      double w3 = ingest_trace.on ? now_ms() : 0;
       if (st == CP2_OK) st = sched.hashed_on(side);
-      if (st == CP2_OK) st = sched.advance(c0 + m, c0 + m == total_cells, side);
+      if (st == CP2_OK) st = sched.advance(c1, c1 == total_cells, side);
+      if (ingest_trace.on) { const double w4 = now_ms(); t_post += w1 - w0; t_join += w2 - w1; t_submit += w3 - w2; t_sched += w4 - w3; }
+      c0 = c1;
+      cur = nxt;
     }
+    pipe->fill_join_all();                        // (an error above may leave fills in flight)
+    if (ingest_trace.on)
+      std::fprintf(stderr, "[cp2 trace] slot files: %zu turn(s); the building thread spent %.1f ms posting fills (incl. waiting for a pinned buffer), %.1f ms in fills (its own grains + waiting for the workers), %.1f ms submitting, %.1f ms on layer passes + the caller's hook\n",
+                   n_turns, t_post, t_join, t_submit, t_sched);
     pipe->mappings_done_before(~0ULL);            // (they stay mapped until their windows are released: the pipe's end, or the next release)
     if (scratch) scratch->tail_stream = sched.layer_stream();   // where the batch ends: the caller's copy-out follows the layer passes there
     int fin = sched.finish();
@@ -1307,6 +1466,7 @@ extern "C" int cp2_slot_trees_attach_cells(cp2_slot_trees* t, const uint8_t* hos
 extern "C" void cp2_slot_trees_free(cp2_slot_trees* t) {
   if (!t) return;
   if (t->nodes.borrowed) { delete t; return; }   // a pipelined batch: its nodes belong to the pipeline's scratch, whose owner does the waiting
+  if (t->ctx->stuck) { delete t; return; }        // its streams will not drain: nothing is waited for, the node buffer is dropped from the books (DevBuf::release)
   (void)hipSetDevice(t->ctx->device);
   (void)hipStreamSynchronize(t->ctx->stream);
   if (t->ctx->aux_stream) (void)hipStreamSynchronize(t->ctx->aux_stream);

@@ -28,14 +28,14 @@ static uint64_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 
 struct Shape {
   IngestGeom g;
   size_t chunk_bytes, cell_multiple, pipe_turn0, group;
-  bool take_all;
+  bool take_all, ramp;
   int threads;
 };
 
 [[noreturn]] static void fail(const Shape& s, const char* what, size_t turn, size_t c0, size_t m) {
-  std::printf("FAILED: %s  (units %zu x %zu cells of %zu B, first_unit %llu, units_per_slot %llu, chunk %zu B, cell_multiple %zu, pipe turn %zu, group %zu take_all %d, threads %d: turn %zu at cell %zu, %zu cells)\n",
+  std::printf("FAILED: %s  (units %zu x %zu cells of %zu B, first_unit %llu, units_per_slot %llu, chunk %zu B, cell_multiple %zu, pipe turn %zu, group %zu take_all %d ramp %d, threads %d: turn %zu at cell %zu, %zu cells)\n",
               what, s.g.n_units, s.g.n_cells, s.g.cell_size, (unsigned long long)s.g.first_unit, (unsigned long long)s.g.units_per_slot, s.chunk_bytes, s.cell_multiple,
-              s.pipe_turn0, s.group, (int)s.take_all, s.threads, turn, c0, m);
+              s.pipe_turn0, s.group, (int)s.take_all, (int)s.ramp, s.threads, turn, c0, m);
   std::exit(1);
 }
 
@@ -43,6 +43,7 @@ struct Shape {
 struct LayerWalk {
   size_t n_slots, n_cells, group;
   bool take_all;
+  size_t ramp_min = 0;
   size_t built = 0, passes = 0, max_pass = 0;
   std::vector<uint8_t> times;
   LayerWalk(size_t ns, size_t nc, size_t g, bool ta) : n_slots(ns), n_cells(nc), group(g), take_all(ta), times(ns, 0) {}
@@ -50,7 +51,7 @@ struct LayerWalk {
   bool advance(size_t cells_hashed, bool final) {
     const size_t complete = cells_hashed / n_cells;
     for (;;) {
-      const size_t take = layer_take(complete, built, group, take_all, final);
+      const size_t take = layer_take(complete, built, group, take_all, final, n_slots, ramp_min);
       if (!take) return true;
       if (built + take > complete || built + take > n_slots) return false;        // a slot whose cells are not all enqueued yet
       for (size_t s = built; s < built + take; ++s) ++times[s];
@@ -73,6 +74,7 @@ static long check_shape(const Shape& s, long* pieces_out, long* bytes_checked) {
   if (chunk == 0 || chunk > total) fail(s, "ring-slot capacity out of range", 0, 0, chunk);
   const size_t cap_bytes = chunk * g.cell_size;
   LayerWalk layers(g.n_units, g.n_cells, s.group, s.take_all);
+  layers.ramp_min = s.ramp ? std::max<size_t>(1, chunk / g.n_cells) : 0;       // as the slot-file builder sets it
   size_t turns = 0;
   long pieces = 0;
   for (size_t c0 = 0, m = 0; c0 < total; c0 += m, ++turns) {
@@ -92,14 +94,22 @@ static long check_shape(const Shape& s, long* pieces_out, long* bytes_checked) {
     if (u0 > u1 || u1 >= g.n_units || u0 != c0 / g.n_cells) fail(s, "turn's unit range", turns, c0, m);
     // ---- the fill: ranges tile the buffer, pieces tile the ranges
     const size_t nbytes = m * g.cell_size;
+    // two ways the product cuts a turn's bytes: grains from a shared counter (slot files: fill_begin / fill_grains) and equal ranges,
+    // one per thread (host arrays: parallel_ranges); a shape walks one of them, grains also far below the product's 4 MiB so that
+    // small shapes split
     const size_t align = (s.cell_multiple > 1) ? 4096 : 1;
-    const int nt = ingest_fill_threads(nbytes, ((size_t)2 << 20) >> (rnd() % 12), s.threads);    // (also grains far below 2 MiB, so that small shapes split)
+    const bool by_grains = (rnd() & 1) != 0;
+    const size_t grain = by_grains ? std::max<size_t>(std::max<size_t>(align, (nbytes / 512 + align - 1) / align * align), (INGEST_FILL_GRAIN >> (rnd() % 14)) / align * align) : 0;   // (at most ~512 grains per turn: the walk stays short)
+    const int nt = by_grains ? (int)ingest_grain_count(nbytes, grain) : ingest_fill_threads(nbytes, ((size_t)2 << 20) >> (rnd() % 12), s.threads);
     const bool real = nbytes <= ((size_t)1 << 14);
     std::vector<uint8_t> buf, hits;
     if (real) { buf.assign(nbytes, 0); hits.assign(nbytes, 0); }
     size_t prev_end = 0;
+    if (INGEST_FILL_GRAIN % 4096) fail(s, "the fill grain is not a multiple of the O_DIRECT granule", turns, c0, m);
     for (int t = 0; t < nt; ++t) {
-      const size_t a = ingest_range_cut(nbytes, align, nt, t), b = ingest_range_cut(nbytes, align, nt, t + 1);
+      size_t a = 0, b = 0;
+      if (by_grains) ingest_grain(nbytes, grain, (size_t)t, &a, &b);
+      else { a = ingest_range_cut(nbytes, align, nt, t); b = ingest_range_cut(nbytes, align, nt, t + 1); }
       if (a != prev_end || b < a || b > nbytes) fail(s, "fill ranges do not tile the turn's buffer", turns, c0, m);
       if (t > 0 && a % align) fail(s, "inner fill boundary off the O_DIRECT granule", turns, c0, m);
       prev_end = b;
@@ -172,7 +182,7 @@ int main(int argc, char** argv) {
   // the shapes the round's measurements run, literally: configs[3]'s scale-down and nominal slots, default ring slot
   {
     Shape s{};
-    s.g.n_units = 4096; s.g.n_cells = 4096; s.g.cell_size = 2048; s.chunk_bytes = (size_t)384 << 20; s.cell_multiple = 1; s.group = 256; s.take_all = true; s.threads = 8;
+    s.g.n_units = 4096; s.g.n_cells = 4096; s.g.cell_size = 2048; s.chunk_bytes = (size_t)512 << 20; s.cell_multiple = 1; s.group = 256; s.take_all = false; s.ramp = true; s.threads = 8;
     turns += check_shape(s, &pieces, &bytes); ++shapes;
     s.g.n_units = 4; s.g.n_cells = (size_t)1 << 22; s.cell_multiple = 2; s.group = 1;
     turns += check_shape(s, &pieces, &bytes); ++shapes;
@@ -194,7 +204,8 @@ int main(int argc, char** argv) {
     }
     s.pipe_turn0 = (rnd() % 3 == 0) ? rnd() % 50 : 0;
     s.group = (rnd() % 3 == 0) ? 0 : 1 + rnd() % ((rnd() % 2) ? 8 : 600);
-    s.take_all = s.group != 0 && (rnd() % 4 != 0);
+    s.take_all = s.group != 0 && (rnd() % 4 == 0);
+    s.ramp = s.group != 0 && !s.take_all && (rnd() % 3 != 0);
     s.threads = 1 + (int)(rnd() % 16);
     const size_t chunk = ingest_chunk_cells(s.chunk_bytes, s.g.cell_size, s.g.total_cells());
     if (s.g.total_cells() / chunk > 400) continue;   // (shapes of very many turns prove nothing more: skip them)

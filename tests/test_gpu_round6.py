@@ -172,7 +172,7 @@ import __graft_entry__ as g
 pkg = g.load_package()
 cfg = pkg.make_config(maxDepth=8, maxLog2NSlots=3, cellSize=128, blockSize=512, nSlots=6, nCells=16, nSamples=3, seed=7)
 m = pkg.Multi([0, 0])
-m.set_policy(pkg.GATHER_COPY, 0)
+m.set_policy(pkg.GATHER_COPY, 1)                       # one cell per device is enough for a shard: two shards, a real exchange
 out = {}
 t0 = time.time()
 try:

@@ -34,16 +34,16 @@ def test_fake_builder_turn_plan_with_sanitizers(tmp_path):
 def test_slot_file_builder_plan_and_layer_scheduler_with_sanitizers(tmp_path):
     """The slot-file builder's arithmetic (csrc/ingest_turns.hpp: turns over a batch of slot files, the fill threads' byte
     ranges, which file bytes a turn's buffer holds) and the layer scheduler's decision (layer_take), the very header
-    trees_build_files / LayerScheduler use: walked over 1.2e5 shapes under AddressSanitizer + UBSan -- every turn has a buffer of
+    trees_build_files / LayerScheduler use: walked over 1e5 shapes under AddressSanitizer + UBSan -- every turn has a buffer of
     sufficient size, every buffer byte is written once from the file byte slot.nim:57-68 reads, every slot's layers are built
     exactly once after its last cell; the same layer walk over the fake-data builder's plans.  No GPU."""
     exe = str(tmp_path / "ingest_plan_check")
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                            "-I" + os.path.join(ROOT, "codex-storage-proofs-circuits_amd", "csrc"), "-o", exe,
                            os.path.join(ROOT, "tests", "host_check", "ingest_plan_check.cpp")])
-    r = subprocess.run([exe, "120000"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([exe, "100000"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "ingest plan ok: 120000 shapes" in r.stdout, r.stdout
+    assert "ingest plan ok: 100000 shapes" in r.stdout, r.stdout
 
 
 def _build_text_check(pkg, tmp_path, sanitize=("-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"), name="host_text_check"):

@@ -1,0 +1,19 @@
+#!/bin/bash
+# round 6: passes of `group` slots with a ramp-down (not a pass per ring turn)
+set -o pipefail
+O=gpurun_out/r6s14
+mkdir -p $O
+timeout -k 10 900 python -m pytest tests/test_gpu_round6.py -q -m gpu -x > $O/pytest.txt 2>&1 || { tail -30 $O/pytest.txt; exit 1; }
+tail -2 $O/pytest.txt
+CP2_TRACE=1 timeout -k 10 300 python tools/streamed_files_ab.py /dev/shm small - 3 > $O/small_default.txt 2>&1 || { tail -5 $O/small_default.txt; exit 1; }
+echo "default: $(grep 'file/fake' $O/small_default.txt)"
+grep -E "building thread" $O/small_default.txt | tail -1 | cut -c1-300
+grep -E "sampling hook" $O/small_default.txt | tail -2 | cut -c1-220
+CP2_INGEST_CHUNK_MB=256 timeout -k 10 300 python tools/streamed_files_ab.py /dev/shm small - 2 > $O/small_256.txt 2>&1 || exit 1
+echo "256: $(grep 'file/fake' $O/small_256.txt)"
+CP2_INGEST_CHUNK_MB=384 timeout -k 10 300 python tools/streamed_files_ab.py /dev/shm small - 2 > $O/small_384.txt 2>&1 || exit 1
+echo "384: $(grep 'file/fake' $O/small_384.txt)"
+CP2_INGEST_CHUNK_MB=1024 timeout -k 10 300 python tools/streamed_files_ab.py /dev/shm small - 2 > $O/small_1024.txt 2>&1 || exit 1
+echo "1024: $(grep 'file/fake' $O/small_1024.txt)"
+timeout -k 10 500 python tools/streamed_files_ab.py /dev/shm big 16 2 > $O/big_default.txt 2>&1 || exit 1
+echo "big: $(grep 'file/fake' $O/big_default.txt)"

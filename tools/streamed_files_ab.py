@@ -22,7 +22,7 @@ which = sys.argv[2] if len(sys.argv) > 2 else "both"
 big_slots = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] != "-" else 16
 repeats = int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4] != "-" else 3
 ENTROPY, SEED, CS = 1234567, 12345, 2048
-thr = max(1, min(16, len(os.sched_getaffinity(0))))
+thr = int(os.environ.get("SFAB_THREADS", "0")) or max(1, min(16, len(os.sched_getaffinity(0))))   # formatting threads (SFAB_THREADS: sweeps)
 ctx = pkg.Context(0)
 dev = torch.device("cuda", 0)
 
@@ -43,18 +43,26 @@ def write_slots(base, n_slots, n_cells):
     print("wrote %d slot files of %.3f GiB in %.1f s" % (n_slots, n_cells * CS / 2**30, time.time() - t0), flush=True)
 
 
+def cpu_seconds():
+    import resource
+    r = resource.getrusage(resource.RUSAGE_SELF)          # every thread of the process: fill threads, formatting threads, the runtime's own
+    return r.ru_utime + r.ru_stime
+
+
 def one(cfg, n_slots, check_slots):
+    c0 = cpu_seconds()
     t = time.perf_counter()
     sd = ctx.dataset_streamed(cfg, ENTROPY, threads=thr)
     tb = time.perf_counter() - t
     sd.set_roots(None)
     nbytes = sd.export_streamed(None, threads=thr)
     dt = time.perf_counter() - t
+    cpu = cpu_seconds() - c0
     root = np.asarray(sd.root(), dtype=np.uint8).tobytes()
     roots = hashlib.sha256(np.asarray(sd.local_roots(), dtype=np.uint8).tobytes()).hexdigest()
     texts = {s: hashlib.sha256(sd.streamed_json(s).encode()).hexdigest() for s in check_slots}
     sd.free()
-    return {"build_s": tb, "total_s": dt, "json_bytes": int(nbytes), "root": root.hex(), "roots_sha": roots, "texts": texts}
+    return {"build_s": tb, "total_s": dt, "cpu_s": cpu, "json_bytes": int(nbytes), "root": root.hex(), "roots_sha": roots, "texts": texts}
 
 
 def shape(label, n_slots, n_cells, max_log2):
@@ -72,8 +80,8 @@ def shape(label, n_slots, n_cells, max_log2):
             for src, cfg in (("file", cfg_file), ("fake", cfg_fake)):
                 x = one(cfg, n_slots, check)
                 runs[src].append(x)
-                print("%-5s %-4s run %d: build with bodies %.4f s, total %.4f s -> %.1f witnesses/s, %.2f GB/s of cells, json %d bytes" %
-                      (label, src, r, x["build_s"], x["total_s"], n_slots / x["total_s"], n_slots * n_cells * CS / x["total_s"] / 1e9, x["json_bytes"]), flush=True)
+                print("%-5s %-4s run %d: build with bodies %.4f s, total %.4f s -> %.1f witnesses/s, %.2f GB/s of cells, json %d bytes; %.2f CPU-seconds = %.1f cores busy" %
+                      (label, src, r, x["build_s"], x["total_s"], n_slots / x["total_s"], n_slots * n_cells * CS / x["total_s"] / 1e9, x["json_bytes"], x["cpu_s"], x["cpu_s"] / x["total_s"]), flush=True)
         same = all(a["root"] == b["root"] and a["roots_sha"] == b["roots_sha"] and a["texts"] == b["texts"] and a["json_bytes"] == b["json_bytes"]
                    for a in runs["file"] for b in runs["fake"])
         best = {s: min(x["total_s"] for x in runs[s][1:]) for s in runs}
@@ -81,6 +89,7 @@ def shape(label, n_slots, n_cells, max_log2):
                     "witnesses_per_s": {s: round(n_slots / v, 1) for s, v in best.items()},
                     "cells_GB_per_s": {s: round(n_slots * n_cells * CS / v / 1e9, 2) for s, v in best.items()},
                     "file_over_fake": round(best["fake"] / best["file"], 4),
+                    "cpu_seconds_per_run": {s: round(min(x["cpu_s"] for x in runs[s][1:]), 2) for s in runs},
                     "roots_and_%d_texts_identical_file_vs_fake" % len(check): same})
         print("%-5s file/fake witnesses/s = %.4f; dataset root, slot roots and %d full texts identical: %s" % (label, res["file_over_fake"], len(check), same), flush=True)
     finally:

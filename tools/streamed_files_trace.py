@@ -116,7 +116,9 @@ def summarize(d, out_path=None):
         small = {nm: [(a, b) for n, a, b, _ in seg if nm in n] for nm in ("k_compress_layer", "k_sample_paths", "k_gather_rows")}
         if not hashk:
             continue
-        t0, t1 = min(a for a, _ in hashk + gen), max(b for _, a, b, _ in seg)
+        # the build: from the marker to the last gather of the last pass (what follows in the segment -- the dataset tree, the texts
+        # read back, the free -- is not the streamed build)
+        t0, t1 = lo, max(b for n, a, b, _ in seg if "k_gather_rows" in n)
         span = t1 - t0
         h2d = [(a, b) for dname, a, b in M if t0 <= a < t1 and ("HOST_TO_DEVICE" in dname.upper() or "H2D" in dname.upper())]
         d2h = [(a, b) for dname, a, b in M if t0 <= a < t1 and ("DEVICE_TO_HOST" in dname.upper() or "D2H" in dname.upper())]
