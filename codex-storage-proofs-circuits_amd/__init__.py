@@ -210,6 +210,8 @@ def load_library():
         "cp2_write_circom_main": (i32, [ctypes.POINTER(Config), cp]),
     }
     for name, (res, args) in sigs.items():
+        if v is None and name == "cp2_abi_version":
+            continue           # (an older library named on purpose through CODEX_P2_LIB: A/B tooling)
         f = getattr(L, name)   # AttributeError if the header and the library ever disagree
         f.restype, f.argtypes = res, args
     L._cp2_signatures = sigs

@@ -82,6 +82,17 @@ def shape(label, n_slots, n_cells, max_log2):
                 runs[src].append(x)
                 print("%-5s %-4s run %d: build with bodies %.4f s, total %.4f s -> %.1f witnesses/s, %.2f GB/s of cells, json %d bytes; %.2f CPU-seconds = %.1f cores busy" %
                       (label, src, r, x["build_s"], x["total_s"], n_slots / x["total_s"], n_slots * n_cells * CS / x["total_s"] / 1e9, x["json_bytes"], x["cpu_s"], x["cpu_s"] / x["total_s"]), flush=True)
+        # the plain tree build of the same slots (no proof inputs: launches at full occupancy, one layer pass at the end), file and fake
+        plain = {"file": [], "fake": []}
+        for r in range(3):
+            for src, cfg in (("file", cfg_file), ("fake", cfg_fake)):
+                t = time.perf_counter()
+                ds = ctx.dataset(cfg)
+                plain[src].append(time.perf_counter() - t)
+                ds.free()
+        print("%-5s plain tree build (no proof inputs): file %s s, fake %s s -> file/fake rate %.4f" %
+              (label, [round(x, 4) for x in plain["file"]], [round(x, 4) for x in plain["fake"]], min(plain["fake"][1:]) / min(plain["file"][1:])), flush=True)
+        res["plain_tree_build_s"] = {k: round(min(v[1:]), 4) for k, v in plain.items()}
         same = all(a["root"] == b["root"] and a["roots_sha"] == b["roots_sha"] and a["texts"] == b["texts"] and a["json_bytes"] == b["json_bytes"]
                    for a in runs["file"] for b in runs["fake"])
         best = {s: min(x["total_s"] for x in runs[s][1:]) for s in runs}

@@ -168,9 +168,29 @@ def summarize(d, out_path=None):
     print(text)
 
 
+def timeline(d, first=4, last=16):
+    """per turn of the measured build from files: when its upload and its hash launch started and ended (ms from the build's start)"""
+    kt = sorted(glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True), key=os.path.getsize)[-1]
+    mc = sorted(glob.glob(os.path.join(d, "**", "*_memory_copy_trace.csv"), recursive=True), key=os.path.getsize)[-1]
+    K = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r["Grid_Size_X"]), r.get("Stream_Id", "?")) for r in csv.DictReader(open(kt)))
+    M = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Direction"], r.get("Stream_Id", "?")) for r in csv.DictReader(open(mc)))
+    mk = [k for k in K if "k_permute_batch" in k[2] and k[3] <= 256]
+    lo, hi = mk[2][1], mk[3][0]
+    H = [k for k in K if lo <= k[0] < hi and "k_hash_cells" in k[2]]
+    U = [m for m in M if lo <= m[0] < hi and "HOST_TO_DEVICE" in m[2] and m[1] - m[0] > 500000]
+    prev_end = lo
+    for i, (h, u) in enumerate(zip(H, U)):
+        if first <= i < last:
+            print("turn %2d: upload %7.2f .. %7.2f on stream %s | hash %7.2f .. %7.2f on stream %s (%d cells) | the upload started %+.2f ms from the end of hash %d, the hash %+.2f ms from the end of the hash before it" %
+                  (i, (u[0] - lo) / 1e6, (u[1] - lo) / 1e6, u[3], (h[0] - lo) / 1e6, (h[1] - lo) / 1e6, h[4], h[3], (u[0] - H[i - 2][1]) / 1e6 if i >= 2 else 0.0, i - 2, (h[0] - prev_end) / 1e6))
+        prev_end = max(prev_end, h[1])
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "run":
         run(sys.argv[2] if len(sys.argv) > 2 else None)
+    elif len(sys.argv) > 2 and sys.argv[1] == "timeline":
+        timeline(sys.argv[2])
     elif len(sys.argv) > 2 and sys.argv[1] == "summarize":
         summarize(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
     else:
