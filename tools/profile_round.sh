@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence bench.py's roofline refers to.  Run ON THE GPU BOX from the repo root:
-#   bash tools/profile_round.sh r05
+#   bash tools/profile_round.sh r06
 # kernel-trace/stats and every --pmc group are separate runs (gpurun refuses --pmc combined with trace domains).
 # The program after `--` is python3 itself (no env / bash -c hop: the profiler's preload initialises the GPU first).
 set -e
-R=${1:-r05}
+R=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/prof_$R
 cd $GRAFT_REPO_ROOT
