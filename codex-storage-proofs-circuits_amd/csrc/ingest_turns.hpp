@@ -102,18 +102,8 @@ inline IngestPiece ingest_piece(const IngestGeom& g, size_t c0, size_t p, size_t
   return q;
 }
 
-// The fill threads' byte ranges of a turn of n bytes: thread t of nt takes [cut(t), cut(t + 1)); inner boundaries are multiples of
-// `align` (O_DIRECT reads need block-aligned offsets), whole `align`-sized pieces are dealt out evenly, the last range takes the rest.
-inline int ingest_fill_threads(size_t n, size_t grain, int threads) {
-  return (int)std::min<size_t>((size_t)std::max(1, threads), std::max<size_t>(1, n / std::max<size_t>(1, grain)));
-}
-inline size_t ingest_range_cut(size_t n, size_t align, int nt, int t) {
-  if (t >= nt) return n;
-  return (size_t)((unsigned __int128)(n / align) * (unsigned)t / (unsigned)nt) * align;
-}
-
-// The fill of a slot-file turn: grains of INGEST_FILL_GRAIN bytes (a multiple of the O_DIRECT granule), taken by the fill threads
-// from a shared counter; grain i of a turn of n bytes is [a, b).
+// The fill of a turn (slot files: pread; host arrays: memcpy): grains of INGEST_FILL_GRAIN bytes (a multiple of the O_DIRECT granule),
+// taken by the fill threads from a shared counter; grain i of a turn of n bytes is [a, b).
 constexpr size_t INGEST_FILL_GRAIN = (size_t)4 << 20;
 inline size_t ingest_grain_count(size_t n, size_t grain) { return (n + grain - 1) / grain; }
 inline void ingest_grain(size_t n, size_t grain, size_t i, size_t* a, size_t* b) {

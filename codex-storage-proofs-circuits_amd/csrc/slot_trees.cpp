@@ -494,16 +494,6 @@ struct IngestPipe {
   // a pipe that outlives builder calls: the next batch's chunk size (its buffers were sized by the first batch)
   bool fits(size_t cell_size) const { return cap_bytes >= cell_size; }
   void rebatch(size_t cell_size, size_t max_cells) { chunk = std::max<size_t>(1, std::min(max_cells, cap_bytes / cell_size)); }
-  // f(a, b) over [0, n) split across the fill threads (the calling thread takes the first range); inner boundaries are
-  // multiples of `align` (O_DIRECT reads need block-aligned offsets)
-  template <typename F> void parallel_ranges(size_t n, size_t grain, F f, size_t align = 1) {
-    const int nt = ingest_fill_threads(n, grain, threads);
-    if (nt <= 1 || !pool) { f(0, n); return; }
-    auto cut = [=](int t) { return ingest_range_cut(n, align, nt, t); };   // csrc/ingest_turns.hpp
-    for (int t = 1; t < nt; ++t) pool->submit([=] { f(cut(t), cut(t + 1)); });
-    f(0, cut(1));
-    pool->wait_idle();
-  }
   // the pinned buffer the host may fill next (blocks until the upload that last read it is done)
   int acquire(uint8_t** buf, size_t ahead = 0) {   // ahead = 1: the buffer of the ring turn AFTER the one about to be shipped
     const int b = (int)((pin_turn + ahead) % pin_depth);
@@ -577,6 +567,7 @@ struct IngestPipe {
     std::string base;
     size_t c0 = 0, nbytes = 0, n_grains = 0;
     uint8_t* buf = nullptr;
+    const uint8_t* mem = nullptr;           // non-null: the turn's bytes are copied from host memory at `mem` (host arrays) instead of read from slot files
     bool direct = false;
     std::atomic<size_t> next{0};            // the next grain nobody has taken yet
     std::mutex mu;
@@ -587,6 +578,7 @@ struct IngestPipe {
   };
   std::deque<std::shared_ptr<FillJob>> jobs;   // posted, not yet joined: at most two (the turn about to be shipped and the one after it)
   static void fill_range(FillJob& job, size_t a, size_t b) {
+    if (job.mem) { std::memcpy(job.buf + a, job.mem + a, b - a); return; }
     const IngestGeom& g = job.g;
     uint8_t* buf = job.buf;
     for (size_t p = a; p < b;) {
@@ -643,11 +635,12 @@ struct IngestPipe {
     }
   }
   // post the fill of the turn [c0, c0 + m) into `buf`: the workers start on it as soon as they run out of grains of the job before
-  void fill_begin(const IngestGeom& g, const std::string& base, size_t c0, size_t m, uint8_t* buf, bool want_direct) {
+  void fill_begin(const IngestGeom& g, const std::string& base, size_t c0, size_t m, uint8_t* buf, bool want_direct, const uint8_t* mem = nullptr) {
     auto job = std::make_shared<FillJob>();
     job->g = g;
     job->base = base;
     job->c0 = c0;
+    job->mem = mem;
     job->nbytes = m * g.cell_size;
     job->n_grains = ingest_grain_count(job->nbytes, INGEST_FILL_GRAIN);
     job->buf = buf;
@@ -868,14 +861,29 @@ int cp2i::hash_host_cells_pipelined(cp2_ctx* ctx, const uint8_t* cells, size_t c
   CP2_TRY(pipe.init(ctx, cell_size, n));
   IngestGeom g;
   g.n_units = 1; g.n_cells = n; g.cell_size = cell_size;
-  for (size_t c0 = 0, m = 0; c0 < n; c0 += m) {
-    m = ingest_turn_cells(g, pipe.chunk, 1, pipe.turn, c0);
-    uint8_t* buf = nullptr;
-    CP2_TRY(pipe.acquire(&buf));
-    const uint8_t* src = cells + c0 * cell_size;
-    pipe.parallel_ranges(m * cell_size, (size_t)2 << 20, [=](size_t a, size_t b) { std::memcpy(buf + a, src + a, b - a); });
-    CP2_TRY(pipe.submit(m, cell_size, d_leaves + c0 * 32));
+  // turns like the slot-file builder's: the copy of turn k + 1 into its pinned buffer is posted behind turn k's before that is joined
+  // (grains of 4 MiB from a shared counter: no fill thread waits at a turn's end), the pinned ring free again once uploaded
+  const std::string none;
+  size_t m = 0, m_next = 0;
+  uint8_t* buf = nullptr;
+  int st = CP2_OK;
+  if (n) {
+    m = ingest_turn_cells(g, pipe.chunk, 1, pipe.turn, 0);
+    st = pipe.acquire(&buf);
+    if (st == CP2_OK) pipe.fill_begin(g, none, 0, m, buf, false, cells);
   }
+  for (size_t c0 = 0; st == CP2_OK && c0 < n; c0 += m, m = m_next) {
+    const size_t c1 = c0 + m;
+    if (c1 < n && pipe.pin_depth >= 2) {
+      m_next = ingest_turn_cells(g, pipe.chunk, 1, pipe.turn + 1, c1);
+      st = pipe.acquire(&buf, 1);
+      if (st == CP2_OK) pipe.fill_begin(g, none, c1, m_next, buf, false, cells + c1 * cell_size);
+    }
+    if (st == CP2_OK) st = pipe.fill_join();
+    if (st == CP2_OK) st = pipe.submit(m, cell_size, d_leaves + c0 * 32);
+  }
+  pipe.fill_join_all();
+  if (st != CP2_OK) return st;
   return pipe.finish();   // the pipe's destructor waits for the streams
 }
 

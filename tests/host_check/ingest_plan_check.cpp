@@ -4,7 +4,7 @@
 // group sizes -- walk the turns exactly as the builder does and check what a GPU run can only check by faulting or by a wrong root:
 //   turns    every turn is non-empty, fits its ring buffer, starts where the previous one ended, ends on a slot boundary whenever one
 //            is in reach; the turns add up to the batch
-//   pieces   the fill threads' byte ranges tile the turn's buffer; the pieces of every range tile the range; every piece lies inside
+//   pieces   the fill grains tile the turn's buffer; the pieces of every grain tile the grain; every piece lies inside
 //            ONE unit's byte range of ONE file; every byte of the buffer comes from the file byte slot.nim:57-68 reads for that cell
 //            (recomputed independently); small shapes are written into a real buffer of exactly the turn's size (AddressSanitizer
 //            sees any byte outside it) and every byte is written exactly once
@@ -94,13 +94,11 @@ static long check_shape(const Shape& s, long* pieces_out, long* bytes_checked) {
     if (u0 > u1 || u1 >= g.n_units || u0 != c0 / g.n_cells) fail(s, "turn's unit range", turns, c0, m);
     // ---- the fill: ranges tile the buffer, pieces tile the ranges
     const size_t nbytes = m * g.cell_size;
-    // two ways the product cuts a turn's bytes: grains from a shared counter (slot files: fill_begin / fill_grains) and equal ranges,
-    // one per thread (host arrays: parallel_ranges); a shape walks one of them, grains also far below the product's 4 MiB so that
-    // small shapes split
+    // the product cuts a turn's bytes into grains taken from a shared counter (fill_begin / fill_grains); the walk also uses grains far
+    // below the product's 4 MiB so that small shapes split
     const size_t align = (s.cell_multiple > 1) ? 4096 : 1;
-    const bool by_grains = (rnd() & 1) != 0;
-    const size_t grain = by_grains ? std::max<size_t>(std::max<size_t>(align, (nbytes / 512 + align - 1) / align * align), (INGEST_FILL_GRAIN >> (rnd() % 14)) / align * align) : 0;   // (at most ~512 grains per turn: the walk stays short)
-    const int nt = by_grains ? (int)ingest_grain_count(nbytes, grain) : ingest_fill_threads(nbytes, ((size_t)2 << 20) >> (rnd() % 12), s.threads);
+    const size_t grain = std::max<size_t>(std::max<size_t>(align, (nbytes / 512 + align - 1) / align * align), (INGEST_FILL_GRAIN >> (rnd() % 14)) / align * align);   // (at most ~512 grains per turn: the walk stays short)
+    const int nt = (int)ingest_grain_count(nbytes, grain);
     const bool real = nbytes <= ((size_t)1 << 14);
     std::vector<uint8_t> buf, hits;
     if (real) { buf.assign(nbytes, 0); hits.assign(nbytes, 0); }
@@ -108,8 +106,7 @@ static long check_shape(const Shape& s, long* pieces_out, long* bytes_checked) {
     if (INGEST_FILL_GRAIN % 4096) fail(s, "the fill grain is not a multiple of the O_DIRECT granule", turns, c0, m);
     for (int t = 0; t < nt; ++t) {
       size_t a = 0, b = 0;
-      if (by_grains) ingest_grain(nbytes, grain, (size_t)t, &a, &b);
-      else { a = ingest_range_cut(nbytes, align, nt, t); b = ingest_range_cut(nbytes, align, nt, t + 1); }
+      ingest_grain(nbytes, grain, (size_t)t, &a, &b);
       if (a != prev_end || b < a || b > nbytes) fail(s, "fill ranges do not tile the turn's buffer", turns, c0, m);
       if (t > 0 && a % align) fail(s, "inner fill boundary off the O_DIRECT granule", turns, c0, m);
       prev_end = b;
