@@ -24,6 +24,8 @@ repeats = int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4] != "-" else 3
 ENTROPY, SEED, CS = 1234567, 12345, 2048
 thr = int(os.environ.get("SFAB_THREADS", "0")) or max(1, min(16, len(os.sched_getaffinity(0))))   # formatting threads (SFAB_THREADS: sweeps)
 ctx = pkg.Context(0)
+if os.environ.get("SFAB_KEEP"):                          # what the datasets keep of their trees: 1 every node, 2 compact, 0 roots only (default: the library's choice)
+    ctx.set_keep_trees(int(os.environ["SFAB_KEEP"]))
 dev = torch.device("cuda", 0)
 
 
