@@ -375,24 +375,24 @@ extern "C" int cp2_slot_trees_build_dev(cp2_ctx* ctx, const void* d_cells, size_
 }
 
 // ---- streaming ingestion ----------------------------------------------------
-// Overlapped stages: host threads fill a PINNED buffer (pread or memcpy), the copy engine moves it into a DEVICE buffer,
-// one of the context's two hashing streams hashes it (the upload rides on that same stream, ahead of its kernel: upload_stream).  While chunk i is copied and hashed the host is already filling chunk
-// i+1 (and i+2), so disk / host memory, PCIe and the GPU work concurrently (the reference re-opens the slot file and reads one
-// cell per call, slot.nim:57-68).  Fill threads, ring depth and chunk size are run-time knobs: cp2_set_ingest, or
-// CP2_INGEST_THREADS / CP2_INGEST_RING / CP2_INGEST_CHUNK_MB.
+// Overlapped stages: host threads fill a PINNED buffer (pread or memcpy), the copy engine moves it into a DEVICE buffer, one of
+// the context's two hashing streams hashes it.  While chunk i is uploaded and hashed the host is already filling chunks i + 1 and
+// i + 2, so disk / host memory, PCIe and the GPU work concurrently (the reference re-opens the slot file and reads one cell per
+// call, slot.nim:57-68).  Fill threads, ring depth and chunk size are run-time knobs: cp2_set_ingest, or CP2_INGEST_THREADS /
+// CP2_INGEST_RING / CP2_INGEST_CHUNK_MB.
 //
 // Chunk size is what matters (measured, tools/ingest_probe.cpp, profiles/r02_ingest_probe.txt): the hash kernel runs
 // one CELL per lane, so a 64 MiB chunk of 2 KiB cells is 128 workgroups on a GPU that holds 768 of them -- the kernel
 // then takes the lifetime of one workgroup (3.75 ms) whatever its size, and the pipe ran at 17 GB/s although host
 // memcpy (130 GB/s on 8 threads), pinned H2D (56 GB/s) and the kernel from HBM (43 GB/s) are each far faster.  The
-// default chunk is therefore one full residency of the kernel: 768 workgroups x 256 cells (384 MiB at 2 KiB cells).
+// default chunk is therefore a whole number of residencies of the kernel (wanted_chunk_bytes).
 //
-// Round 6: (1) a chunk is a range of the BATCH's cells and may span many slot files (csrc/ingest_turns.hpp: a dataset of 8 MiB
-// slots used to be hashed 16 workgroups at a time); (2) the pinned ring and the device ring are separate: a pinned buffer is free
-// again once its upload is done (~7 ms), not once its chunk is hashed (two chunks are hashed at a time, ~18 ms each), so three
-// pinned buffers keep the host filling while four device buffers hold one chunk landing, two being hashed and one of slack; the
-// upload into a device buffer waits ON THE DEVICE for the kernel that last read it; (3) the pipe can outlive a builder call
-// (BuildScratch::file_pipe): the batches of a transient build then pipeline like the fake-data ones.
+// Round 6 (profiles/r06_streamed_files_ab.txt, r06_streamed_files_trace.txt): (1) a chunk is a range of the BATCH's cells and may
+// span many slot files (csrc/ingest_turns.hpp: a dataset of 8 MiB slots used to be hashed 16 workgroups at a time); (2) the pinned
+// ring (3 buffers, free again once uploaded) is apart from the device ring (4); (3) fills are posted two turns deep in 4 MiB grains
+// (fill_begin / fill_join); (4) a turn's upload rides on its own hashing stream, ahead of its kernel (upload_stream: a separate copy
+// stream shared a hardware queue with the second hashing stream); (5) the pipe can outlive a builder call
+// (BuildScratch::file_pipe): the batches of a transient build pipeline like the fake-data ones.
 namespace {
 
 size_t env_size(const char* name, size_t dflt) {
@@ -455,9 +455,9 @@ struct IngestPipe {
   // 256 cells (one residency: 384 MiB at 2 KiB cells), and, when the launches leave room, 256 CUs x 2 workgroups x 256 cells TWICE
   // (512 MiB).  Every workgroup of a launch runs the same instruction stream for the same time, so a launch costs a whole number of
   // waves of workgroups: round 6's first trace of the streamed build from files showed 768-workgroup launches on the 512 slots a
-  // launch with room has -- two waves for the price of 1.5, 11.6 ms per chunk where 8.9 would do (profiles/r06_streamed_files_trace.txt);
-  // and of the sizes that are whole waves the larger won on the box (one wave 0.76, 1.5 waves 0.83, two waves 0.86 of the fake
-  // source's rate before the fill was rebalanced: fewer turns, fewer joins).
+  // launch with room has -- two waves for the price of 1.5, 11.6 ms per chunk where 8.9 would do (profiles/r06_streamed_files_trace.txt).
+  // On the final library the size matters little (0.949 / 0.946 / 0.972 / 0.972 of the fake source's rate at 256 / 384 / 512 / 1024
+  // MiB); it mattered a lot while every ring turn carried a layer pass of its own (layer_take, csrc/ingest_turns.hpp).
   static size_t wanted_chunk_bytes(const cp2_ctx* c, size_t cell_size, bool leave_room) {
     size_t chunk_bytes = c->ingest_chunk ? c->ingest_chunk : env_size("CP2_INGEST_CHUNK_MB", 0) << 20;
     if (chunk_bytes == 0) chunk_bytes = std::max<size_t>((size_t)64 << 20, std::min<size_t>((size_t)(leave_room ? 1024 : 768) * 256 * cell_size, (size_t)1 << 30));
@@ -550,14 +550,13 @@ struct IngestPipe {
 
   // Bytes [0, m * cell_size) of the turn [c0, c0 + m) of batch `g` into `buf`, from the slot files "<base><slot>.dat", zero-filled
   // past the end of a file (slot.nim:61-66).  The turn is cut into GRAINS of 4 MiB which the fill threads take from a shared counter
-  // (round 6; equal byte ranges, one per thread, before): the formatting threads of a streamed build compete for the same cores, and a
-  // fill thread that loses its core for a scheduler slice used to hold up the whole turn -- 2 ms per turn on configs[3] from files,
-  // whatever the turn's size (tools/streamed_files_ab.py over three chunk sizes).  Every thread walks the pieces of its grain
+  // (round 6; equal byte ranges, one per thread, joined per turn, before): the formatting threads of a streamed build compete for the
+  // same cores, and a fill thread that loses its core for a scheduler slice no longer holds up a whole turn.  Every thread walks the pieces of its grain
   // (ingest_piece) and opens the files it needs itself: nothing is held open between turns, however many files a turn touches.
   // The fill is POSTED and JOINED apart (fill_begin / fill_join), two turns deep: the building thread posts turn k + 1's fill before it
   // joins turn k's, so a worker that finds no grain of turn k left goes straight on to turn k + 1 -- no thread waits at a turn's end
-  // for the slowest one (the joins cost the small-slot build a millisecond per turn while there was one fill at a time) -- and turn
-  // k's scheduling work (layer passes, the caller's sampling hook) runs on the building thread while the workers read.
+  // for the slowest one (16 slots of 8 GiB: 0.96 -> 0.99 of the fake source's rate) -- and turn k's scheduling work (layer passes,
+  // the caller's sampling hook) runs on the building thread while the workers read.
   // O_DIRECT (cp2_set_ingest_direct / CP2_INGEST_DIRECT=1): slot files that are not in the page cache are read straight into
   // the pinned ring, whole 4 KiB blocks, without passing through (and evicting) the page cache; a piece whose file offset or
   // buffer address is not block aligned, the last partial block of a piece, and a file system that refuses O_DIRECT (tmpfs)
