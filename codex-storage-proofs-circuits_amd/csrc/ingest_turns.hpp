@@ -35,7 +35,8 @@ inline size_t layer_take(size_t complete, size_t built, size_t group, bool take_
     size_t want = group;
     if (ramp_min && n_slots > built) {
       const size_t left = n_slots - built;
-      if (left < 2 * group) want = left > ramp_min ? std::max(std::min(ramp_min, group), (left + 1) / 2) : left;
+      // (a remainder of up to half a ramp_min goes into the last pass rather than into one of its own: a pass has a fixed cost)
+      if (left < 2 * group) want = left > ramp_min + ramp_min / 2 ? std::max(std::min(ramp_min, group), (left + 1) / 2) : left;
       if (want > group) want = group;
     }
     if (want && avail >= want) return want;

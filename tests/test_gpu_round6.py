@@ -53,17 +53,20 @@ def file_cases(oracle, tmp_path_factory):
 
 
 @pytest.mark.parametrize("how", ["ring", "direct", "mapped"])
-@pytest.mark.parametrize("name", ["A", "B"])
+@pytest.mark.parametrize("name", ["A", "A12", "B"])
 def test_streamed_from_slot_files_every_input_json_vs_oracle(pkg, file_cases, name, how):
     """cp2_dataset_build_streamed + export from slot files, EVERY slot's input.json byte for byte against the oracle: turns of many
-    files (A) and slots of several turns (B), through the pinned ring, with O_DIRECT, and uploaded from mappings of the files."""
-    c, base, chunk, want = file_cases[name]
+    files (A: passes of 4 slots, less than a ring turn's 5; A12: passes of 12 slots = 2.4 ring turns each, three of them and a
+    ramp-down of 7 + 6 at the end) and slots of several turns (B: a pass per slot of 2.67 turns), through the pinned ring, with
+    O_DIRECT, and uploaded from mappings of the files."""
+    group = {"A": 4, "A12": 12, "B": 1}[name]
+    c, base, chunk, want = file_cases[name[0]]
     ctx = pkg.Context(0)
     try:
         ctx.set_ingest(3, 2, chunk)                    # 3 fill threads, the smallest ring (2 pinned + 3 device buffers): every buffer is reused many times
         ctx.set_ingest_direct(1 if how == "direct" else 0)
         ctx.set_ingest_mapped(1 if how == "mapped" else 0)
-        ds = ctx.dataset_streamed(pkg.make_config(**file_config(c, base)), 424243, threads=3, group_slots=4 if name == "A" else 1)
+        ds = ctx.dataset_streamed(pkg.make_config(**file_config(c, base)), 424243, threads=3, group_slots=group)
         assert ds.tree_mode == 1
         ds.export_streamed(None, threads=3)
         got = [ds.streamed_json(s) for s in range(c["nSlots"])]
