@@ -8,7 +8,7 @@
 `python bench.py --gpus N` with N > 1 and no launcher spawns the N rank processes itself (before anything touches the
 GPU) and relays rank 0's JSON line.
 
-Nothing after the timed region can lose the line (section "Orchestration" below): everything after the headline runs under ONE
+Nothing after the timed region can lose the line (bench_orchestration.py; the legs themselves are in bench_legs.py): everything after the headline runs under ONE
 deadline (--extra-budget-s, default 240 s: a leg starts only if its worst case fits what is left, else it is recorded as
 "skipped: budget"); at N > 1 every wait after the headline is a bounded wait on the rendezvous store and the one data-path
 collective of the legs (the gather of slot roots) is bounded too, so a dead or hung rank costs seconds and is named in
@@ -37,7 +37,8 @@ The JSON line also carries
   cpu_baseline  the C oracle (a port of the same algorithm, NOT the Nim binary: no Nim toolchain exists)
                 timed on this box's host cores on a bounded sample, rank 0 at N=1 only.
   extra         config 3 (8 GiB slot -> slot root), config 4 (4096 slots -> 4096 input.json texts: witnesses/s, classic
-                and streamed), ingestion rates against the measured pinned H2D peak, and config 5's shape at SURVEY.md 8(d)'s
+                and streamed; `witnesses_from_files`: the same 4096 slots written as real slot files and read back from the
+                page cache), ingestion rates against the measured pinned H2D peak, and config 5's shape at SURVEY.md 8(d)'s
                 stated scale-down (32 768 slots x 2^12 cells sharded over the ranks, one gather of slot roots, dataset tree
                 of 15 levels, one proof input per rank) at every N including 1; the same shape through the C ABI's own
                 multi-GPU entry points in ONE process (cp2_multi_*: what the cli twin / a Nim caller gets, `dataset_inprocess`;

@@ -448,7 +448,7 @@ LEG_WORST_S = {
     "slot_root": lambda w: 15.0,
     "witnesses": lambda w: 40.0,
     "ingest": lambda w: 70.0,
-    "witnesses_from_files": lambda w: 75.0,
+    "witnesses_from_files": lambda w: 60.0,
     "dataset": lambda w: 15.0 + 15.0 / w,
     "dataset_big_slots": lambda w: 15.0 + 10.0 / w,
     "dataset_inprocess": lambda w: 15.0 + 20.0 / w,          # per child process (main / rccl / copy / host / few)
