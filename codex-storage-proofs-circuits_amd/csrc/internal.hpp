@@ -45,7 +45,7 @@ int device_free_bytes(size_t* out);
 // touches them is in flight (DevBuf / PinBuf synchronise the context's stream first).  Thread-safe.
 class BlockPool {
  public:
-  static constexpr size_t MAX_CACHED_DEV = (size_t)6 << 30, MAX_CACHED_PIN = (size_t)3 << 30;
+  static constexpr size_t MAX_CACHED_DEV = (size_t)6 << 30, MAX_CACHED_PIN = (size_t)4 << 30;
   ~BlockPool() { trim(); }
   // returns nullptr on failure; *got = usable size (>= n)
   void* get(bool pinned, size_t n, size_t* got) {

@@ -452,15 +452,16 @@ struct IngestPipe {
   }
   // what a ring buffer of this context holds, in bytes (before it is clipped to the batch)
   // Default: a whole number of residencies of the hash kernel at the occupancy it will be launched with -- 256 CUs x 3 workgroups x
-  // 256 cells (one residency: 384 MiB at 2 KiB cells), and, when the launches leave room, 256 CUs x 2 workgroups x 256 cells TWICE
-  // (512 MiB).  Every workgroup of a launch runs the same instruction stream for the same time, so a launch costs a whole number of
+  // 256 cells (one residency: 384 MiB at 2 KiB cells), and, when the launches leave room, 256 CUs x 2 workgroups x 256 cells THREE
+  // times (768 MiB: also two residencies at full occupancy).  Every workgroup of a launch runs the same instruction stream for the same time, so a launch costs a whole number of
   // waves of workgroups: round 6's first trace of the streamed build from files showed 768-workgroup launches on the 512 slots a
   // launch with room has -- two waves for the price of 1.5, 11.6 ms per chunk where 8.9 would do (profiles/r06_streamed_files_trace.txt).
-  // On the final library the size matters little (0.949 / 0.946 / 0.972 / 0.972 of the fake source's rate at 256 / 384 / 512 / 1024
-  // MiB); it mattered a lot while every ring turn carried a layer pass of its own (layer_take, csrc/ingest_turns.hpp).
+  // With passes of a group the size matters far less than while every ring turn carried a layer pass of its own (layer_take,
+  // csrc/ingest_turns.hpp), but it still shows: 0.949 / 0.946 / 0.972 of the fake source's rate at 256 / 384 / 512 MiB, and in three
+  // alternating rounds on one box 0.973-0.980 at 512, 0.997-0.998 at 768 (16 slots of 8 GiB: 1.004 and 1.013).
   static size_t wanted_chunk_bytes(const cp2_ctx* c, size_t cell_size, bool leave_room) {
     size_t chunk_bytes = c->ingest_chunk ? c->ingest_chunk : env_size("CP2_INGEST_CHUNK_MB", 0) << 20;
-    if (chunk_bytes == 0) chunk_bytes = std::max<size_t>((size_t)64 << 20, std::min<size_t>((size_t)(leave_room ? 1024 : 768) * 256 * cell_size, (size_t)1 << 30));
+    if (chunk_bytes == 0) chunk_bytes = std::max<size_t>((size_t)64 << 20, std::min<size_t>((size_t)(leave_room ? 1536 : 768) * 256 * cell_size, (size_t)1 << 30));
     return chunk_bytes;
   }
   int init(cp2_ctx* c, size_t cell_size, size_t max_cells, bool leave_room = false) {

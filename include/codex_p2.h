@@ -99,7 +99,8 @@ int cp2_check_environment(char* msg, size_t msg_len);
  * SlotFile data source (the reference reads one cell per call, reference/nim/proof_input/src/slot.nim:57-68):
  * host threads filling the pinned ring, ring depth (2..8) and bytes per chunk.  0 = keep the default
  * (environment CP2_INGEST_THREADS / CP2_INGEST_RING / CP2_INGEST_CHUNK_MB, else 8 threads, depth 3 and one full
- * residency of the hash kernel per chunk: 768 x 256 cells, 384 MiB at 2 KiB cells).  `ring_depth` pinned host buffers
+ * residency of the hash kernel per chunk: 768 x 256 cells, 384 MiB at 2 KiB cells; the streamed builds, whose launches leave room
+ * for their small kernels, take 768 MiB: three waves of workgroups at that occupancy).  `ring_depth` pinned host buffers
  * (free again as soon as their upload is done) feed ring_depth + 1 device buffers (one landing, two being hashed, slack).
  * A chunk is a range of the BATCH's cells: it holds many small slot files, or a piece of a large one. */
 int cp2_set_ingest(cp2_ctx* ctx, int fill_threads, int ring_depth, size_t chunk_bytes);
@@ -119,7 +120,7 @@ int cp2_set_ingest_direct(cp2_ctx* ctx, int on);
  * Not used together with O_DIRECT. */
 int cp2_set_ingest_mapped(cp2_ctx* ctx, int on);
 /* Memory a long-lived context holds.  Scratch blocks (device staging, pinned landing zones) are cached per context so that
- * repeated calls stop allocating: up to 6 GiB of device memory and 3 GiB of PINNED host memory stay with the context after
+ * repeated calls stop allocating: up to 6 GiB of device memory and 4 GiB of PINNED host memory stay with the context after
  * the calls that needed them.  cp2_trim waits for the context's streams and gives all cached blocks back to the system
  * (blocks still referenced by live proof inputs return when those are freed); the next call allocates again. */
 int cp2_trim(cp2_ctx* ctx);

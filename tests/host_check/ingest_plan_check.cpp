@@ -179,7 +179,7 @@ int main(int argc, char** argv) {
   // the shapes the round's measurements run, literally: configs[3]'s scale-down and nominal slots, default ring slot
   {
     Shape s{};
-    s.g.n_units = 4096; s.g.n_cells = 4096; s.g.cell_size = 2048; s.chunk_bytes = (size_t)512 << 20; s.cell_multiple = 1; s.group = 256; s.take_all = false; s.ramp = true; s.threads = 8;
+    s.g.n_units = 4096; s.g.n_cells = 4096; s.g.cell_size = 2048; s.chunk_bytes = (size_t)768 << 20; s.cell_multiple = 1; s.group = 256; s.take_all = false; s.ramp = true; s.threads = 8;
     turns += check_shape(s, &pieces, &bytes); ++shapes;
     s.g.n_units = 4; s.g.n_cells = (size_t)1 << 22; s.cell_multiple = 2; s.group = 1;
     turns += check_shape(s, &pieces, &bytes); ++shapes;

@@ -2,7 +2,7 @@
 import glob, json, os, re, sys
 d = sys.argv[1]
 order = [("ab_small_shm_r05.txt", "configs[3]'s scale-down as 4096 slot files of 8 MiB in /dev/shm (tmpfs: its pages ARE page cache) -- ROUND 5's library (commit c7434d0), CODEX_P2_LIB override"),
-         ("ab_small_shm.txt", "the same files' shape, this round's library, defaults (512 MiB turns with room, fills two turns deep, uploads on the hashing streams, passes of a group)"),
+         ("ab_small_shm.txt", "the same files' shape, this round's library, defaults AT THAT TIME (512 MiB turns with room; 768 since: the last section, fills two turns deep, uploads on the hashing streams, passes of a group)"),
          ("ab_small_tmp.txt", "the same on the box's disk-backed /tmp (files just written: in the page cache)"),
          ("ab_small_shm_chunk256.txt", "CP2_INGEST_CHUNK_MB=256 (one wave of workgroups per launch with room)"),
          ("ab_small_shm_chunk384.txt", "CP2_INGEST_CHUNK_MB=384 (1.5 waves)"),
