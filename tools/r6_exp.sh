@@ -1,15 +1,23 @@
-# round 6: the default turn size of builds whose launches leave room -- 512 (2 waves of 512 workgroups), 768 (3), 1024 (4) MiB -- three rounds, alternating, one box
+# experiment: tail kernels (k_compress_layer, k_sample_paths) capped at 80 VGPRs so that they fit beside THREE hash waves per SIMD -- is the room still needed?
 set -o pipefail
-O=gpurun_out/r6exp2
+O=gpurun_out/r6exp3
 mkdir -p $O
-for round in 1 2 3; do for mb in 512 768 1024; do
-  CP2_INGEST_CHUNK_MB=$mb timeout -k 10 300 python tools/streamed_files_ab.py /tmp small - 2 > $O/small_${mb}_$round.txt 2>&1 || { tail -5 $O/small_${mb}_$round.txt; exit 1; }
-  echo "round $round, $mb MiB: $(grep '^small file/fake' $O/small_${mb}_$round.txt | cut -c1-48) | $(python3 -c "
+LEAN=$PWD/build/libcodex_p2_lean.so
+for round in 1 2; do
+  timeout -k 10 300 python tools/streamed_files_ab.py /tmp small - 2 > $O/default_$round.txt 2>&1 || exit 1
+  echo "default library, room: $(python3 -c "
 import json
-d=json.loads([l for l in open('$O/small_${mb}_$round.txt') if l.startswith('{')][-1])['small']
-print(d['best_total_s'])")"
-done; done
-for mb in 512 768; do
-  CP2_INGEST_CHUNK_MB=$mb timeout -k 10 500 python tools/streamed_files_ab.py /dev/shm big 16 2 > $O/big_$mb.txt 2>&1 || exit 1
-  echo "big, $mb MiB: $(grep '^big   file/fake' $O/big_$mb.txt | cut -c1-48)"
+d=json.loads([l for l in open('$O/default_$round.txt') if l.startswith('{')][-1])['small']; print(d['best_total_s'], d['plain_tree_build_s'])")"
+  CODEX_P2_LIB=$LEAN timeout -k 10 300 python tools/streamed_files_ab.py /tmp small - 2 > $O/lean_room_$round.txt 2>&1 || exit 1
+  echo "lean tail kernels, room: $(python3 -c "
+import json
+d=json.loads([l for l in open('$O/lean_room_$round.txt') if l.startswith('{')][-1])['small']; print(d['best_total_s'], d['plain_tree_build_s'])")"
+  CODEX_P2_LIB=$LEAN CODEX_P2_TEST_LDS_LIMIT=65536 timeout -k 10 300 python tools/streamed_files_ab.py /tmp small - 2 > $O/lean_noroom_$round.txt 2>&1 || exit 1
+  echo "lean tail kernels, NO room: $(python3 -c "
+import json
+d=json.loads([l for l in open('$O/lean_noroom_$round.txt') if l.startswith('{')][-1])['small']; print(d['best_total_s'], d['plain_tree_build_s'])")"
+  CODEX_P2_TEST_LDS_LIMIT=65536 timeout -k 10 300 python tools/streamed_files_ab.py /tmp small - 2 > $O/default_noroom_$round.txt 2>&1 || exit 1
+  echo "default library, NO room: $(python3 -c "
+import json
+d=json.loads([l for l in open('$O/default_noroom_$round.txt') if l.startswith('{')][-1])['small']; print(d['best_total_s'], d['plain_tree_build_s'])")"
 done
