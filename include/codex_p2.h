@@ -93,7 +93,8 @@ int cp2_device_is_native(const cp2_ctx* ctx);
  *   CODEX_P2_TEST_EXCHANGE_FAULT "hang_init" | "hang_collective" | "init" | "collective" | "corrupt": the multi-device exchange of
  *                        slot roots stalls, fails or delivers wrong rows at that point (cp2_multi_*; anything else: ignored)
  * and the A/B knobs of the measurement tools, read leniently (anything but the value named means "off"): CP2_STREAM_SERIAL=1,
- * CP2_STREAM_RAMP=0, CP2_HASH_BLOCK=64, CP2_TRACE (any value: stage timings on stderr). */
+ * CP2_STREAM_RAMP=0, CP2_HASH_BLOCK=64, CP2_INGEST_COPY_STREAM=1 (the ingestion pipe's uploads on a stream of their own, as until
+ * round 6, instead of on the chunk's own hashing stream), CP2_TRACE (any value: stage timings on stderr). */
 int cp2_check_environment(char* msg, size_t msg_len);
 /* Tuning of the host -> GPU ingestion pipe used by cp2_slot_trees_build_host, cp2_hash_cells (large inputs) and the
  * SlotFile data source (the reference reads one cell per call, reference/nim/proof_input/src/slot.nim:57-68):
@@ -357,7 +358,9 @@ int cp2_dataset_export_proof_inputs(cp2_dataset* ds, const uint64_t* slot_idx, s
                                     const char* dir, int threads, size_t batch, uint64_t* total_bytes);
 /* The whole of `generateProofInputBN254` + `exportProofInputBN254` for EVERY local slot with the entropy known up front
  * (reference/nim/proof_input/src/gen_input/bn254.nim:35-79, json/bn254.nim:57-78), as one overlapped pipeline: slot trees
- * are built `group_slots` at a time (0: what fills the 2 GiB staging chunk), and while later slots are still hashing the
+ * are built `group_slots` at a time (0: what fills the 2 GiB staging chunk; the last groups shrink so that little formatting is
+ * left un-overlapped; with the SlotFile source the slots are read in ring turns of many small files or pieces of large ones, and
+ * the groups are what the layer passes and the sampling are done by), and while later slots are still hashing the
  * finished ones are sampled (sample/bn254.nim:16-27), their paths and cells gathered on the device, downloaded into pinned
  * memory and formatted (cellData + merklePaths) on `threads` host threads.  Only the lines that need all slot roots
  * (dataSetRoot, slotProof: gen_input/bn254.nim:49-51,72) are left for cp2_dataset_export_streamed.  The returned dataset
