@@ -1,4 +1,6 @@
-# experiment: tail kernels (k_compress_layer, k_sample_paths) capped at 80 VGPRs so that they fit beside THREE hash waves per SIMD -- is the room still needed?
+# experiment (profiles/r06_lean_tail_kernels_experiment.txt): tail kernels (k_compress_layer, k_sample_paths) capped at 80 VGPRs so that they fit beside
+# THREE hash waves per SIMD -- is the room still needed?  build/libcodex_p2_lean.so = this library built from a copy of the package whose csrc/kernels.hip has
+# `__attribute__((amdgpu_waves_per_eu(6, 6)))` added to those two kernels (hipcc -Rpass-analysis=kernel-resource-usage: 72 VGPRs / 80 with 14 spilled).
 set -o pipefail
 O=gpurun_out/r6exp3
 mkdir -p $O
