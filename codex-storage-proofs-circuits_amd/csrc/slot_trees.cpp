@@ -471,19 +471,32 @@ struct IngestPipe {
     const int want_dev = std::min(ring + 1, (int)MAX_DEPTH);
     threads = c->ingest_threads ? c->ingest_threads : (int)env_size("CP2_INGEST_THREADS", 8);
     threads = std::max(1, std::min(threads, 64));
-    chunk = ingest_chunk_cells(wanted_chunk_bytes(c, cell_size, leave_room), cell_size, max_cells);
-    cap_bytes = chunk * cell_size;
     hash_stream[0] = ctx->stream;
     CP2_TRY(aux_stream(ctx, &hash_stream[1]));
     separate_copy_stream = env_size("CP2_INGEST_COPY_STREAM", 0) != 0;     // A/B tooling: uploads on a stream of their own, as until round 6
+    // The rings: `ring` pinned + `ring + 1` device buffers of one turn each (2.25 + 3 GiB at the streamed builds' 768 MiB turns).  When
+    // the host or the device cannot give that much (a small box, a shared device, CODEX_P2_MEM_LIMIT_MB), the turn is halved -- down to
+    // 32 MiB -- rather than the build failed: smaller launches are slower, not wrong.
+    size_t want_bytes = wanted_chunk_bytes(c, cell_size, leave_room);
+    for (;;) {
+      chunk = ingest_chunk_cells(want_bytes, cell_size, max_cells);
+      cap_bytes = chunk * cell_size;
+      int st = CP2_OK;
+      for (int b = 0; b < ring && st == CP2_OK; ++b) st = pinned[b].alloc(ctx, cap_bytes);
+      for (int b = 0; b < want_dev && st == CP2_OK; ++b) st = dev[b].scratch(ctx, cap_bytes);
+      if (st == CP2_OK) break;
+      for (int b = 0; b < MAX_DEPTH; ++b) { pinned[b].release(); dev[b].release(); }
+      if (st != CP2_ERR_ALLOC || cap_bytes <= ((size_t)32 << 20) || chunk <= 1) return st;
+      if (std::getenv("CP2_TRACE")) std::fprintf(stderr, "[cp2 trace] ingestion pipe: rings of %d + %d buffers of %zu MiB do not fit (%s): half the turn\n", ring, want_dev, cap_bytes >> 20, ctx->err.c_str());
+      ctx->err.clear();
+      want_bytes = cap_bytes / 2;
+    }
     for (int b = 0; b < ring; ++b) {
-      CP2_TRY(pinned[b].alloc(ctx, cap_bytes));
       CP2_HIP(ctx, hipEventCreateWithFlags(&copied[b], hipEventDisableTiming));
       CP2_HIP(ctx, hipEventRecord(copied[b], ctx->stream));
       pin_depth = b + 1;
     }
     for (int b = 0; b < want_dev; ++b) {
-      CP2_TRY(dev[b].scratch(ctx, cap_bytes));
       CP2_HIP(ctx, hipEventCreateWithFlags(&uploaded[b], hipEventDisableTiming));
       CP2_HIP(ctx, hipEventCreateWithFlags(&hashed[b], hipEventDisableTiming));
       CP2_HIP(ctx, hipEventRecord(hashed[b], ctx->stream));

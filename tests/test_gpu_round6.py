@@ -160,6 +160,16 @@ def test_streamed_build_under_the_ab_knobs_and_without_room(knob_case, env, sour
         assert "leave room: two workgroups per CU" in err, err[-2000:]
 
 
+def test_slot_file_rings_shrink_when_the_device_cannot_hold_them(knob_case):
+    """The ingestion pipe's rings (3 pinned + 4 device buffers of one turn each: 2.4 GiB of device memory for this 600 MiB dataset)
+    under a 1 GiB cap on what the process may hold on the device: the turn is halved until the rings fit -- smaller launches, the same
+    input.json for every slot -- instead of the build failing with CP2_ERR_ALLOC in every residency mode."""
+    base, want = knob_case
+    res, err = run_child({"config": file_config(KNOB_CFG, base), "entropy": 777001, "group": 0, "threads": 4}, CODEX_P2_MEM_LIMIT_MB=1024)
+    assert res["json_sha256"] == want
+    assert "half the turn" in err, err[-3000:]
+
+
 # ---- a collective that does not complete (ADVICE r05, medium) ---------------------------------------------------------------------
 def test_an_exchange_that_times_out_is_final_and_nothing_waits_on_its_streams():
     """Test-only fault "hang_collective": the exchange of slot roots (device-to-device copies between two contexts) is followed, on
