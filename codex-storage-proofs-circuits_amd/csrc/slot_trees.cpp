@@ -27,6 +27,7 @@
 #include "trees.hpp"
 #include "fake_turns.hpp"
 #include "ingest_turns.hpp"
+#include "fill_pipeline.hpp"
 
 using namespace cp2i;
 
@@ -52,7 +53,7 @@ int aux_stream(cp2_ctx* ctx, hipStream_t* out, int which) {
   return CP2_OK;
 }
 
-std::string slot_file_name(const std::string& base, uint64_t slot) { return base + std::to_string(slot) + ".dat"; }   // dataset.nim:34
+std::string slot_file_name(const std::string& base, uint64_t slot) { return fill_slot_file_name(base, slot); }   // dataset.nim:34
 
 void read_file_cell(int fd, size_t cell_size, uint64_t cell, uint8_t* out) {
   size_t done = 0;
@@ -421,7 +422,6 @@ struct IngestPipe {
   size_t pin_turn = 0;                   // ... of which through the pinned ring (pinned buffer = pin_turn % pin_depth)
   int threads = 1;
   bool serial = false;                   // CP2_STREAM_SERIAL=1 (A/B tooling): every chunk hashed on the first stream
-  std::unique_ptr<Workers> pool;
   hipStream_t hash_stream[2] = {nullptr, nullptr};   // chunks alternate between the context's two streams: the next chunk's
                                                      // workgroups fill the CUs as the previous kernel's last ones retire
   int last_aux_dev = -1;                 // device buffer of the latest chunk hashed on the second stream
@@ -502,7 +502,7 @@ struct IngestPipe {
       CP2_HIP(ctx, hipEventRecord(hashed[b], ctx->stream));
       dev_depth = b + 1;
     }
-    if (threads > 1) pool.reset(new Workers(threads - 1));
+    fill.reset(new FillPipeline(threads));
     return CP2_OK;
   }
   // a pipe that outlives builder calls: the next batch's chunk size (its buffers were sized by the first batch)
@@ -562,124 +562,22 @@ struct IngestPipe {
     return hash_turn(d, m, cell_size, leaves_out, leave_room, s, us);
   }
 
-  // Bytes [0, m * cell_size) of the turn [c0, c0 + m) of batch `g` into `buf`, from the slot files "<base><slot>.dat", zero-filled
-  // past the end of a file (slot.nim:61-66).  The turn is cut into GRAINS of 4 MiB which the fill threads take from a shared counter
-  // (round 6; equal byte ranges, one per thread, joined per turn, before): the formatting threads of a streamed build compete for the
-  // same cores, and a fill thread that loses its core for a scheduler slice no longer holds up a whole turn.  Every thread walks the pieces of its grain
-  // (ingest_piece) and opens the files it needs itself: nothing is held open between turns, however many files a turn touches.
-  // The fill is POSTED and JOINED apart (fill_begin / fill_join), two turns deep: the building thread posts turn k + 1's fill before it
-  // joins turn k's, so a worker that finds no grain of turn k left goes straight on to turn k + 1 -- no thread waits at a turn's end
-  // for the slowest one (16 slots of 8 GiB: 0.96 -> 0.99 of the fake source's rate) -- and turn k's scheduling work (layer passes,
-  // the caller's sampling hook) runs on the building thread while the workers read.
-  // O_DIRECT (cp2_set_ingest_direct / CP2_INGEST_DIRECT=1): slot files that are not in the page cache are read straight into
-  // the pinned ring, whole 4 KiB blocks, without passing through (and evicting) the page cache; a piece whose file offset or
-  // buffer address is not block aligned, the last partial block of a piece, and a file system that refuses O_DIRECT (tmpfs)
-  // are read buffered.
-  struct FillJob {
-    IngestGeom g;
-    std::string base;
-    size_t c0 = 0, nbytes = 0, n_grains = 0;
-    uint8_t* buf = nullptr;
-    const uint8_t* mem = nullptr;           // non-null: the turn's bytes are copied from host memory at `mem` (host arrays) instead of read from slot files
-    bool direct = false;
-    std::atomic<size_t> next{0};            // the next grain nobody has taken yet
-    std::mutex mu;
-    std::condition_variable cv;
-    size_t done = 0;                        // grains completed (under mu)
-    std::string first_bad;                  // of the files that cannot be opened, the one of the LOWEST slot (whichever thread met it)
-    uint64_t first_bad_slot = ~0ULL;
-  };
-  std::deque<std::shared_ptr<FillJob>> jobs;   // posted, not yet joined: at most two (the turn about to be shipped and the one after it)
-  static void fill_range(FillJob& job, size_t a, size_t b) {
-    if (job.mem) { std::memcpy(job.buf + a, job.mem + a, b - a); return; }
-    const IngestGeom& g = job.g;
-    uint8_t* buf = job.buf;
-    for (size_t p = a; p < b;) {
-      const IngestPiece q = ingest_piece(g, job.c0, p, b);
-      const std::string fname = slot_file_name(job.base, q.slot);
-      const int fd = open(fname.c_str(), O_RDONLY);
-      if (fd < 0) {
-        {
-          std::lock_guard<std::mutex> lk(job.mu);
-          if (q.slot < job.first_bad_slot) { job.first_bad_slot = q.slot; job.first_bad = fname; }
-        }
-        std::memset(buf + p, 0, q.len);
-        p += q.len;
-        continue;
-      }
-      size_t pos = 0;
-      if (job.direct && q.len >= DIRECT_ALIGN && q.file_off % DIRECT_ALIGN == 0 && reinterpret_cast<uintptr_t>(buf + p) % DIRECT_ALIGN == 0) {
-        const int dfd = open(fname.c_str(), O_RDONLY | O_DIRECT);
-        if (dfd >= 0) {
-          const size_t whole = q.len / DIRECT_ALIGN * DIRECT_ALIGN;
-          while (pos < whole) {
-            const ssize_t r = pread(dfd, buf + p + pos, whole - pos, (off_t)(q.file_off + pos));
-            if (r <= 0) break;
-            pos += (size_t)r;
-            if ((size_t)r % DIRECT_ALIGN) break;   // short, unaligned: end of file (the buffered reads below see that too)
-          }
-          close(dfd);
-        }
-      }
-      while (pos < q.len) {
-        const ssize_t r = pread(fd, buf + p + pos, q.len - pos, (off_t)(q.file_off + pos));
-        if (r <= 0) break;
-        pos += (size_t)r;
-      }
-      if (pos < q.len) std::memset(buf + p + pos, 0, q.len - pos);
-      close(fd);
-      p += q.len;
-    }
-  }
-  static void fill_grains(const std::shared_ptr<FillJob>& job) {   // any thread: grains of this job until none is left
-    size_t mine = 0;
-    for (;;) {
-      const size_t i = job->next.fetch_add(1, std::memory_order_relaxed);
-      if (i >= job->n_grains) break;
-      size_t a = 0, b = 0;
-      ingest_grain(job->nbytes, INGEST_FILL_GRAIN, i, &a, &b);
-      fill_range(*job, a, b);
-      ++mine;
-    }
-    if (mine) {
-      std::lock_guard<std::mutex> lk(job->mu);
-      job->done += mine;
-      if (job->done == job->n_grains) job->cv.notify_all();
-    }
-  }
-  // post the fill of the turn [c0, c0 + m) into `buf`: the workers start on it as soon as they run out of grains of the job before
+  // The fills of the turns (csrc/fill_pipeline.hpp: host threads, grains from a shared counter, two turns deep; no HIP in it -- the CPU
+  // suite runs it against real files under ASan/UBSan and under TSan)
+  std::unique_ptr<FillPipeline> fill;
   void fill_begin(const IngestGeom& g, const std::string& base, size_t c0, size_t m, uint8_t* buf, bool want_direct, const uint8_t* mem = nullptr) {
-    auto job = std::make_shared<FillJob>();
-    job->g = g;
-    job->base = base;
-    job->c0 = c0;
-    job->mem = mem;
-    job->nbytes = m * g.cell_size;
-    job->n_grains = ingest_grain_count(job->nbytes, INGEST_FILL_GRAIN);
-    job->buf = buf;
-    job->direct = want_direct;
-    jobs.push_back(job);
-    if (pool)
-      for (size_t t = 1; t < (size_t)threads && t < job->n_grains; ++t) pool->submit([job] { fill_grains(job); });
+    fill->begin(g, base, c0, m, buf, want_direct, mem);
   }
-  // the OLDEST posted fill is complete (this thread takes grains of it too; the workers may already be on the next job)
   int fill_join() {
-    if (jobs.empty()) return CP2_OK;
-    std::shared_ptr<FillJob> job = jobs.front();
-    jobs.pop_front();
-    fill_grains(job);
-    {
-      std::unique_lock<std::mutex> lk(job->mu);
-      job->cv.wait(lk, [&] { return job->done == job->n_grains; });
-    }
-    if (!job->first_bad.empty()) {
-      ctx->err = "cannot open " + job->first_bad;
+    std::string bad;
+    if (fill && !fill->join(&bad)) {
+      ctx->err = "cannot open " + bad;
       return CP2_ERR_IO;
     }
     return CP2_OK;
   }
   void fill_join_all() {
-    while (!jobs.empty()) (void)fill_join();
+    if (fill) fill->join_all();
   }
 
   // ---- mapped mode (round 5): chunks of a slot file that sit in the PAGE CACHE go to the device without a CPU copy.  The file is
@@ -751,6 +649,7 @@ struct IngestPipe {
   // f(i) for i in [0, n) dealt out over the fill threads (the calling thread takes its share)
   template <typename F> void parallel_items(size_t n, F f) {
     const int nt = (int)std::min<size_t>((size_t)threads, n);
+    Workers* pool = fill ? fill->workers() : nullptr;
     if (nt <= 1 || !pool) { for (size_t i = 0; i < n; ++i) f(i); return; }
     for (int t = 1; t < nt; ++t) pool->submit([=] { for (size_t i = (size_t)t; i < n; i += (size_t)nt) f(i); });
     for (size_t i = 0; i < n; i += (size_t)nt) f(i);

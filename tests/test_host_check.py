@@ -46,6 +46,24 @@ def test_slot_file_builder_plan_and_layer_scheduler_with_sanitizers(tmp_path):
     assert "ingest plan ok: 100000 shapes" in r.stdout, r.stdout
 
 
+def test_fill_pipeline_against_real_files_asan_ubsan_and_tsan(tmp_path):
+    """The host side of the ingestion pipe (csrc/fill_pipeline.hpp, the class IngestPipe itself uses: grains from a shared counter,
+    fills posted two turns deep, workers running on into the next turn while the building thread joins this one) against REAL slot
+    files in a scratch directory -- short files, a missing file (named, lowest slot first), slots cut into units, O_DIRECT requested,
+    the host-array source -- every turn compared with the reference's own read of a cell (slot.nim:57-68).  Built with
+    AddressSanitizer + UBSan (ring buffers of exactly a turn's size) and again with ThreadSanitizer.  No GPU, no HIP."""
+    src = os.path.join(ROOT, "tests", "host_check", "fill_pipeline_check.cpp")
+    inc = "-I" + os.path.join(ROOT, "codex-storage-proofs-circuits_amd", "csrc")
+    for name, flags, shapes in (("asan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"], "150"), ("tsan", ["-fsanitize=thread"], "40")):
+        exe = str(tmp_path / ("fill_pipeline_" + name))
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-Wall", *flags, inc, "-o", exe, src])
+        scratch = tmp_path / ("files_" + name)
+        scratch.mkdir()
+        r = subprocess.run([exe, str(scratch), shapes], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (name, r.stdout[-2000:], r.stderr[-4000:])
+        assert "fill pipeline ok: %s shapes" % shapes in r.stdout and "ThreadSanitizer" not in r.stderr, (name, r.stdout, r.stderr[-2000:])
+
+
 def _build_text_check(pkg, tmp_path, sanitize=("-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"), name="host_text_check"):
     libdir = os.path.dirname(pkg.LIB_PATH)
     exe = str(tmp_path / name)
