@@ -2,7 +2,8 @@
 (CP2_STREAM_SERIAL, CP2_STREAM_RAMP), the staging size and the test hooks are read by the library once per process or per context.
 
   stream_child.py <json>    {"config": {...}, "entropy": int, "group": int, "keep": -1|0|1|2, "threads": int,
-                             "ingest": {"threads": n, "ring": n, "chunk_bytes": n, "direct": 0|1, "mapped": 0|1}}
+                             "ingest": {"threads": n, "ring": n, "chunk_bytes": n, "direct": 0|1, "mapped": 0|1},
+                             "later": {"slot": s, "entropy": e}}
 prints one JSON object: what the dataset kept, the dataset root, sha256 of the slot roots and the sha256 of EVERY slot's input.json."""
 import hashlib
 import json
@@ -30,6 +31,8 @@ def main():
     sha = lambda b: hashlib.sha256(b).hexdigest()   # noqa: E731
     res = {"mode": ds.tree_mode, "dataset_root_hex": ds.root().tobytes()[::-1].hex(), "slot_roots_sha256": sha(ds.local_roots().tobytes()),
            "json_sha256": [sha(ds.streamed_json(s).encode()) for s in range(job["config"]["nSlots"])]}
+    if job.get("later"):         # a proof input for ANOTHER entropy from what the dataset kept (every node / compact layers / roots only)
+        res["later_json_sha256"] = sha(ds.proof_input(job["later"]["slot"], job["later"]["entropy"]).json().encode())
     ds.free()
     ctx.close()
     print(json.dumps(res), flush=True)

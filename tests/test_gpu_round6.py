@@ -78,12 +78,14 @@ def test_streamed_from_slot_files_every_input_json_vs_oracle(pkg, file_cases, na
 
 
 @pytest.mark.parametrize("keep", [2, 0])
-def test_streamed_from_slot_files_transient_batches_pipeline(pkg, file_cases, keep):
+def test_streamed_from_slot_files_transient_batches_pipeline(pkg, oracle, file_cases, keep):
     """Compact / roots-only streamed builds from slot files: several batches through ONE ingestion pipe and two node buffers (round 6;
     a pipe per batch, drained, before).  A fresh process with a 1 MiB staging size: 37 slots go in three batches.  Every input.json
     equals the oracle's, and the kept layers answer for a later entropy."""
     c, base, chunk, want = file_cases["A"]
-    job = {"config": file_config(c, base), "entropy": 424243, "group": 4, "keep": keep, "threads": 3, "ingest": {"threads": 3, "ring": 2, "chunk_bytes": chunk, "direct": 0, "mapped": 0}}
+    C, P = oracle
+    job = {"config": file_config(c, base), "entropy": 424243, "group": 4, "keep": keep, "threads": 3, "ingest": {"threads": 3, "ring": 2, "chunk_bytes": chunk, "direct": 0, "mapped": 0},
+           "later": {"slot": 29, "entropy": 31337}}
     clean = {k: v for k, v in os.environ.items() if not k.startswith("CODEX_P2_") and not k.startswith("CP2_")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "stream_child.py"), json.dumps(job)], capture_output=True, text=True, timeout=900,
                        env=dict(clean, CODEX_P2_STAGE_MB="1", CP2_TRACE="1"))
@@ -92,6 +94,7 @@ def test_streamed_from_slot_files_transient_batches_pipeline(pkg, file_cases, ke
     assert res["mode"] == keep
     assert res["json_sha256"] == [sha(t) for t in want]
     assert "37 of 37 slots enqueued" in r.stderr, r.stderr[-2000:]
+    assert res["later_json_sha256"] == sha(P.export_json(expected_proof_input_fast(C, P, c, 29, 31337, threads=8)))   # (sampled cells read from the files)
 
 
 def test_short_and_missing_slot_files(pkg, oracle, tmp_path):
