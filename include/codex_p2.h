@@ -103,7 +103,9 @@ int cp2_check_environment(char* msg, size_t msg_len);
  * residency of the hash kernel per chunk: 768 x 256 cells, 384 MiB at 2 KiB cells; the streamed builds, whose launches leave room
  * for their small kernels, take 768 MiB: three waves of workgroups at that occupancy).  `ring_depth` pinned host buffers
  * (free again as soon as their upload is done) feed ring_depth + 1 device buffers (one landing, two being hashed, slack).
- * A chunk is a range of the BATCH's cells: it holds many small slot files, or a piece of a large one. */
+ * A chunk is a range of the BATCH's cells: it holds many small slot files, or a piece of a large one.  Memory: ring_depth x chunk of
+ * pinned host memory + (ring_depth + 1) x chunk of device memory while a build runs (2.25 + 3 GiB at the streamed builds' default),
+ * cached by the context afterwards (cp2_trim); when the host or the device cannot give that much the chunk is halved until it fits. */
 int cp2_set_ingest(cp2_ctx* ctx, int fill_threads, int ring_depth, size_t chunk_bytes);
 /* SlotFile source: read the slot files with O_DIRECT (block-aligned requests straight into the pinned ring, no page-cache copy
  * and no eviction of what the cache holds): for files that are NOT cached -- a cached file reads faster through the cache.
