@@ -95,6 +95,26 @@ def shape(label, n_slots, n_cells, max_log2):
         print("%-5s plain tree build (no proof inputs): file %s s, fake %s s -> file/fake rate %.4f" %
               (label, [round(x, 4) for x in plain["file"]], [round(x, 4) for x in plain["fake"]], min(plain["fake"][1:]) / min(plain["file"][1:])), flush=True)
         res["plain_tree_build_s"] = {k: round(min(v[1:]), 4) for k, v in plain.items()}
+        # COLD files (SFAB_COLD=1; a disk-backed directory): every slot file evicted from the page cache (fsync + POSIX_FADV_DONTNEED) before
+        # each build; buffered reads, then O_DIRECT straight into the pinned ring -- what the box's storage delivers, not the pipe
+        if os.environ.get("SFAB_COLD"):
+            def evict():
+                for k in range(n_slots):
+                    fd = os.open("%s%d.dat" % (base, k), os.O_RDONLY)
+                    os.fsync(fd)
+                    os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+                    os.close(fd)
+            cold = {}
+            for how, direct in (("buffered", 0), ("o_direct", 1), ("buffered_again", 0), ("o_direct_again", 1)):
+                evict()
+                ctx.set_ingest_direct(direct)
+                x = one(cfg_file, n_slots, check)
+                cold[how] = round(x["total_s"], 4)
+                ok_cold = x["root"] == runs["fake"][-1]["root"] and x["texts"] == runs["fake"][-1]["texts"]
+                print("%-5s COLD files, %s: total %.4f s -> %.1f witnesses/s, %.2f GB/s of cells; texts equal the fake source's: %s" %
+                      (label, how, x["total_s"], n_slots / x["total_s"], n_slots * n_cells * CS / x["total_s"] / 1e9, ok_cold), flush=True)
+            ctx.set_ingest_direct(-1)
+            res["cold_files_total_s"] = cold
         same = all(a["root"] == b["root"] and a["roots_sha"] == b["roots_sha"] and a["texts"] == b["texts"] and a["json_bytes"] == b["json_bytes"]
                    for a in runs["file"] for b in runs["fake"])
         best = {s: min(x["total_s"] for x in runs[s][1:]) for s in runs}
